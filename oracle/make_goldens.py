@@ -1,0 +1,259 @@
+"""Generates tests/golden/*.npz by running the REAL reference (read-only tree at /root/reference) on
+CPU through oracle/ref_shims.py.  Build-container only; the outputs are small data fixtures (inputs
+are regenerated from seeds by lsdm_amd/synthetic.py; files hold expected outputs, taps and RNG draws).
+
+    python -m oracle.make_goldens [--only g1,g2,g3,g4,g5,long] [--long-steps 1000]
+
+Golden sets:
+  G1  schedule tables: cosine-1000 and the ddim50 / ddim250 respaced processes (float64).
+  G2  one SceneDiffusionModel.forward, B=3 ragged masks, C in {13, 43}: outputs + module taps.
+  G3  PointNet++ known answers on 3 clouds (one all-zero): FPS / ball-query / 3-NN indices, features.
+  G4  short p_sample_loop chains (skip_timesteps = 1000-K) with per-step samples; B in {1,3,16}.
+  G5  DDIM-50: reference p_mean_variance + the arithmetic of gaussian_diffusion.py:790-811.
+  long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shims  # noqa: E402
+
+SDM, mu, clip = ref_shims.import_reference()
+import torch  # noqa: E402
+from diffusion import gaussian_diffusion as gd  # noqa: E402  (reference module)
+from diffusion.respace import SpacedDiffusion, space_timesteps  # noqa: E402
+import model.pcd_backbone.pointnet2_utils as pnu  # noqa: E402
+from lsdm_amd.synthetic import make_synthetic_state_dict, make_synthetic_batch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def ref_model(max_cats, seed=0):
+    kw = mu.get_default_model_proxd()
+    kw["max_cats"] = max_cats
+    m = SDM(**kw, use_cuda=False).eval()
+    m.load_state_dict(make_synthetic_state_dict(seed=seed, max_cats=max_cats))
+    return m
+
+
+def ref_diffusion(respacing=None):
+    """util/model_util.py:127-163 with an explicit timestep_respacing."""
+    betas = gd.get_named_beta_schedule("cosine", 1000, 1.0)
+    return SpacedDiffusion(
+        use_timesteps=space_timesteps(1000, respacing if respacing else [1000]), betas=betas,
+        model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+        loss_type=gd.LossType.MSE, rescale_timesteps=False, lambda_vel=0.0, lambda_rcxyz=0.0, lambda_fc=0.0,
+        lambda_cat=0.1)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if v.dtype == np.int64 and v.size > 16 and v.max(initial=0) < 32767 and v.min(initial=0) >= 0:
+            v = v.astype(np.int16)
+        conv[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def g1():
+    out = {}
+    for tag, resp in (("t1000", None), ("ddim50", "ddim50"), ("ddim250", "ddim250")):
+        d = ref_diffusion(resp)
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "posterior_variance",
+                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod"):
+            out["%s.%s" % (tag, k)] = getattr(d, k)
+        out["%s.timestep_map" % tag] = np.asarray(d.timestep_map, dtype=np.int64)
+    save("g1_schedule", **out)
+
+
+def g2():
+    for C in (13, 43):
+        m = ref_model(C)
+        taps = {}
+        hooks = [
+            m.pcd_backbone.register_forward_hook(lambda mod, i, o: taps.__setitem__("pcd", o)),
+            m.human_backbone.register_forward_hook(lambda mod, i, o: taps.__setitem__("hm", o)),
+            m.pcd_attention.register_forward_hook(lambda mod, i, o: taps.__setitem__("o_rows", o[0])),
+            m.attn_layer.register_forward_hook(lambda mod, i, o: taps.__setitem__("w", o[1])),
+            m.translation_layer.register_forward_hook(lambda mod, i, o: taps.__setitem__("tr", o)),
+            m.embed_text.register_forward_hook(lambda mod, i, o: taps.__setitem__("enc", o)),
+            m.embed_cat.register_forward_hook(lambda mod, i, o: taps.__setitem__("ecat", o)),
+            m.embed_timestep.register_forward_hook(lambda mod, i, o: taps.__setitem__("ets", o)),
+            m.upsampling_layer.register_forward_hook(lambda mod, i, o: taps.__setitem__("e", o)),
+            m.combine_extraction.register_forward_hook(lambda mod, i, o: taps.__setitem__("emb", o)),
+        ]
+        B = 3
+        bt = make_synthetic_batch(B, seed=5, max_cats=C)
+        torch.manual_seed(11)
+        x = torch.randn(B, 1024, 3)
+        x_in = x.clone()
+        t = torch.tensor([987, 500, 3])
+        clip._model.features = bt["text_features"]
+        torch.manual_seed(12)
+        starts = [torch.randint(0, n, (B * 9,)) for n in (1024, 1024, 256, 64)]
+        torch.manual_seed(12)
+        out_cat, out = m(x, bt["mask"], t, bt["given_objs"], bt["given_cats"], y=["p"] * B)
+        for h in hooks:
+            h.remove()
+        o_rows = taps["o_rows"].view(B, 9, 1024, 12)
+        assert (o_rows - o_rows[:, :, :1]).abs().max().item() == 0.0  # Q7
+        save("g2_forward_c%d" % C, x_in=x_in, t=t, starts=torch.stack([s for s in starts]),
+             out_cat=out_cat, out=out, guiding=m.saved_guiding_points, x_mut=x,
+             pcd=taps["pcd"].reshape(B, 9, -1), hm=taps["hm"], o=o_rows[:, :, 0], w=taps["w"][:, 0],
+             tr=taps["tr"], enc=taps["enc"], ecat=taps["ecat"], ets=taps["ets"][0],
+             e_sub=taps["e"].permute(0, 2, 1)[:, ::16], emb_sub=taps["emb"][:, ::16])
+
+
+def g3():
+    """Geometry known answers recorded by wrapping the reference's own helper functions."""
+    m = ref_model(13)
+    bb = m.pcd_backbone
+    bt = make_synthetic_batch(2, seed=21, num_objects=3)
+    clouds = torch.stack([bt["given_objs"][0, 0], bt["given_objs"][0, 2], torch.zeros(1024, 3),
+                          bt["given_objs"][1, 1] * 0.3])
+    rec = {"fps": [], "ball": [], "idx3": [], "sqd": []}
+    o_fps, o_ball, o_index, o_sq = pnu.farthest_point_sample, pnu.query_ball_point, pnu.index_points, pnu.square_distance
+
+    def w_fps(xyz, npoint):
+        r = o_fps(xyz, npoint)
+        rec["fps"].append(r.clone())
+        return r
+
+    def w_ball(radius, nsample, xyz, new_xyz):
+        r = o_ball(radius, nsample, xyz, new_xyz)
+        rec["ball"].append(r.clone())
+        return r
+
+    def w_index(points, idx):
+        if idx.dim() == 3 and idx.shape[-1] == 3:
+            rec["idx3"].append(idx.clone())
+        return o_index(points, idx)
+
+    def w_sq(src, dst):
+        r = o_sq(src, dst)
+        rec["sqd"].append(r.clone())
+        return r
+
+    pnu.farthest_point_sample, pnu.query_ball_point, pnu.index_points, pnu.square_distance = w_fps, w_ball, w_index, w_sq
+    feats = {}
+    hooks = []
+    for name in ("sa1", "sa2", "sa3", "sa4"):
+        hooks.append(getattr(bb, name).register_forward_hook(
+            lambda mod, i, o, name=name: feats.__setitem__(name, (o[0].permute(0, 2, 1), o[1].permute(0, 2, 1)))))
+    for name in ("fp4", "fp3", "fp2", "fp1"):
+        hooks.append(getattr(bb, name).register_forward_hook(
+            lambda mod, i, o, name=name: feats.__setitem__(name, o.permute(0, 2, 1))))
+    try:
+        torch.manual_seed(31)
+        starts = [torch.randint(0, n, (clouds.shape[0],)) for n in (1024, 1024, 256, 64)]
+        torch.manual_seed(31)
+        out = bb(clouds)
+    finally:
+        pnu.farthest_point_sample, pnu.query_ball_point, pnu.index_points, pnu.square_distance = o_fps, o_ball, o_index, o_sq
+        for h in hooks:
+            h.remove()
+    arrs = dict(clouds=clouds, starts=torch.stack(starts), out=out)
+    SUB, FSUB = (8, 2, 1, 1), (1, 2, 8, 8)  # point-axis sub-sampling of the stored feature taps
+    for i in range(4):
+        arrs["fps%d" % (i + 1)] = rec["fps"][i]
+        arrs["ball%d" % (i + 1)] = rec["ball"][i]
+        arrs["sa%d_xyz" % (i + 1)] = feats["sa%d" % (i + 1)][0]
+        arrs["sa%d_points" % (i + 1)] = feats["sa%d" % (i + 1)][1][:, ::SUB[i]]
+    for i, name in enumerate(("fp4", "fp3", "fp2", "fp1")):
+        arrs["%s_idx" % name] = rec["idx3"][i]
+        arrs["%s_out" % name] = feats[name][:, ::FSUB[i]]
+    # raw squared distances of the sa3 ball query (64x256) and fp3 (256x64): pins the fp32 rounding sequence
+    arrs["sqd_sa3"] = rec["sqd"][2]
+    arrs["sqd_fp3"] = rec["sqd"][5]
+    save("g3_pointnet", **arrs)
+
+
+def _chain(m, diff, B, C, K, seed, bt_seed, record_every=1):
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
+    clip._model.features = bt["text_features"]
+    samples = []
+    torch.manual_seed(seed)
+    steps = 0
+    for i, out in enumerate(diff.p_sample_loop_progressive(
+            m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], ["p"] * B,
+            clip_denoised=False, skip_timesteps=diff.num_timesteps - K)):
+        if (i % record_every) == record_every - 1 or i == K - 1:
+            samples.append(out["sample"].clone())
+        steps += 1
+    return torch.stack(samples), m.saved_cat.clone(), m.saved_guiding_points.clone()
+
+
+def g4():
+    diff = ref_diffusion()
+    for tag, B, C, K in (("b1", 1, 13, 4), ("b3", 3, 13, 4), ("b16c43", 16, 43, 2)):
+        m = ref_model(C)
+        t0 = time.time()
+        samples, cat, guid = _chain(m, diff, B, C, K, seed=100 + B, bt_seed=40 + B)
+        print("chain %s: %.1f s" % (tag, time.time() - t0))
+        if B == 16:
+            samples = samples[-1:]
+        save("g4_chain_%s" % tag, samples=samples, saved_cat=cat, guiding=guid, meta=np.array([B, C, K, 100 + B, 40 + B]))
+
+
+def g5():
+    """DDIM composed exactly as SURVEY.md A9: the reference's p_mean_variance on the respaced process,
+    followed by the reference's ddim_sample arithmetic (gaussian_diffusion.py:790-811) re-evaluated
+    with the reference's own helpers (eta = 0)."""
+    diff = ref_diffusion("ddim50")
+    B, C, K = 2, 13, 3
+    m = ref_model(C)
+    bt = make_synthetic_batch(B, seed=52, max_cats=C)
+    clip._model.features = bt["text_features"]
+    torch.manual_seed(61)
+    img = torch.randn(B, 1024, 3)
+    samples = []
+    for i in list(range(diff.num_timesteps))[::-1][:K]:
+        t = torch.tensor([i] * B)
+        x = img
+        out = diff.p_mean_variance(m, x, bt["mask"], t, bt["given_objs"], bt["given_cats"], ["p"] * B, clip_denoised=False)
+        eps = diff._predict_eps_from_xstart(x, t, out["pred_xstart"])
+        ab = gd._extract_into_tensor(diff.alphas_cumprod, t, x.shape)
+        abp = gd._extract_into_tensor(diff.alphas_cumprod_prev, t, x.shape)
+        sigma = 0.0 * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        noise = torch.randn_like(x)
+        mean_pred = out["pred_xstart"] * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
+        nz = (t != 0).float().view(-1, 1, 1)
+        img = mean_pred + nz * sigma * noise
+        samples.append(img.clone())
+    save("g5_ddim50", samples=torch.stack(samples), meta=np.array([B, C, K, 61, 52]))
+
+
+def long_chain(steps):
+    diff = ref_diffusion()
+    m = ref_model(13)
+    t0 = time.time()
+    samples, cat, guid = _chain(m, diff, 1, 13, steps, seed=777, bt_seed=70, record_every=100)
+    print("long chain: %.1f s" % (time.time() - t0))
+    save("g4_chain_long_b1", samples=samples, saved_cat=cat, guiding=guid, meta=np.array([1, 13, steps, 777, 70]))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5")
+    ap.add_argument("--long-steps", type=int, default=1000)
+    a = ap.parse_args()
+    todo = a.only.split(",")
+    for name in todo:
+        if name == "long":
+            long_chain(a.long_steps)
+        else:
+            globals()[name]()
