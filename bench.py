@@ -1,0 +1,186 @@
+"""Headline benchmark: denoising-steps/sec of the LSDM sampling loop on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one p_sample iteration (SceneDiffusionModel.forward + posterior update) of the whole per-GPU batch
+(B = 64 chains, 9 slots x 1024 points, C = 13, cosine T = 1000), i.e. BASELINE.json configs[2]'s shapes evaluated in
+fp32 like configs[1] -- the precision every parity test covers (a bf16 number would be a reduced-precision figure).
+Inputs, weights and the RNG draws of the timed steps (host generator, reference order) are resident in HBM before
+the timed region; the K steps run inside ONE C-ABI call (lsdm_sample_steps).  Ranks are independent chain batches
+(seed = base + rank); the only collective is one all-gather of the final samples.
+
+The JSON line also carries
+  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events on the launch stream, live in the timed
+                 region) against the dense fp32 MFMA peak, plus whole-step figures;
+  cpu_baseline : the CPU oracle (oracle/cpu_ref.py, the checker -- never the product) timed on this host's cores on a
+                 bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
+
+
+def cpu_baseline(batch, steps, C):
+    """Times the CPU oracle on `steps` consecutive p_sample steps at a small batch; returns batch-steps/s scaled to B=64."""
+    from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
+    from oracle import cpu_ref
+    torch.set_num_threads(os.cpu_count())
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    bt = make_synthetic_batch(batch, seed=1, max_cats=C, num_objects=8)
+    smp = cpu_ref.Sampler(sd)
+    torch.manual_seed(1)
+    x = torch.randn(batch, 1024, 3)
+    t = torch.tensor([999] * batch)
+    out = smp.p_sample(x, bt["mask"], t, bt["given_objs"], bt["given_cats"], bt["text_features"])  # warm-up
+    t0 = time.time()
+    for k in range(steps):
+        out = smp.p_sample(out["sample"], bt["mask"], t - 1 - k, bt["given_objs"], bt["given_cats"], bt["text_features"])
+    dt = time.time() - t0
+    sample_steps = batch * steps / dt
+    return {"value": sample_steps / 64.0, "unit": "denoising-steps/sec (batch of 64 chains)", "cores": os.cpu_count(),
+            "kind": "port", "sample_steps_per_s": sample_steps,
+            "sample": "%d p_sample steps at B=%d (8 objects, C=%d) with the torch-CPU oracle, %.1f s; scaled to B=64 by /64"
+                      % (steps, batch, C, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.set_grad_enabled(False)
+
+    from lsdm_amd import _lib
+    from lsdm_amd.parallel import gather_samples
+    from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
+    from lsdm_amd.util.model_util import create_model_and_diffusion
+
+    B, K, W, C = a.batch, a.steps, a.warmup, 13
+    model, diffusion = create_model_and_diffusion("proxd", device=local_rank)
+    model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
+    ctx = model._context()
+    model._reserve(B)
+    model._set_schedule((id(diffusion), diffusion.num_timesteps), diffusion._device_tables())
+    bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=a.seed + rank, max_cats=C, num_objects=8).items()}
+    # RNG stream of the reference: x_T, then per step 4 FPS randints + randn, host generator
+    torch.manual_seed(a.seed + rank)
+    x = torch.randn(B, 1024, 3)
+    starts, noise = [], []
+    for _ in range(W + K):
+        starts.append(torch.stack([torch.randint(0, n, (B * 9,), dtype=torch.long) for n in (1024, 1024, 256, 64)]))
+        noise.append(torch.randn(B, 1024, 3))
+    x = x.to(dev).contiguous()
+    starts = torch.stack(starts).to(dev).contiguous()
+    noise = torch.stack(noise).to(dev).contiguous()
+    out_cat = torch.empty(B, 1, C, device=dev)
+    out_x0, out_g = torch.empty_like(x), torch.empty_like(x)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda v: v.data_ptr()
+
+    def run(t_first, k0, k):
+        ctx.call("lsdm_sample_steps", _lib.MODE_P_SAMPLE, 0.0, B, t_first, k, p(x), p(bt["mask"]), p(bt["given_objs"]),
+                 p(bt["given_cats"]), p(bt["text_features"]), p(starts[k0]), p(noise[k0]), p(out_cat), p(out_x0), p(out_g), stream)
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    T = diffusion.num_timesteps
+    log("inputs resident; warm-up %d steps" % W)
+    if W:
+        run(T - 1, 0, W)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    log("timing %d steps" % K)
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    run(T - 1 - W, W, K)
+    gathered = gather_samples(x, dist)          # the path's only collective (RCCL all-gather over xGMI)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    log("timed region %.3f s" % dt)
+    if dist:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
+
+    if rank == 0:
+        units = {"ball": B * 9, "sa_": B * 9, "three": B * 9, "fp_k": B * 9, "fps": B * 9}
+        rows = []
+        for r in prof:
+            if r["launches"] == 0:
+                continue
+            per_launch_units = B * 9 if r["name"][:4] in ("ball", "sa_k", "thre", "fp_k", "fps_") else B
+            avg_ms = r["total_ms"] / r["launches"]
+            flops = 2.0 * r["macs_per_unit"] * per_launch_units
+            rows.append(dict(name=r["name"], avg_ms=avg_ms, launches=r["launches"], tflops=flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                             gflop=flops / 1e9))
+        rows.sort(key=lambda r: -r["avg_ms"])
+        dom = rows[0]
+        step_ms = dt / K * 1e3
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom["name"])
+        res = {
+            "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
+            "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch)",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "sample_steps_per_s": world * B * K / dt,
+            "config": {"workload": "BASELINE configs[2] shapes (B=%d chains/GPU, 8 objects + human x 1024 pts, C=13, cosine T=1000, "
+                                   "p_sample steps t=%d..%d) in fp32 (the parity-tested precision of configs[1]); strict per-step "
+                                   "recompute incl. PointNet++ with host-replayed RNG" % (B, T - 1 - W, T - W - K),
+                       "global_batch": B * world, "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_ms": dom["avg_ms"],
+                         "algorithmic_gflop_per_launch": dom["gflop"],
+                         "whole_step": {"achieved": GFLOP_PER_SAMPLE_STEP * B / step_ms, "frac": GFLOP_PER_SAMPLE_STEP * B / step_ms / PEAK_FP32_MFMA_TFLOPS,
+                                        "note": "14.58 GFLOP per sample-step (SURVEY.md 8d) x B / ms_per_step, TFLOP/s vs fp32 MFMA peak"},
+                         "kernels": [{"name": r["name"], "avg_ms": round(r["avg_ms"], 4), "tflops": round(r["tflops"], 2)} for r in rows]},
+        }
+        if not a.no_cpu_baseline:
+            log("cpu baseline (oracle) ...")
+            res["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, C)
+        print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/* liblsdm_hip -- C ABI of the MI355X (gfx950) implementation of LSDM's denoising sampling path.
+ *
+ * The reference (andvg3/LSDM) is pure Python/PyTorch and has no FFI of its own; the drop-in
+ * boundary at the Python level is SceneDiffusionModel.forward (model/sdm.py:131) and
+ * GaussianDiffusion.p_sample (diffusion/gaussian_diffusion.py:501).  This header is the C boundary underneath the
+ * Python mirror in lsdm_amd/: plain pointers and sizes, no C++ or torch types.  Each entry point names the
+ * reference code it replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative lsdm_status; lsdm_last_error() gives the message.
+ *     Nothing throws across the boundary.
+ *   - the caller allocates every input/output (raw device pointers, e.g. tensor.data_ptr()); the library owns only
+ *     its parameter arena and a workspace inside the context (sized by lsdm_reserve).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous.
+ *   - one context per (process, device); a context is not thread-safe; different contexts are independent.
+ *   - all floating-point tensors are fp32, dense, row-major; timesteps / FPS starts are int64 (torch.long),
+ *     internal index outputs are int32.
+ *   - fixed by the model (model/sdm.py:19-22, pointnet2.py:46-55): 9 object slots, 1024 points per cloud,
+ *     text feature width 512, latent 128.
+ */
+#ifndef LSDM_HIP_H
+#define LSDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lsdm_ctx lsdm_ctx;
+
+typedef enum {
+    LSDM_OK = 0,
+    LSDM_ERR_ARG = -1,      /* bad argument / shape */
+    LSDM_ERR_STATE = -2,    /* call order (parameters not finalised, workspace too small, ...) */
+    LSDM_ERR_HIP = -3,      /* HIP runtime error */
+    LSDM_ERR_PARAM = -4     /* missing or mis-shaped parameter */
+} lsdm_status;
+
+typedef enum {
+    LSDM_MODE_FORWARD = 0,  /* SceneDiffusionModel.forward only                      (model/sdm.py:131-218) */
+    LSDM_MODE_P_SAMPLE = 1, /* forward + ancestral step                 (gaussian_diffusion.py:501-561) */
+    LSDM_MODE_DDIM = 2      /* forward + DDIM step                      (gaussian_diffusion.py:790-811) */
+} lsdm_mode;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------- */
+int lsdm_create(lsdm_ctx** out, int device);
+int lsdm_destroy(lsdm_ctx* ctx);
+/* message of the last failing call on ctx (ctx may be NULL for lsdm_create failures) */
+const char* lsdm_last_error(const lsdm_ctx* ctx);
+
+/* ---- parameters: replaces model.load_state_dict(ckpt['model_state_dict'])  (run/test_sdm.py:124) ---------- */
+/* `name` is a state_dict key of SURVEY.md Appendix A; `data` is a HOST fp32 pointer (num_batches_tracked and the
+ * duplicate pe alias are ignored).  Shapes are checked in lsdm_finalize_params. */
+int lsdm_set_param(lsdm_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
+/* folds eval-mode BatchNorm into the 1x1 convolutions, packs the MFMA operands, uploads.  max_cats = C. */
+int lsdm_finalize_params(lsdm_ctx* ctx, int max_cats);
+/* per-timestep fp32 tables of the (possibly respaced) diffusion process, length T each:
+ * posterior_mean_coef1/2, posterior_log_variance_clipped, sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * alphas_cumprod, alphas_cumprod_prev   (gaussian_diffusion.py:166-202, cast to fp32 as _extract_into_tensor :1594) */
+int lsdm_set_schedule(lsdm_ctx* ctx, int T, const float* coef1, const float* coef2, const float* logvar,
+                      const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* acp, const float* acp_prev);
+/* allocates the workspace for batches up to max_batch samples */
+int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
+
+/* ---- the hot path ---------------------------------------------------------------------------------------- */
+/* One denoising-network evaluation, optionally fused with the sampler update.
+ *   x            (B,1024,3)   in/out: mutated in place, x += g (model/sdm.py:204)
+ *   mask         (B,9)        float 0/1
+ *   t            (B)          int64 timesteps (index into the schedule tables and the pe buffer)
+ *   given_objs   (B,9,1024,3)
+ *   given_cats   (B,9,C)
+ *   text_feat    (B,512)      CLIP encode_text output (the path boundary, model/sdm.py:147)
+ *   fps_start    (4,B*9)      int64 FPS start indices of sa1..sa4 (pointnet2_utils.py:72), ranges 1024,1024,256,64
+ *   noise        (B,1024,3)   randn draw of p_sample (gaussian_diffusion.py:545); may be NULL for LSDM_MODE_FORWARD
+ *   out_cat      (B,1,C)      softmax category prediction (= model.saved_cat)
+ *   out_x0       (B,1024,3)   model output = pred_xstart
+ *   out_guiding  (B,1024,3)   model.saved_guiding_points
+ *   out_sample   (B,1024,3)   x_{t-1}; ignored for LSDM_MODE_FORWARD
+ */
+int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* mask, const int64_t* t,
+              const float* given_objs, const float* given_cats, const float* text_feat, const int64_t* fps_start,
+              const float* noise, float* out_cat, float* out_x0, float* out_guiding, float* out_sample, void* stream);
+
+/* K consecutive ancestral steps t = t_first, t_first-1, ... with device-resident RNG draws; `x` ping-pongs with
+ * an internal buffer and holds the final sample on return.  Replaces the loop body of
+ * p_sample_loop_progressive (gaussian_diffusion.py:736-759) for a fixed batch.
+ *   fps_start_steps (K,4,B*9) int64 ; noise_steps (K,B,1024,3) */
+int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+                      const float* given_objs, const float* given_cats, const float* text_feat,
+                      const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,
+                      float* out_guiding, void* stream);
+
+/* ---- stage entry points (parity tests against the oracle's taps; same kernels the hot path launches) -------- */
+/* farthest_point_sample x4 chained (pointnet2_utils.py:60-81): idx_l (num_clouds,S_l) int32, xyz_l (num_clouds,S_l,3),
+ * S = 1024,256,64,16 */
+int lsdm_fps(lsdm_ctx* ctx, const float* clouds, const int64_t* fps_start, int num_clouds, int32_t* idx1, int32_t* idx2,
+             int32_t* idx3, int32_t* idx4, float* xyz1, float* xyz2, float* xyz3, float* xyz4, void* stream);
+/* query_ball_point (pointnet2_utils.py:84-104): out (num_clouds,S,32) int32; N in {1024,256,64}.  `radius` is a
+ * double like the reference's Python float; radius*radius is rounded to fp32 for the comparison */
+int lsdm_ball_query(lsdm_ctx* ctx, const float* xyz, const float* new_xyz, int num_clouds, int N, int S, double radius,
+                    int32_t* out, void* stream);
+/* 3-NN + inverse-distance weights (pointnet2_utils.py:293-299): idx (num_clouds,N,3) int32, w (num_clouds,N,3) */
+int lsdm_three_nn(lsdm_ctx* ctx, const float* fine, const float* coarse, int num_clouds, int N, int S, int32_t* idx,
+                  float* w, void* stream);
+/* get_backbone.forward (pointnet2.py:61-80): clouds (num_clouds,1024,3) -> out (num_clouds,1024,3) */
+int lsdm_scene_encoder(lsdm_ctx* ctx, const float* clouds, const int64_t* fps_start, int num_clouds, float* out, void* stream);
+/* POSA Decoder.forward (posa_models.py:320-326) on given_objs[:,0]: -> hm (B,1024,3) */
+int lsdm_human_backbone(lsdm_ctx* ctx, const float* given_objs, int B, float* hm, void* stream);
+/* device pointer + element count of a named workspace intermediate of the last call
+ * ("feat1".."feat4","fp4","fp3","fp2","pcd","hm","w","tr","o12","e0","ball1".."ball4","nn_idx1".."nn_idx4") */
+int lsdm_workspace_tensor(lsdm_ctx* ctx, const char* name, void** ptr, int64_t* numel);
+
+/* ---- measurement: per-kernel durations from HIP events recorded on the launch stream ----------------------------- */
+/* After lsdm_profile_begin every launch of the hot path is bracketed by events until lsdm_profile_end, which
+ * synchronises and returns (number of kernels, or < 0): total_ms[k] = summed duration, launches[k] = launch count,
+ * macs_per_unit[k] = algorithmic multiply-accumulates of one launch per cloud (PointNet++ kernels) or per sample
+ * (the others) -- the figures of DESIGN.md / SURVEY.md 8(d).  Arrays must hold `capacity` >= 22 entries. */
+int lsdm_profile_begin(lsdm_ctx* ctx);
+int lsdm_profile_end(lsdm_ctx* ctx, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit);
+const char* lsdm_profile_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSDM_HIP_H */

@@ -1,0 +1,575 @@
+// liblsdm_hip: context, parameter folding/packing, workspace and the extern "C" surface (include/lsdm_hip.h).
+#include "../../include/lsdm_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace lsdm;
+
+namespace {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+thread_local std::string g_create_error;
+
+constexpr int kO = 9, kN = 1024;
+const int kS[4] = {1024, 256, 64, 16};          // points kept per SA level (pointnet2.py:46-49)
+const int kSrcN[4] = {1024, 1024, 256, 64};     // points searched per level
+const double kRadius[4] = {0.1, 0.2, 0.4, 0.8};    // python doubles in the reference (pointnet2.py:46-49)
+const int kFeatC[4] = {64, 128, 256, 512};
+
+}  // namespace
+
+struct lsdm_ctx {
+    int device = 0;
+    std::string err;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    int max_cats = 0;
+    std::vector<void*> allocs;  // parameter arena
+    // device parameter blocks
+    Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
+    CondParams cond{};
+    PosaParams posa{};
+    SceneAttnParams sattn{};
+    DenoiseParams den{};
+    Lin up0{};
+    Dense up2{};
+    StepCoefs sched{};
+    int sched_T = 0;
+    // workspace
+    int cap_B = 0;
+    std::vector<void*> ws_allocs;
+    std::map<std::string, std::pair<void*, int64_t>> ws_named;
+    int* idx[4] = {};
+    float* xyz[4] = {};
+    int* ball[4] = {};
+    float* feat[4] = {};
+    int* nn_idx[4] = {};
+    float* nn_w[4] = {};
+    float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
+    float *hm = nullptr, *e0 = nullptr, *tr = nullptr, *w = nullptr, *o12 = nullptr, *h2p = nullptr, *xs = nullptr;
+    int64_t* tbuf = nullptr;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-step marker)
+    size_t prof_cur = 0;
+};
+
+namespace {
+
+int fail(lsdm_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(c, LSDM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+enum KernelId { K_COND = 0, K_UP12, K_POSA, K_FPS, K_BALL1, K_BALL2, K_BALL3, K_BALL4, K_SA1, K_SA2, K_SA3, K_SA4, K_NN4, K_NN3, K_NN2,
+                K_NN1, K_FP4, K_FP3, K_FP2, K_FP1, K_SATTN, K_DENOISE, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"cond_kernel", "upsample12_kernel", "posa_kernel", "fps_chain_kernel", "ball_query<1024>/sa1",
+    "ball_query<1024>/sa2", "ball_query<256>/sa3", "ball_query<64>/sa4", "sa_kernel<3,32,32,64>", "sa_kernel<64,64,64,128>",
+    "sa_kernel<128,128,128,256>", "sa_kernel<256,256,256,512>", "three_nn<16>/fp4", "three_nn<64>/fp3", "three_nn<256>/fp2",
+    "three_nn<1024>/fp1", "fp_kernel<fp4>", "fp_kernel<fp3>", "fp_kernel<fp2>", "fp_kernel<fp1+head>", "scene_attn_kernel",
+    "denoise_kernel"};
+// algorithmic MACs of one launch per cloud (encoder kernels) or per sample (others); SURVEY.md §8(d), DESIGN.md
+const double kKernelMacs[K_COUNT] = {0.24e6, 16.8e6, 7.2e6, 0, 0, 0, 0, 0,
+    32768.0 * (6 * 32 + 32 * 32 + 32 * 64), 8192.0 * (67 * 64 + 64 * 64 + 64 * 128), 2048.0 * (131 * 128 + 128 * 128 + 128 * 256),
+    512.0 * (259 * 256 + 256 * 256 + 256 * 512), 0, 0, 0, 0, 64.0 * (768 * 256 + 256 * 256), 256.0 * (384 * 256 + 256 * 256),
+    1024.0 * (320 * 256 + 256 * 128), 1024.0 * (3 * 128 * 128 + 128 * 128 + 128 * 3), 0.0009e9 / 9,
+    1024.0 * (512 * 256 + 256 * 128 + 2 * (3 * 64 + 64 * 128 + 256 * 192 + 192 * 128 + 128 * 64 + 64 * 3))};
+
+void prof_mark(lsdm_ctx* c, int id, hipStream_t st) {
+    if (!c->prof_on) return;
+    if (c->prof_cur >= c->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { c->prof_on = false; return; }
+        c->prof_ev.push_back(e);
+        c->prof_id.push_back(id);
+    }
+    c->prof_id[c->prof_cur] = id;
+    (void)hipEventRecord(c->prof_ev[c->prof_cur++], st);
+}
+
+int check_launch(lsdm_ctx* c, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, LSDM_ERR_HIP, "launch %s: %s", what, hipGetErrorString(e));
+    return LSDM_OK;
+}
+
+const HostTensor* find(lsdm_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = c->host.find(name);
+    if (it == c->host.end()) { fail(c, LSDM_ERR_PARAM, "missing parameter %s", name.c_str()); return nullptr; }
+    int64_t want = 1; for (auto s : shape) want *= s;
+    if (it->second.numel() != want) {
+        fail(c, LSDM_ERR_PARAM, "parameter %s has %lld elements, expected %lld", name.c_str(), (long long)it->second.numel(), (long long)want);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+float* upload(lsdm_ctx* c, const float* src, size_t n) {
+    void* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) { fail(c, LSDM_ERR_HIP, "hipMalloc(%zu)", n * sizeof(float)); return nullptr; }
+    c->allocs.push_back(d);
+    if (hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { fail(c, LSDM_ERR_HIP, "hipMemcpy H2D"); return nullptr; }
+    return static_cast<float*>(d);
+}
+
+// plain Linear: weight (N,K) as stored
+bool load_lin(lsdm_ctx* c, const std::string& prefix, int N, int K, Lin* out) {
+    const HostTensor* w = find(c, prefix + ".weight", {N, K});
+    const HostTensor* b = find(c, prefix + ".bias", {N});
+    if (!w || !b) return false;
+    out->w = upload(c, w->data.data(), w->data.size());
+    out->b = upload(c, b->data.data(), b->data.size());
+    return out->w && out->b;
+}
+
+// MFMA B-operand layout: Wp[kb][n][j] = W[n][8*kb + j], K zero-padded to a multiple of 8 (mlp_core.hpp)
+std::vector<float> pack_weight(const std::vector<float>& W, int N, int K) {
+    const int Kp = (K + 7) / 8 * 8;
+    std::vector<float> p((size_t)Kp * N, 0.0f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) p[((size_t)(k / 8) * N + n) * 8 + (k % 8)] = W[(size_t)n * K + k];
+    return p;
+}
+
+// (conv|linear) [+ eval BatchNorm folded: y = (Wx + b - mean) * gamma / sqrt(var + eps) + beta] -> packed Dense
+bool load_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname, const std::string& bn, int N, int K, Dense* out) {
+    const HostTensor* w = find(c, wname, {N, K});
+    const HostTensor* b = find(c, bname, {N});
+    if (!w || !b) return false;
+    std::vector<float> W = w->data, Bv = b->data;
+    if (!bn.empty()) {
+        const HostTensor* g = find(c, bn + ".weight", {N});
+        const HostTensor* be = find(c, bn + ".bias", {N});
+        const HostTensor* mu = find(c, bn + ".running_mean", {N});
+        const HostTensor* var = find(c, bn + ".running_var", {N});
+        if (!g || !be || !mu || !var) return false;
+        for (int n = 0; n < N; ++n) {
+            const double s = (double)g->data[n] / std::sqrt((double)var->data[n] + 1e-5);
+            for (int k = 0; k < K; ++k) W[(size_t)n * K + k] = (float)((double)W[(size_t)n * K + k] * s);
+            Bv[n] = (float)(((double)Bv[n] - (double)mu->data[n]) * s + (double)be->data[n]);
+        }
+    }
+    std::vector<float> p = pack_weight(W, N, K);
+    out->w = upload(c, p.data(), p.size());
+    out->b = upload(c, Bv.data(), Bv.size());
+    return out->w && out->b;
+}
+
+template <typename T>
+T* ws_alloc(lsdm_ctx* c, const char* name, size_t count) {
+    void* d = nullptr;
+    if (hipMalloc(&d, count * sizeof(T)) != hipSuccess) { fail(c, LSDM_ERR_HIP, "hipMalloc workspace %s (%zu bytes)", name, count * sizeof(T)); return nullptr; }
+    c->ws_allocs.push_back(d);
+    c->ws_named[name] = {d, (int64_t)count};
+    return static_cast<T*>(d);
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// geometry + dense stages of get_backbone.forward on `num_clouds` clouds
+int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
+    prof_mark(c, K_FPS, st);
+    launch_fps_chain(clouds, starts, nc, c->idx, c->xyz, st);
+    const float* lvl_xyz[5] = {clouds, c->xyz[0], c->xyz[1], c->xyz[2], c->xyz[3]};
+    const float* lvl_feat[5] = {clouds, c->feat[0], c->feat[1], c->feat[2], c->feat[3]};
+    for (int l = 0; l < 4; ++l) {
+        // radius ** 2 is a double in the reference and is compared against fp32 distances (Q13)
+        const float r2 = (float)(kRadius[l] * kRadius[l]);
+        prof_mark(c, K_BALL1 + l, st);
+        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], nc, kSrcN[l], kS[l], r2, c->ball[l], st);
+        prof_mark(c, K_SA1 + l, st);
+        launch_sa(l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], c->ball[l], c->sa[l], c->feat[l], st);
+    }
+    // fp4: l3 <- l4 ; fp3: l2 <- l3 ; fp2: l1 <- l2 ; fp1: l0 <- l1
+    prof_mark(c, K_NN4, st);
+    launch_three_nn(c->xyz[2], c->xyz[3], nc, 64, 16, c->nn_idx[0], c->nn_w[0], st);
+    prof_mark(c, K_FP4, st);
+    launch_fp(4, nc, c->feat[2], c->feat[3], c->nn_idx[0], c->nn_w[0], c->fp[0], nullptr, c->fpo4, st);
+    prof_mark(c, K_NN3, st);
+    launch_three_nn(c->xyz[1], c->xyz[2], nc, 256, 64, c->nn_idx[1], c->nn_w[1], st);
+    prof_mark(c, K_FP3, st);
+    launch_fp(3, nc, c->feat[1], c->fpo4, c->nn_idx[1], c->nn_w[1], c->fp[1], nullptr, c->fpo3, st);
+    prof_mark(c, K_NN2, st);
+    launch_three_nn(c->xyz[0], c->xyz[1], nc, 1024, 256, c->nn_idx[2], c->nn_w[2], st);
+    prof_mark(c, K_FP2, st);
+    launch_fp(2, nc, c->feat[0], c->fpo3, c->nn_idx[2], c->nn_w[2], c->fp[2], nullptr, c->fpo2, st);
+    prof_mark(c, K_NN1, st);
+    launch_three_nn(clouds, c->xyz[0], nc, 1024, 1024, c->nn_idx[3], c->nn_w[3], st);
+    prof_mark(c, K_FP1, st);
+    launch_fp(1, nc, nullptr, c->fpo2, c->nn_idx[3], c->nn_w[3], c->fp[3], c->head, out, st);
+    return check_launch(c, "scene encoder");
+}
+
+int run_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
+             const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat, float* out_x0,
+             float* out_guiding, float* out_sample, hipStream_t st) {
+    prof_mark(c, K_COND, st);
+    launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, c->e0, c->tr, c->w, st);
+    prof_mark(c, K_UP12, st);
+    launch_upsample12(c->e0, c->up0, c->up2.w, c->up2.b, B, c->h2p, st);
+    prof_mark(c, K_POSA, st);
+    launch_posa(c->posa, given_objs, B, c->hm, st);
+    int rc = run_scene_encoder(c, given_objs, starts, B * kO, c->pcd, st);
+    if (rc) return rc;
+    prof_mark(c, K_SATTN, st);
+    launch_scene_attn(c->sattn, c->pcd, c->w, c->tr, B, c->o12, st);
+    prof_mark(c, K_DENOISE, st);
+    launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, c->w, c->o12, c->hm, c->h2p, noise, out_x0, out_guiding,
+                   out_sample, st);
+    prof_mark(c, -1, st);
+    return check_launch(c, "step");
+}
+
+int check_ready(lsdm_ctx* c, int B, bool need_sched) {
+    if (!c) return LSDM_ERR_ARG;
+    if (!c->finalized) return fail(c, LSDM_ERR_STATE, "parameters not finalised (lsdm_finalize_params)");
+    if (B <= 0 || B > c->cap_B) return fail(c, LSDM_ERR_STATE, "batch %d exceeds reserved workspace %d (lsdm_reserve)", B, c->cap_B);
+    if (need_sched && c->sched_T == 0) return fail(c, LSDM_ERR_STATE, "schedule not set (lsdm_set_schedule)");
+    return LSDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsdm_create(lsdm_ctx** out, int device) {
+    if (!out) return fail(nullptr, LSDM_ERR_ARG, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(nullptr, LSDM_ERR_HIP, "no HIP device available");
+    if (device < 0 || device >= n) return fail(nullptr, LSDM_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, LSDM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    lsdm_ctx* c = new lsdm_ctx();
+    c->device = device;
+    *out = c;
+    return LSDM_OK;
+}
+
+int lsdm_destroy(lsdm_ctx* c) {
+    if (!c) return LSDM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->allocs) (void)hipFree(p);
+    for (void* p : c->ws_allocs) (void)hipFree(p);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    delete c;
+    return LSDM_OK;
+}
+
+const char* lsdm_last_error(const lsdm_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int lsdm_set_param(lsdm_ctx* c, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !name || !data || ndim < 0 || ndim > 8) return fail(c, LSDM_ERR_ARG, "lsdm_set_param: bad argument");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data, data + t.numel());
+    c->host[name] = std::move(t);
+    c->finalized = false;
+    return LSDM_OK;
+}
+
+int lsdm_finalize_params(lsdm_ctx* c, int C) {
+    if (!c || C <= 0 || C > 512) return fail(c, LSDM_ERR_ARG, "lsdm_finalize_params: bad max_cats");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (void* p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    c->max_cats = C;
+    bool ok = true;
+    const char* sa_names[4] = {"sa1", "sa2", "sa3", "sa4"};
+    const int sa_in[4] = {6, 67, 131, 259};
+    const int sa_mlp[4][3] = {{32, 32, 64}, {64, 64, 128}, {128, 128, 256}, {256, 256, 512}};
+    for (int l = 0; l < 4 && ok; ++l) {
+        int last = sa_in[l];
+        for (int i = 0; i < 3 && ok; ++i) {
+            const std::string p = std::string("pcd_backbone.") + sa_names[l];
+            ok = load_dense(c, p + ".mlp_convs." + std::to_string(i) + ".weight", p + ".mlp_convs." + std::to_string(i) + ".bias",
+                            p + ".mlp_bns." + std::to_string(i), sa_mlp[l][i], last, &c->sa[l][i]);
+            last = sa_mlp[l][i];
+        }
+    }
+    const char* fp_names[4] = {"fp4", "fp3", "fp2", "fp1"};
+    const int fp_in[4] = {768, 384, 320, 128};
+    const int fp_mlp[4][3] = {{256, 256, 0}, {256, 256, 0}, {256, 128, 0}, {128, 128, 128}};
+    for (int l = 0; l < 4 && ok; ++l) {
+        int last = fp_in[l];
+        for (int i = 0; i < 3 && ok && fp_mlp[l][i]; ++i) {
+            const std::string p = std::string("pcd_backbone.") + fp_names[l];
+            ok = load_dense(c, p + ".mlp_convs." + std::to_string(i) + ".weight", p + ".mlp_convs." + std::to_string(i) + ".bias",
+                            p + ".mlp_bns." + std::to_string(i), fp_mlp[l][i], last, &c->fp[l][i]);
+            last = fp_mlp[l][i];
+        }
+    }
+    ok = ok && load_dense(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, &c->head[0]);
+    if (ok) {
+        Lin l{};
+        ok = load_lin(c, "pcd_backbone.conv2", 3, 128, &l);
+        c->head[1] = Dense{l.w, l.b};
+    }
+    // conditioning MLPs (plain)
+    if (ok) {
+        const HostTensor* pe = find(c, "sequence_pos_encoder.pe", {5000, 1, 128});
+        ok = pe != nullptr;
+        if (ok) c->cond.pe = upload(c, pe->data.data(), pe->data.size());
+    }
+    ok = ok && load_lin(c, "embed_timestep.time_embed.0", 128, 128, &c->cond.time0) &&
+         load_lin(c, "embed_timestep.time_embed.2", 128, 128, &c->cond.time2) && load_lin(c, "embed_text.0", 256, 512, &c->cond.text0) &&
+         load_lin(c, "embed_text.2", 256, 256, &c->cond.text2) && load_lin(c, "embed_text.4", 128, 256, &c->cond.text4) &&
+         load_lin(c, "predict_cat.0", 64, 128, &c->cond.pcat0) && load_lin(c, "predict_cat.2", 32, 64, &c->cond.pcat2) &&
+         load_lin(c, "predict_cat.4", C, 32, &c->cond.pcat4) && load_lin(c, "embed_cat.0", 32, C, &c->cond.ecat) &&
+         load_lin(c, "translation_layer.0", 128, 160, &c->cond.tr0) && load_lin(c, "translation_layer.2", 12, 128, &c->cond.tr2);
+    if (ok) {
+        const HostTensor* wq = find(c, "attn_layer.q_proj_weight", {128, 128});
+        const HostTensor* wk = find(c, "attn_layer.k_proj_weight", {128, 32});
+        const HostTensor* ib = find(c, "attn_layer.in_proj_bias", {384});
+        ok = wq && wk && ib;
+        if (ok) {
+            c->cond.attn_wq = upload(c, wq->data.data(), wq->data.size());
+            c->cond.attn_wk = upload(c, wk->data.data(), wk->data.size());
+            c->cond.attn_inb = upload(c, ib->data.data(), ib->data.size());
+        }
+    }
+    // POSA decoder
+    for (int i = 0; i < 3 && ok; ++i) {
+        const std::string p = "human_backbone.de_spiral." + std::to_string(i);
+        ok = load_lin(c, p + ".conv.layer", 64, i == 0 ? 3 : 64, &c->posa.lin[i]);
+        const HostTensor* gw = ok ? find(c, p + ".norm.weight", {64}) : nullptr;
+        const HostTensor* gb = ok ? find(c, p + ".norm.bias", {64}) : nullptr;
+        ok = ok && gw && gb;
+        if (ok) {
+            c->posa.gn_w[i] = upload(c, gw->data.data(), 64);
+            c->posa.gn_b[i] = upload(c, gb->data.data(), 64);
+        }
+    }
+    ok = ok && load_lin(c, "human_backbone.de_spiral.3.layer", 3, 64, &c->posa.last);
+    // pcd_attention
+    if (ok) {
+        const HostTensor* wq = find(c, "pcd_attention.q_proj_weight", {12, 12});
+        const HostTensor* wk = find(c, "pcd_attention.k_proj_weight", {12, 3});
+        const HostTensor* wv = find(c, "pcd_attention.v_proj_weight", {12, 3});
+        const HostTensor* ib = find(c, "pcd_attention.in_proj_bias", {36});
+        ok = wq && wk && wv && ib;
+        if (ok) {
+            c->sattn.wq = upload(c, wq->data.data(), 144);
+            c->sattn.wk = upload(c, wk->data.data(), 36);
+            c->sattn.wv = upload(c, wv->data.data(), 36);
+            c->sattn.inb = upload(c, ib->data.data(), 36);
+        }
+    }
+    ok = ok && load_lin(c, "pcd_attention.out_proj", 12, 12, &c->sattn.outp);
+    // up-sampling + per-point denoiser
+    ok = ok && load_lin(c, "upsampling_layer.0", 128, 1, &c->up0) &&
+         load_dense(c, "upsampling_layer.2.weight", "upsampling_layer.2.bias", "", 512, 128, &c->up2);
+    if (ok) {
+        Lin l{};
+        ok = load_lin(c, "upsampling_layer.4", 1024, 512, &l);
+        c->den.up4_w = l.w;
+        c->den.up4_b = l.b;
+    }
+    ok = ok && load_dense(c, "combine_extraction.0.weight", "combine_extraction.0.bias", "", 128, 256, &c->den.comb) &&
+         load_lin(c, "input_process.pose_embedding.0", 64, 3, &c->den.pose0) &&
+         load_dense(c, "input_process.pose_embedding.2.weight", "input_process.pose_embedding.2.bias", "", 128, 64, &c->den.pose2) &&
+         load_dense(c, "input_process.combination_extraction.0.weight", "input_process.combination_extraction.0.bias", "", 192, 256, &c->den.cex0) &&
+         load_dense(c, "input_process.combination_extraction.2.weight", "input_process.combination_extraction.2.bias", "", 128, 192, &c->den.cex2) &&
+         load_dense(c, "output_process.pose_final.0.weight", "output_process.pose_final.0.bias", "", 64, 128, &c->den.fin0) &&
+         load_lin(c, "output_process.pose_final.2", 3, 64, &c->den.fin2) && load_lin(c, "point_wise_trans_layer.0", 3, 15, &c->den.pwt);
+    if (!ok) return c->err.empty() ? fail(c, LSDM_ERR_PARAM, "parameter upload failed") : LSDM_ERR_PARAM;
+    c->finalized = true;
+    return LSDM_OK;
+}
+
+int lsdm_set_schedule(lsdm_ctx* c, int T, const float* coef1, const float* coef2, const float* logvar, const float* sr,
+                      const float* srm1, const float* acp, const float* acp_prev) {
+    if (!c || T <= 0 || T > 5000 || !coef1 || !coef2 || !logvar || !sr || !srm1 || !acp || !acp_prev)
+        return fail(c, LSDM_ERR_ARG, "lsdm_set_schedule: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->sched.coef1 = upload(c, coef1, T);
+    c->sched.coef2 = upload(c, coef2, T);
+    c->sched.logvar = upload(c, logvar, T);
+    c->sched.sr_acp = upload(c, sr, T);
+    c->sched.srm1_acp = upload(c, srm1, T);
+    c->sched.acp = upload(c, acp, T);
+    c->sched.acp_prev = upload(c, acp_prev, T);
+    if (!c->sched.acp_prev) return LSDM_ERR_HIP;
+    c->sched_T = T;
+    return LSDM_OK;
+}
+
+int lsdm_reserve(lsdm_ctx* c, int B) {
+    if (!c || B <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_reserve: bad batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (B <= c->cap_B) return LSDM_OK;
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (void* p : c->ws_allocs) (void)hipFree(p);
+    c->ws_allocs.clear();
+    c->ws_named.clear();
+    c->cap_B = 0;
+    const size_t nc = (size_t)B * kO;
+    bool ok = true;
+    const char* lv[4] = {"1", "2", "3", "4"};
+    for (int l = 0; l < 4 && ok; ++l) {
+        ok = (c->idx[l] = ws_alloc<int>(c, (std::string("fps_idx") + lv[l]).c_str(), nc * kS[l])) &&
+             (c->xyz[l] = ws_alloc<float>(c, (std::string("xyz") + lv[l]).c_str(), nc * kS[l] * 3)) &&
+             (c->ball[l] = ws_alloc<int>(c, (std::string("ball") + lv[l]).c_str(), nc * kS[l] * 32)) &&
+             (c->feat[l] = ws_alloc<float>(c, (std::string("feat") + lv[l]).c_str(), nc * kS[l] * kFeatC[l]));
+    }
+    const int nn_n[4] = {64, 256, 1024, 1024};
+    for (int l = 0; l < 4 && ok; ++l) {
+        ok = (c->nn_idx[l] = ws_alloc<int>(c, (std::string("nn_idx") + lv[l]).c_str(), nc * nn_n[l] * 3)) &&
+             (c->nn_w[l] = ws_alloc<float>(c, (std::string("nn_w") + lv[l]).c_str(), nc * nn_n[l] * 3));
+    }
+    ok = ok && (c->fpo4 = ws_alloc<float>(c, "fp4", nc * 64 * 256)) && (c->fpo3 = ws_alloc<float>(c, "fp3", nc * 256 * 256)) &&
+         (c->fpo2 = ws_alloc<float>(c, "fp2", nc * 1024 * 128)) && (c->pcd = ws_alloc<float>(c, "pcd", nc * kN * 3)) &&
+         (c->hm = ws_alloc<float>(c, "hm", (size_t)B * kN * 3)) && (c->e0 = ws_alloc<float>(c, "e0", (size_t)B * 256)) &&
+         (c->tr = ws_alloc<float>(c, "tr", nc * 12)) && (c->w = ws_alloc<float>(c, "w", nc)) &&
+         (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) && (c->h2p = ws_alloc<float>(c, "h2p", (size_t)B * 256 * 512)) &&
+         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->tbuf = ws_alloc<int64_t>(c, "tbuf", (size_t)B));
+    if (!ok) return LSDM_ERR_HIP;
+    c->cap_B = B;
+    return LSDM_OK;
+}
+
+int lsdm_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
+              const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat, float* out_x0,
+              float* out_guiding, float* out_sample, void* stream) {
+    int rc = check_ready(c, B, mode != LSDM_MODE_FORWARD);
+    if (rc) return rc;
+    if (mode < 0 || mode > 2) return fail(c, LSDM_ERR_ARG, "lsdm_step: bad mode %d", mode);
+    if (!x || !mask || !t || !given_objs || !given_cats || !text || !starts || !out_cat || !out_x0 || !out_guiding ||
+        (mode != LSDM_MODE_FORWARD && !out_sample))
+        return fail(c, LSDM_ERR_ARG, "lsdm_step: NULL tensor");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_step(c, mode, eta, B, x, mask, t, given_objs, given_cats, text, starts, noise, out_cat, out_x0, out_guiding, out_sample,
+                    static_cast<hipStream_t>(stream));
+}
+
+int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int K, float* x, const float* mask, const float* given_objs,
+                      const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat,
+                      float* out_x0, float* out_guiding, void* stream) {
+    int rc = check_ready(c, B, true);
+    if (rc) return rc;
+    if (mode != LSDM_MODE_P_SAMPLE && mode != LSDM_MODE_DDIM) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: bad mode %d", mode);
+    if (K <= 0 || t_first >= c->sched_T || t_first - K + 1 < 0) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: steps [%d..%d] outside schedule", t_first - K + 1, t_first);
+    if (!x || !mask || !given_objs || !given_cats || !text || !starts || !noise || !out_cat || !out_x0 || !out_guiding)
+        return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: NULL tensor");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* cur = x;
+    float* nxt = c->xs;
+    const size_t xn = (size_t)B * kN * 3;
+    for (int k = 0; k < K; ++k) {
+        hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, c->tbuf, (int64_t)(t_first - k), B);
+        rc = run_step(c, mode, eta, B, cur, mask, c->tbuf, given_objs, given_cats, text, starts + (size_t)k * 4 * B * kO,
+                      noise + (size_t)k * xn, out_cat, out_x0, out_guiding, nxt, st);
+        if (rc) return rc;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return LSDM_OK;
+}
+
+int lsdm_fps(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, int32_t* i1, int32_t* i2, int32_t* i3, int32_t* i4,
+             float* x1, float* x2, float* x3, float* x4, void* stream) {
+    if (!c || !clouds || !starts || nc <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_fps: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int* idx[4] = {i1, i2, i3, i4};
+    float* xyz[4] = {x1, x2, x3, x4};
+    launch_fps_chain(clouds, starts, nc, idx, xyz, static_cast<hipStream_t>(stream));
+    return check_launch(c, "fps");
+}
+
+int lsdm_ball_query(lsdm_ctx* c, const float* xyz, const float* new_xyz, int nc, int N, int S, double radius, int32_t* out, void* stream) {
+    if (!c || !xyz || !new_xyz || !out || nc <= 0 || S <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_ball_query: bad argument");
+    if (N != 1024 && N != 256 && N != 64) return fail(c, LSDM_ERR_ARG, "lsdm_ball_query: N must be 1024, 256 or 64");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float r2 = (float)(radius * radius);
+    launch_ball_query(xyz, new_xyz, nc, N, S, r2, out, static_cast<hipStream_t>(stream));
+    return check_launch(c, "ball_query");
+}
+
+int lsdm_three_nn(lsdm_ctx* c, const float* fine, const float* coarse, int nc, int N, int S, int32_t* idx, float* w, void* stream) {
+    if (!c || !fine || !coarse || !idx || !w || nc <= 0 || N <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_three_nn: bad argument");
+    if (S != 1024 && S != 256 && S != 64 && S != 16) return fail(c, LSDM_ERR_ARG, "lsdm_three_nn: S must be 1024, 256, 64 or 16");
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_three_nn(fine, coarse, nc, N, S, idx, w, static_cast<hipStream_t>(stream));
+    return check_launch(c, "three_nn");
+}
+
+int lsdm_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, void* stream) {
+    if (!c || !clouds || !starts || !out || nc <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_scene_encoder: bad argument");
+    if (!c->finalized) return fail(c, LSDM_ERR_STATE, "parameters not finalised");
+    if ((nc + kO - 1) / kO > c->cap_B) return fail(c, LSDM_ERR_STATE, "%d clouds exceed the reserved workspace (%d samples)", nc, c->cap_B);
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_scene_encoder(c, clouds, starts, nc, out, static_cast<hipStream_t>(stream));
+}
+
+int lsdm_human_backbone(lsdm_ctx* c, const float* given_objs, int B, float* hm, void* stream) {
+    if (!c || !given_objs || !hm || B <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_human_backbone: bad argument");
+    if (!c->finalized) return fail(c, LSDM_ERR_STATE, "parameters not finalised");
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_posa(c->posa, given_objs, B, hm, static_cast<hipStream_t>(stream));
+    return check_launch(c, "posa");
+}
+
+int lsdm_profile_begin(lsdm_ctx* c) {
+    if (!c) return LSDM_ERR_ARG;
+    c->prof_cur = 0;
+    c->prof_on = true;
+    return LSDM_OK;
+}
+
+int lsdm_profile_end(lsdm_ctx* c, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit) {
+    if (!c || !total_ms || !launches || capacity < K_COUNT) return fail(c, LSDM_ERR_ARG, "lsdm_profile_end: need capacity >= %d", (int)K_COUNT);
+    c->prof_on = false;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (int k = 0; k < K_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; if (macs_per_unit) macs_per_unit[k] = kKernelMacs[k]; }
+    for (size_t i = 0; i + 1 < c->prof_cur; ++i) {
+        const int id = c->prof_id[i];
+        if (id < 0) continue;
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
+        total_ms[id] += ms;
+        launches[id] += 1;
+    }
+    return K_COUNT;
+}
+
+const char* lsdm_profile_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+
+int lsdm_workspace_tensor(lsdm_ctx* c, const char* name, void** ptr, int64_t* numel) {
+    if (!c || !name || !ptr || !numel) return fail(c, LSDM_ERR_ARG, "lsdm_workspace_tensor: bad argument");
+    auto it = c->ws_named.find(name);
+    if (it == c->ws_named.end()) return fail(c, LSDM_ERR_ARG, "no workspace tensor named %s", name);
+    *ptr = it->second.first;
+    *numel = it->second.second;
+    return LSDM_OK;
+}
+
+}  // extern "C"

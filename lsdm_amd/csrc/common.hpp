@@ -1,0 +1,48 @@
+// Shared device/host helpers for liblsdm_hip (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsdm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kPoints = 1024;      // points per cloud (model/sdm.py:21 pcd_points)
+constexpr int kSlots = 9;          // human + 8 objects (posa/dataset.py:453)
+constexpr int kNSample = 32;       // ball-query group size (pointnet2.py:46-49)
+
+// exact-erf GELU (nn.GELU() default)
+__device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float reluf(float v) { return v > 0.0f ? v : 0.0f; }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+    if constexpr (ACT == ACT_RELU) return reluf(v);
+    else if constexpr (ACT == ACT_GELU) return gelu(v);
+    else if constexpr (ACT == ACT_SIGMOID) return sigmoidf(v);
+    else return v;
+}
+
+// pointnet2_utils.py:19-38 square_distance, in the fp32 rounding sequence of the CPU reference for K=3
+// (oracle/cpu_ref.py::square_distance, pinned by tests/test_oracle_golden.py::test_g3_square_distance_rounding):
+//   dot = fma(a2,b2, fma(a1,b1, a0*b0));  d = -2*dot;  d += |a|^2;  d += |b|^2,  |v|^2 = (v0^2+v1^2)+v2^2
+__device__ __forceinline__ float sumsq3(float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+__device__ __forceinline__ float sqdist_ref(float ax, float ay, float az, float a2, float bx, float by, float bz, float b2) {
+    float dot = __fmul_rn(ax, bx);
+    dot = __fmaf_rn(ay, by, dot);
+    dot = __fmaf_rn(az, bz, dot);
+    float d = __fmul_rn(-2.0f, dot);
+    d = __fadd_rn(d, a2);
+    d = __fadd_rn(d, b2);
+    return d;
+}
+
+}  // namespace lsdm

@@ -1,0 +1,231 @@
+// PointNet++ geometry for gfx950: farthest-point sampling, ball query, 3-NN.
+//
+// Restates (never materialising the reference's (S,N) distance / sort tensors):
+//   farthest_point_sample   model/pcd_backbone/pointnet2_utils.py:60-81
+//   query_ball_point        model/pcd_backbone/pointnet2_utils.py:84-104
+//   3-NN + IDW weights      model/pcd_backbone/pointnet2_utils.py:283-298
+// All arithmetic is fp32 in the reference's rounding sequence (common.hpp::sqdist_ref) so that the
+// discrete decisions (arg-max, d > r^2, nearest-3) are index-exact against the CPU oracle.
+// Built with -ffp-contract=off; explicit __f*_rn intrinsics are used where the order matters.
+#include "common.hpp"
+
+namespace lsdm {
+
+// ---------------------------------------------------------------------------------------------
+// wave64 max of a 64-bit key with DPP (no LDS traffic); result broadcast from lane 63.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+    unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = dpp_max_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max_step<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_max_step<0x140, 0xf>(v);  // row_mirror
+    v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FPS: one 256-thread workgroup per cloud runs the four chained levels (1024->1024->256->64->16).
+// Points and running minima live in registers; the chosen centroid is re-read from LDS (broadcast).
+// Arg-max key = (bits(running_min) << 32) | (~index): distances are >= 0 so the bit pattern is
+// monotone, and ties resolve to the lowest index like torch.max on CPU (pointnet2_utils.py:80).
+// ---------------------------------------------------------------------------------------------
+template <int N, int NP>
+__device__ __forceinline__ int fps_level(const float* __restrict__ src, float* __restrict__ dst, int start,
+                                          int* __restrict__ out_idx, float* __restrict__ out_xyz,
+                                          unsigned long long (*red)[4]) {
+    constexpr int PPT = (N + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float px[PPT], py[PPT], pz[PPT], run[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = tid + 256 * j;
+        const bool valid = p < N;
+        px[j] = valid ? src[p * 3 + 0] : 0.0f;
+        py[j] = valid ? src[p * 3 + 1] : 0.0f;
+        pz[j] = valid ? src[p * 3 + 2] : 0.0f;
+        run[j] = 1e10f;
+    }
+    int far = start;
+    for (int i = 0; i < NP; ++i) {
+        const float cx = src[far * 3 + 0], cy = src[far * 3 + 1], cz = src[far * 3 + 2];
+        if (tid == 0) {
+            out_idx[i] = far;
+            dst[i * 3 + 0] = cx; dst[i * 3 + 1] = cy; dst[i * 3 + 2] = cz;
+            out_xyz[i * 3 + 0] = cx; out_xyz[i * 3 + 1] = cy; out_xyz[i * 3 + 2] = cz;
+        }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int p = tid + 256 * j;
+            const float dx = __fsub_rn(px[j], cx), dy = __fsub_rn(py[j], cy), dz = __fsub_rn(pz[j], cz);
+            const float d = sumsq3(dx, dy, dz);
+            run[j] = d < run[j] ? d : run[j];
+            unsigned long long key = ((unsigned long long)__float_as_uint(run[j]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+            if (p >= N) key = 0ull;
+            best = key > best ? key : best;
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) red[i & 1][wave] = best;
+        __syncthreads();
+        unsigned long long b0 = red[i & 1][0], b1 = red[i & 1][1], b2 = red[i & 1][2], b3 = red[i & 1][3];
+        b0 = b1 > b0 ? b1 : b0;
+        b2 = b3 > b2 ? b3 : b2;
+        b0 = b2 > b0 ? b2 : b0;
+        far = (int)(0xFFFFFFFFu - (unsigned)b0);
+    }
+    __syncthreads();
+    return far;
+}
+
+__global__ __launch_bounds__(256) void fps_chain_kernel(
+    const float* __restrict__ clouds, const int64_t* __restrict__ starts, int num_clouds,
+    int* __restrict__ idx1, int* __restrict__ idx2, int* __restrict__ idx3, int* __restrict__ idx4,
+    float* __restrict__ xyz1, float* __restrict__ xyz2, float* __restrict__ xyz3, float* __restrict__ xyz4) {
+    __shared__ float bufA[kPoints * 3];
+    __shared__ float bufB[kPoints * 3];
+    __shared__ unsigned long long red[2][4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float* src = clouds + (size_t)c * kPoints * 3;
+    for (int i = tid; i < kPoints * 3; i += 256) bufA[i] = src[i];
+    __syncthreads();
+    const int s1 = (int)starts[0 * (size_t)num_clouds + c], s2 = (int)starts[1 * (size_t)num_clouds + c];
+    const int s3 = (int)starts[2 * (size_t)num_clouds + c], s4 = (int)starts[3 * (size_t)num_clouds + c];
+    fps_level<1024, 1024>(bufA, bufB, s1, idx1 + (size_t)c * 1024, xyz1 + (size_t)c * 1024 * 3, red);
+    fps_level<1024, 256>(bufB, bufA, s2, idx2 + (size_t)c * 256, xyz2 + (size_t)c * 256 * 3, red);
+    fps_level<256, 64>(bufA, bufB, s3, idx3 + (size_t)c * 64, xyz3 + (size_t)c * 64 * 3, red);
+    fps_level<64, 16>(bufB, bufA, s4, idx4 + (size_t)c * 16, xyz4 + (size_t)c * 16 * 3, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ball query: one wave per centroid scans the N source points in index order, 64 at a time, and
+// keeps the first 32 with NOT(d > r^2); unfilled slots repeat the first hit.  No sort.
+// Workgroup = 4 waves x CPW centroids each; the source cloud is staged once in LDS as (x,y,z,|p|^2).
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                         int S, float r2, int* __restrict__ out) {
+    constexpr int CPW = 4;
+    __shared__ float4 pts[N];
+    __shared__ int slots[4][kNSample];
+    const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = xyz + (size_t)c * N * 3;
+    for (int p = tid; p < N; p += 256) {
+        const float x = src[p * 3 + 0], y = src[p * 3 + 1], z = src[p * 3 + 2];
+        pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
+    }
+    __syncthreads();
+    for (int q = 0; q < CPW; ++q) {
+        const int s = (blockIdx.x * 4 + wave) * CPW + q;
+        if (s >= S) break;  // wave-uniform
+        const float* cp = new_xyz + ((size_t)c * S + s) * 3;
+        const float ax = cp[0], ay = cp[1], az = cp[2];
+        const float a2 = sumsq3(ax, ay, az);
+        int cnt = 0;
+        for (int base = 0; base < N && cnt < kNSample; base += 64) {
+            const int p = base + lane;
+            bool in = false;
+            if (p < N) {
+                const float4 b = pts[p];
+                const float d = sqdist_ref(ax, ay, az, a2, b.x, b.y, b.z, b.w);
+                in = !(d > r2);
+            }
+            const unsigned long long m = __ballot(in);
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && pos < kNSample) slots[wave][pos] = p;
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kNSample) {
+            // cnt == 0 cannot happen for a centroid drawn from the cloud (the reference would index out of range)
+            const int first = slots[wave][0];
+            const int v = lane < cnt ? slots[wave][lane] : first;
+            out[((size_t)c * S + s) * kNSample + lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-NN: one thread per fine point keeps the three smallest distances (ties -> lower index) to the S
+// coarse points staged in LDS, then the inverse-distance weights of pointnet2_utils.py:297-299.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__ fine, const float* __restrict__ coarse, int N,
+                                                       int* __restrict__ out_idx, float* __restrict__ out_w) {
+    __shared__ float4 pts[S];
+    const int c = blockIdx.y, tid = threadIdx.x;
+    const float* src = coarse + (size_t)c * S * 3;
+    for (int p = tid; p < S; p += 256) {
+        const float x = src[p * 3 + 0], y = src[p * 3 + 1], z = src[p * 3 + 2];
+        pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    if (n >= N) return;
+    const float* fp = fine + ((size_t)c * N + n) * 3;
+    const float ax = fp[0], ay = fp[1], az = fp[2];
+    const float a2 = sumsq3(ax, ay, az);
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0;
+    for (int p = 0; p < S; ++p) {
+        const float4 b = pts[p];
+        const float d = sqdist_ref(ax, ay, az, a2, b.x, b.y, b.z, b.w);
+        if (d < d2) {
+            if (d < d1) {
+                d2 = d1; i2 = i1;
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = p; }
+                else { d1 = d; i1 = p; }
+            } else { d2 = d; i2 = p; }
+        }
+    }
+    const float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
+    const float r1 = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f));
+    const float r2 = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+    const float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+    const size_t o = ((size_t)c * N + n) * 3;
+    out_idx[o + 0] = i0; out_idx[o + 1] = i1; out_idx[o + 2] = i2;
+    out_w[o + 0] = __fdiv_rn(r0, norm); out_w[o + 1] = __fdiv_rn(r1, norm); out_w[o + 2] = __fdiv_rn(r2, norm);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int* const idx[4], float* const xyz[4],
+                      hipStream_t st) {
+    hipLaunchKernelGGL(fps_chain_kernel, dim3(num_clouds), dim3(256), 0, st, clouds, starts, num_clouds, idx[0], idx[1],
+                       idx[2], idx[3], xyz[0], xyz[1], xyz[2], xyz[3]);
+}
+
+void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, hipStream_t st) {
+    dim3 grid((S + 15) / 16, num_clouds), block(256);
+    switch (N) {
+        case 1024: hipLaunchKernelGGL(ball_query_kernel<1024>, grid, block, 0, st, xyz, new_xyz, S, r2, out); break;
+        case 256: hipLaunchKernelGGL(ball_query_kernel<256>, grid, block, 0, st, xyz, new_xyz, S, r2, out); break;
+        case 64: hipLaunchKernelGGL(ball_query_kernel<64>, grid, block, 0, st, xyz, new_xyz, S, r2, out); break;
+    }
+}
+
+void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w,
+                     hipStream_t st) {
+    dim3 grid((N + 255) / 256, num_clouds), block(256);
+    switch (S) {
+        case 1024: hipLaunchKernelGGL(three_nn_kernel<1024>, grid, block, 0, st, fine, coarse, N, out_idx, out_w); break;
+        case 256: hipLaunchKernelGGL(three_nn_kernel<256>, grid, block, 0, st, fine, coarse, N, out_idx, out_w); break;
+        case 64: hipLaunchKernelGGL(three_nn_kernel<64>, grid, block, 0, st, fine, coarse, N, out_idx, out_w); break;
+        case 16: hipLaunchKernelGGL(three_nn_kernel<16>, grid, block, 0, st, fine, coarse, N, out_idx, out_w); break;
+    }
+}
+
+}  // namespace lsdm

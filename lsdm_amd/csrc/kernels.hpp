@@ -1,0 +1,84 @@
+// Parameter blocks and host-side launchers of liblsdm_hip's kernels (internal header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsdm {
+
+struct Dense {  // folded (conv|linear)[+BN] layer for the MFMA core: packed weights Wp[kb][n][8], bias[n]
+    const float* w;
+    const float* b;
+};
+
+struct Lin {  // plain torch.nn.Linear parameters: weight (N,K) row-major, bias (N)
+    const float* w;
+    const float* b;
+};
+
+struct CondParams {
+    const float* pe;                            // sequence_pos_encoder.pe (5000,1,128)
+    Lin time0, time2;                           // embed_timestep.time_embed.{0,2}
+    Lin text0, text2, text4;                    // embed_text.{0,2,4}
+    Lin pcat0, pcat2, pcat4;                    // predict_cat.{0,2,4}
+    Lin ecat;                                   // embed_cat.0
+    const float *attn_wq, *attn_wk, *attn_inb;  // attn_layer.{q,k}_proj_weight, in_proj_bias
+    Lin tr0, tr2;                               // translation_layer.{0,2}
+};
+
+struct PosaParams {
+    Lin lin[3];            // human_backbone.de_spiral.{0,1,2}.conv.layer
+    const float* gn_w[3];  // human_backbone.de_spiral.{0,1,2}.norm.{weight,bias}
+    const float* gn_b[3];
+    Lin last;              // human_backbone.de_spiral.3.layer (3,64)
+};
+
+struct SceneAttnParams {
+    const float *wq, *wk, *wv, *inb;  // pcd_attention.{q,k,v}_proj_weight (12,12),(12,3),(12,3); in_proj_bias (36)
+    Lin outp;                         // pcd_attention.out_proj (12,12)
+};
+
+struct DenoiseParams {
+    const float* up4_w;   // upsampling_layer.4.weight (1024,512) row-major: the A operand of the third up-sampling layer
+    const float* up4_b;   // (1024) -- a per-ROW bias in the transposed product
+    Dense comb;           // combine_extraction.0            256 -> 128  GELU
+    Lin pose0;            // input_process.pose_embedding.0    3 -> 64   sigmoid (VALU)
+    Dense pose2;          // input_process.pose_embedding.2   64 -> 128  sigmoid
+    Dense cex0, cex2;     // input_process.combination_extraction.{0,2}  256 -> 192 -> 128 sigmoid
+    Dense fin0;           // output_process.pose_final.0     128 -> 64   GELU
+    Lin fin2;             // output_process.pose_final.2      64 -> 3    GELU (VALU)
+    Lin pwt;              // point_wise_trans_layer.0         15 -> 3    GELU
+};
+
+struct StepCoefs {  // per-timestep fp32 tables (gathered by t inside the kernel); see diffusion/schedule.py
+    const float* coef1;     // posterior_mean_coef1
+    const float* coef2;     // posterior_mean_coef2
+    const float* logvar;    // posterior_log_variance_clipped
+    const float* sr_acp;    // sqrt_recip_alphas_cumprod      (DDIM)
+    const float* srm1_acp;  // sqrt_recipm1_alphas_cumprod    (DDIM)
+    const float* acp;       // alphas_cumprod                 (DDIM)
+    const float* acp_prev;  // alphas_cumprod_prev            (DDIM)
+};
+
+enum StepMode { MODE_FORWARD = 0, MODE_P_SAMPLE = 1, MODE_DDIM = 2 };
+
+// geometry.hip
+void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int* const idx[4], float* const xyz[4], hipStream_t st);
+void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, hipStream_t st);
+void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, hipStream_t st);
+// encoder.hip
+void launch_sa(int level, int num_clouds, const float* src_xyz, const float* src_feat, const float* new_xyz, const int* ball,
+               const Dense* l, float* out, hipStream_t st);
+void launch_fp(int which, int num_clouds, const float* points1, const float* points2, const int* nn_idx, const float* nn_w,
+               const Dense* l, const Dense* head, float* out, hipStream_t st);
+// cond.hip
+void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int C,
+                 float* out_cat, float* e0, float* tr, float* w, hipStream_t st);
+void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st);
+void launch_upsample12(const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, float* h2p, hipStream_t st);
+void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st);
+// denoise.hip
+void launch_denoise(const DenoiseParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
+                    const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const float* h2p,
+                    const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
+
+}  // namespace lsdm

@@ -1,0 +1,200 @@
+"""``SceneDiffusionModel`` -- drop-in for the reference's ``model.sdm.SceneDiffusionModel`` on MI355X.
+
+Same constructor signature, ``forward`` signature, side-effect attributes (``saved_cat``,
+``saved_guiding_points``) and ``state_dict`` key names/shapes as the reference (model/sdm.py:19-22,
+131, 158, 217), so ``model.load_state_dict(ckpt['model_state_dict'])``
+(run/test_sdm.py:124) works unchanged.  The module owns parameters only; every computation of
+``forward`` runs in hand-written HIP kernels behind the C ABI of ``liblsdm_hip.so``
+(include/lsdm_hip.h).  There is no eager/CPU fallback: calling ``forward`` without the library or
+with host tensors raises.
+
+Extensions (keyword-only, defaults preserve reference behaviour):
+  * ``y`` may be a ``(B, 512)`` tensor of precomputed CLIP text features -- the boundary of this
+    path (the reference re-runs ``clip_model.encode_text`` every step, model/sdm.py:147); a list of
+    strings is encoded through ``self.text_encoder`` (the ``clip`` package when importable).
+  * ``forward(..., fps_starts=...)`` injects the four FPS start draws; by default they are drawn
+    from the global CPU generator exactly where the reference draws them
+    (model/pcd_backbone/pointnet2_utils.py:72 -- ``torch.randint`` without a device argument).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..state_spec import state_dict_spec
+
+NUM_SLOTS = 9
+FPS_RANGES = (1024, 1024, 256, 64)  # N of the cloud each SA level samples from
+
+
+def _attach(root, dotted, tensor, kind):
+    """Registers ``tensor`` under a dotted state_dict name, creating plain container modules on the way."""
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    if kind in ("pe", "bn_mean", "bn_var", "bn_count"):
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class SceneDiffusionModel(nn.Module):
+    def __init__(self, seg_len=256, modality='text', clip_version='ViT-B/32', clip_dim=768, dropout=0.1, n_layer=6,
+                 n_head=8, f_vert=64, dim_ff=512, cat_emb=32, mesh_ds_dir="data/mesh_ds", posa_path=None,
+                 latent_dim=128, cond_mask_prob=1.0, device=0, vert_dims=655, obj_cat=8, data_rep='rot6d', njoints=251,
+                 use_cuda=True, pcd_points=1024, pcd_dim=128, xyz_dim=3, max_cats=13, translation_params=12,
+                 pcd_backbone_type="PNT2", human_backbone_type="POSA", text_encoder_type="CLIP", **kwargs):
+        super().__init__()
+        if pcd_backbone_type != "PNT2" or human_backbone_type != "POSA":
+            raise NotImplementedError("only the default PNT2 / POSA backbones are on the accelerated path "
+                                      "(DGCNN / P2R are ablation options of the reference, SURVEY.md §2)")
+        if (clip_dim, latent_dim, cat_emb, pcd_points, xyz_dim, translation_params, n_head) != (512, 128, 32, 1024, 3, 12, 8) \
+                or pcd_dim != 3:
+            raise NotImplementedError("kernels are specialised for the proxd/humanise defaults of util/model_util.py:26-72 "
+                                      "(clip_dim=512, latent_dim=128, pcd_dim=3, n_head=8)")
+        self.seg_len, self.modality, self.clip_version, self.clip_dim = seg_len, modality, clip_version, clip_dim
+        self.latent_dim, self.pcd_dim, self.pcd_points, self.xyz_dim = latent_dim, pcd_dim, pcd_points, xyz_dim
+        self.max_cats, self.n_head, self.translation_params = max_cats, n_head, translation_params
+        self.text_encoder_type = text_encoder_type
+        self.device = "cuda:{}".format(device) if use_cuda else "cpu"
+        self._device_index = int(device)
+        self.saved_cat = None
+        self.saved_guiding_points = None
+        self.text_encoder = None  # callable(list[str]) -> (B,512) tensor
+        gen = torch.Generator().manual_seed(0)
+        for name, (shape, kind) in state_dict_spec(max_cats=max_cats).items():
+            if kind == "pe":
+                from ..synthetic import sinusoid_table
+                t = sinusoid_table(shape[0], shape[2])
+            elif kind == "bn_count":
+                t = torch.tensor(0, dtype=torch.long)
+            elif kind in ("norm_w", "bn_var"):
+                t = torch.ones(shape)
+            elif kind in ("norm_b", "bn_mean", "bias"):
+                t = torch.zeros(shape)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                t = (torch.rand(shape, generator=gen) * 2 - 1) / float(np.sqrt(fan_in))
+            _attach(self, name, t, kind)
+        self._ctx = None
+        self._dirty = True
+        self._schedule_key = None
+        self._cap = 0
+        self.requires_grad_(False)
+        if use_cuda and torch.cuda.is_available():
+            self.to(self.device)
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # real checkpoints also carry the CLIP weights (clip_model.*), which live outside this path
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("clip_model.")}
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._dirty = True
+        return out
+
+    def refresh(self):
+        """Re-uploads the parameters after they were modified in place."""
+        self._dirty = True
+
+    def _context(self):
+        if self._ctx is None:
+            if not torch.cuda.is_available():
+                raise _lib.LsdmError("SceneDiffusionModel.forward needs a HIP device: the hot path runs only in "
+                                     "liblsdm_hip.so (no CPU fallback)")
+            self._ctx = _lib.Context(self._device_index)
+        if self._dirty:
+            for name, tensor in self.state_dict().items():
+                if name.endswith("num_batches_tracked") or name.startswith("embed_timestep.sequence_pos_encoder"):
+                    continue
+                self._ctx.set_param(name, np.ascontiguousarray(tensor.detach().cpu().float().numpy()))
+            self._ctx.call("lsdm_finalize_params", self.max_cats)
+            self._dirty = False
+        return self._ctx
+
+    def _reserve(self, batch):
+        if batch > self._cap:
+            self._context().call("lsdm_reserve", batch)
+            self._cap = batch
+
+    def _set_schedule(self, key, tables):
+        """tables: 7 fp32 numpy arrays (see lsdm_set_schedule)."""
+        if self._schedule_key != key:
+            ctx = self._context()
+            arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in tables]
+            ctx.call("lsdm_set_schedule", len(arrs[0]), *[a.ctypes.data_as(_lib._vp) for a in arrs])
+            self._schedule_key = key
+
+    # ------------------------------------------------------------------ text boundary
+    def _encode_text(self, y, batch, device):
+        if isinstance(y, torch.Tensor):
+            feats = y
+        else:
+            if self.text_encoder is None:
+                self.text_encoder = _default_clip_encoder(self.clip_version, device)
+            feats = self.text_encoder(list(y))
+        feats = feats.to(device=device, dtype=torch.float32).contiguous()
+        if feats.shape != (batch, self.clip_dim):
+            raise ValueError("text features must be (B, %d), got %s" % (self.clip_dim, tuple(feats.shape)))
+        return feats
+
+    # ------------------------------------------------------------------ the hot path
+    def _run(self, mode, eta, x, mask, timesteps, given_objs, given_cats, y, fps_starts=None, noise_fn=None):
+        if not x.is_cuda:
+            raise _lib.LsdmError("SceneDiffusionModel runs on the HIP device only; got a %s tensor" % x.device)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("x must be a contiguous float32 tensor (it is updated in place)")
+        B, O, N, _ = given_objs.shape
+        if (O, N) != (NUM_SLOTS, self.pcd_points) or x.shape != (B, N, 3):
+            raise ValueError("expected given_objs (B,9,1024,3) and x (B,1024,3)")
+        dev = x.device
+        ctx = self._context()
+        self._reserve(B)
+        f32 = lambda v: v.to(device=dev, dtype=torch.float32).contiguous()
+        mask, given_objs, given_cats = f32(mask), f32(given_objs), f32(given_cats)
+        if given_cats.shape != (B, O, self.max_cats):
+            raise ValueError("given_cats must be (B,9,%d)" % self.max_cats)
+        t = timesteps.to(device=dev, dtype=torch.long).contiguous()
+        text = self._encode_text(y, B, dev)
+        if fps_starts is None:
+            # reference draw order and generator: CPU global RNG, sa1..sa4
+            fps_starts = [torch.randint(0, n, (B * O,), dtype=torch.long) for n in FPS_RANGES]
+        starts = torch.stack([s.reshape(-1) for s in fps_starts]).to(device=dev, dtype=torch.long).contiguous()
+        noise = noise_fn() if noise_fn is not None else None
+        out_cat = torch.empty(B, 1, self.max_cats, device=dev)
+        out_x0 = torch.empty_like(x)
+        out_guid = torch.empty_like(x)
+        out_sample = torch.empty_like(x) if mode != _lib.MODE_FORWARD else None
+        p = lambda v: None if v is None else v.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ctx.call("lsdm_step", mode, float(eta), B, p(x), p(mask), p(t), p(given_objs), p(given_cats), p(text), p(starts),
+                 p(noise), p(out_cat), p(out_x0), p(out_guid), p(out_sample), stream)
+        self.saved_cat = out_cat
+        self.saved_guiding_points = out_guid
+        return out_cat, out_x0, out_sample
+
+    def forward(self, x, mask, timesteps, given_objs, given_cats, y=None, force_mask=False, *, fps_starts=None):
+        """x (B,1024,3) is mutated in place (x += guidance, model/sdm.py:204).  Returns (out_cat, x_out)."""
+        out_cat, out_x0, _ = self._run(_lib.MODE_FORWARD, 0.0, x, mask, timesteps, given_objs, given_cats, y, fps_starts)
+        return out_cat, out_x0
+
+
+def _default_clip_encoder(clip_version, device):
+    """CLIP text tower as the reference uses it (model/sdm.py:245-277): tokenize with context 22, zero-pad to 77."""
+    try:
+        import clip  # third party: git+https://github.com/openai/CLIP.git (reference README.md:27)
+    except ImportError as e:
+        raise RuntimeError("the `clip` package is not installed: pass precomputed (B,512) text features as `y` "
+                           "or set model.text_encoder") from e
+    clip_model, _ = clip.load(clip_version, device=device, jit=False)
+    clip_model.eval()
+
+    def encode(texts):
+        tok = clip.tokenize(texts, context_length=22, truncate=True).to(device)
+        tok = torch.cat([tok, torch.zeros(tok.shape[0], 77 - 22, dtype=tok.dtype, device=tok.device)], dim=1)
+        with torch.no_grad():
+            return clip_model.encode_text(tok).float()
+
+    return encode

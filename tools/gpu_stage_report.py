@@ -1,0 +1,94 @@
+"""Prints max-abs differences of every stage of the HIP path against the CPU oracle (debug aid, run on a GPU box)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict  # noqa: E402
+from lsdm_amd.util.model_util import create_model_and_diffusion  # noqa: E402
+from oracle import cpu_ref  # noqa: E402
+
+torch.set_grad_enabled(False)
+DEV = "cuda:0"
+hip = C.CDLL("libamdhip64.so")
+
+
+def ws(m, name, shape, dtype=torch.float32):
+    ptr, n = m._ctx.workspace_tensor(name)
+    numel = int(np.prod(shape))
+    out = torch.empty(numel, dtype=dtype)
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(numel * out.element_size()), 2) == 0
+    return out.view(*shape)
+
+
+def rep(name, got, ref):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    if got.dtype.is_floating_point:
+        d = (got.double() - ref.double()).abs()
+        print("%-22s max-abs %.3e  (ref absmax %.3g, mean-abs diff %.3e)" % (name, d.max(), ref.abs().max(), d.mean()), flush=True)
+    else:
+        print("%-22s mismatches %d / %d" % (name, int((got.long() != ref.long()).sum()), got.numel()), flush=True)
+
+
+def main():
+    B = int(os.environ.get("B", 3))
+    sd = make_synthetic_state_dict(seed=0)
+    m, diff = create_model_and_diffusion("proxd")
+    m.load_state_dict(sd)
+    bt = make_synthetic_batch(B, seed=5)
+    torch.manual_seed(11)
+    x0 = torch.randn(B, 1024, 3)
+    t = torch.tensor([987, 500, 3][:B] + [100] * max(0, B - 3))
+    torch.manual_seed(12)
+    starts = cpu_ref.draw_fps_starts(B * 9)
+    taps = {}
+    xr = x0.clone()
+    t0 = time.time()
+    cat_o, out_o, guid_o = cpu_ref.forward(sd, xr, bt["mask"], t, bt["given_objs"], bt["given_cats"], bt["text_features"], fps_starts=starts, taps=taps)
+    print("oracle forward %.2fs" % (time.time() - t0))
+    x = x0.clone().to(DEV)
+    d = {k: v.to(DEV) for k, v in bt.items()}
+    out_cat, out = m(x, d["mask"], t.to(DEV), d["given_objs"], d["given_cats"], y=d["text_features"], fps_starts=starts)
+    torch.cuda.synchronize()
+    nc = B * 9
+    S, Cc = (1024, 256, 64, 16), (64, 128, 256, 512)
+    for l in range(4):
+        n = "sa%d" % (l + 1)
+        rep(n + ".fps_idx", ws(m, "fps_idx%d" % (l + 1), (nc, S[l]), torch.int32), taps[n + ".fps_idx"])
+        rep(n + ".new_xyz", ws(m, "xyz%d" % (l + 1), (nc, S[l], 3)), taps[n + ".new_xyz"])
+        rep(n + ".ball_idx", ws(m, "ball%d" % (l + 1), (nc, S[l], 32), torch.int32), taps[n + ".ball_idx"])
+        rep(n + ".new_points", ws(m, "feat%d" % (l + 1), (nc, S[l], Cc[l])), taps[n + ".new_points"])
+    for i, (n, N) in enumerate((("fp4", 64), ("fp3", 256), ("fp2", 1024), ("fp1", 1024))):
+        rep(n + ".nn_idx", ws(m, "nn_idx%d" % (i + 1), (nc, N, 3), torch.int32), taps[n + ".nn_idx"])
+        rep(n + ".nn_w", ws(m, "nn_w%d" % (i + 1), (nc, N, 3)), taps[n + ".nn_w"])
+    rep("fp4.out", ws(m, "fp4", (nc, 64, 256)), taps["fp4.out"])
+    rep("fp3.out", ws(m, "fp3", (nc, 256, 256)), taps["fp3.out"])
+    rep("fp2.out", ws(m, "fp2", (nc, 1024, 128)), taps["fp2.out"])
+    rep("pcd", ws(m, "pcd", (B, 9, 3072)), taps["pcd"])
+    rep("e0", ws(m, "e0", (B, 256)), torch.cat([taps["ets"], taps["enc"]], 1))
+    rep("w", ws(m, "w", (B, 9)), taps["w"])
+    rep("tr", ws(m, "tr", (B, 9, 12)), taps["tr"])
+    rep("hm", ws(m, "hm", (B, 1024, 3)), taps["hm"])
+    rep("o12", ws(m, "o12", (B, 9, 12)), taps["o"])
+    rep("out_cat", out_cat, cat_o)
+    rep("x (mutated)", x, xr)
+    rep("out", out, out_o)
+    rep("guiding", m.saved_guiding_points, guid_o)
+    # timing of one step at this batch
+    for _ in range(2):
+        m(x, d["mask"], t.to(DEV), d["given_objs"], d["given_cats"], y=d["text_features"], fps_starts=starts)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(5):
+        m(x, d["mask"], t.to(DEV), d["given_objs"], d["given_cats"], y=d["text_features"], fps_starts=starts)
+    torch.cuda.synchronize()
+    print("HIP forward B=%d: %.3f ms/step" % (B, (time.time() - t0) / 5 * 1e3))
+
+
+if __name__ == "__main__":
+    main()
