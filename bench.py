@@ -35,7 +35,10 @@ def cpu_baseline(batch, steps, C):
     """Times the CPU oracle on `steps` consecutive p_sample steps at a small batch; returns batch-steps/s scaled to B=64."""
     from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
     from oracle import cpu_ref
-    torch.set_num_threads(os.cpu_count())
+    # 16 threads is the fastest setting for the oracle's many small ATen ops on the 256-core GPU-box host
+    # (8: 2.3 s, 16: 2.0 s, 32: 2.2 s, 64: 3.6 s, 128+: minutes per B=2 step; tools/cpu_threads_probe.py)
+    threads = min(16, os.cpu_count())
+    torch.set_num_threads(threads)
     sd = make_synthetic_state_dict(seed=0, max_cats=C)
     bt = make_synthetic_batch(batch, seed=1, max_cats=C, num_objects=8)
     smp = cpu_ref.Sampler(sd)
@@ -48,10 +51,10 @@ def cpu_baseline(batch, steps, C):
         out = smp.p_sample(out["sample"], bt["mask"], t - 1 - k, bt["given_objs"], bt["given_cats"], bt["text_features"])
     dt = time.time() - t0
     sample_steps = batch * steps / dt
-    return {"value": sample_steps / 64.0, "unit": "denoising-steps/sec (batch of 64 chains)", "cores": os.cpu_count(),
+    return {"value": sample_steps / 64.0, "unit": "denoising-steps/sec (batch of 64 chains)", "cores": threads,
             "kind": "port", "sample_steps_per_s": sample_steps,
-            "sample": "%d p_sample steps at B=%d (8 objects, C=%d) with the torch-CPU oracle, %.1f s; scaled to B=64 by /64"
-                      % (steps, batch, C, dt)}
+            "sample": "%d p_sample steps at B=%d (8 objects, C=%d) with the torch-CPU oracle on %d of %d host cores, %.1f s; "
+                      "scaled to B=64 by /64" % (steps, batch, C, threads, os.cpu_count(), dt)}
 
 
 def main():
@@ -62,8 +65,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))

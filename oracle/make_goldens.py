@@ -2,9 +2,10 @@
 CPU through oracle/ref_shims.py.  Build-container only; the outputs are small data fixtures (inputs
 are regenerated from seeds by lsdm_amd/synthetic.py; files hold expected outputs, taps and RNG draws).
 
-    python -m oracle.make_goldens [--only g1,g2,g3,g4,g5,long] [--long-steps 1000]
+    python -m oracle.make_goldens [--only g0,g1,g2,g3,g4,g5,long] [--long-steps 1000]
 
 Golden sets:
+  G0  state_dict names/shapes/dtypes of the reference model (proxd C=13, humanise C=11).
   G1  schedule tables: cosine-1000 and the ddim50 / ddim250 respaced processes (float64).
   G2  one SceneDiffusionModel.forward, B=3 ragged masks, C in {13, 43}: outputs + module taps.
   G3  PointNet++ known answers on 3 clouds (one all-zero): FPS / ball-query / 3-NN indices, features.
@@ -65,6 +66,18 @@ def save(name, **arrs):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **conv)
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def g0():
+    """state_dict contract of the reference model (names, shapes, dtypes, registration order)."""
+    import json
+    for C in (13, 11):
+        kw = mu.get_default_model_proxd() if C == 13 else mu.get_default_model_humanise()
+        m = SDM(**kw, use_cuda=False)
+        spec = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        with open(os.path.join(OUT, "g0_state_dict_c%d.json" % C), "w") as fh:
+            json.dump(spec, fh)
+        print("wrote g0_state_dict_c%d.json (%d entries)" % (C, len(spec)))
 
 
 def g1():
@@ -248,7 +261,7 @@ def long_chain(steps):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5")
     ap.add_argument("--long-steps", type=int, default=1000)
     a = ap.parse_args()
     todo = a.only.split(",")

@@ -122,8 +122,14 @@ def _install_stubs():
 def import_reference():
     """Returns (SceneDiffusionModel, create_gaussian_diffusion, get_default_diffusion, defaults, clip_stub)."""
     _install_stubs()
-    if REF_ROOT not in sys.path:
-        sys.path.insert(0, REF_ROOT)
+    # The repo root carries drop-in alias packages with the reference's own names (model/, diffusion/, util/,
+    # run/).  They are regular packages and would shadow the reference's namespace packages wherever they sit
+    # on sys.path, so the repo root leaves sys.path while the reference is imported and returns at the END.
+    repo_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in [m for m in sys.modules if m.split(".")[0] in ("model", "diffusion", "util", "run", "posa")]:
+        del sys.modules[name]
+    sys.path[:] = [p for p in sys.path if p not in ("", ".", repo_root, REF_ROOT)]
+    sys.path.insert(0, REF_ROOT)
     os.chdir(REF_ROOT)  # posa_models.Decoder reads ./mesh_ds relative to the CWD (posa_models.py:293)
     import posa.posa_utils as posa_utils
     import posa.posa_models as posa_models
@@ -141,4 +147,8 @@ def import_reference():
     posa_models.load_ds_us_param = load_cpu
     from model.sdm import SceneDiffusionModel
     import util.model_util as mu
+    import diffusion.gaussian_diffusion  # noqa: F401  (cached in sys.modules for the golden generator)
+    import diffusion.respace  # noqa: F401
+    import model.pcd_backbone.pointnet2_utils  # noqa: F401
+    sys.path.append(repo_root)
     return SceneDiffusionModel, mu, sys.modules["clip"]

@@ -1,0 +1,170 @@
+"""CPU tests of the product's host side: C-ABI surface, schedule tables, respacing, state_dict contract, the
+fail-loud rule, data format + CLI plumbing (BASELINE configs[0]) with the oracle injected as the sampler."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from lsdm_amd import _lib
+from lsdm_amd.diffusion.respace import space_timesteps
+from lsdm_amd.synthetic import make_synthetic_state_dict
+from lsdm_amd.util.model_util import create_gaussian_diffusion, create_model_and_diffusion, get_default_diffusion
+
+torch.set_grad_enabled(False)
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "lsdm_hip.h")).read()
+    declared = set(re.findall(r"\b(lsdm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"lsdm_ctx", "lsdm_status", "lsdm_mode"}
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(_lib.LIB_PATH)       # no compute calls: there is no GPU here
+    for name in sorted(declared):
+        assert hasattr(lib, name), "liblsdm_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+
+
+def test_no_cpu_fallback():
+    """The product fails loudly without a HIP device instead of computing anything on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m, d = create_model_and_diffusion("proxd", use_cuda=False)
+    args = (torch.zeros(1, 1024, 3), torch.zeros(1, 9), torch.zeros(1).long(), torch.zeros(1, 9, 1024, 3), torch.zeros(1, 9, 13))
+    with pytest.raises(_lib.LsdmError):
+        m(*args, y=torch.zeros(1, 512))
+    with pytest.raises(_lib.LsdmError):
+        d.p_sample_loop(m, [1, 1024, 3], args[1], args[3], args[4], torch.zeros(1, 512), clip_denoised=False, device="cpu")
+    with pytest.raises(_lib.LsdmError, match="no HIP device"):
+        _lib.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    import ast
+    roots = [os.path.join(ROOT, d) for d in ("lsdm_amd", "model", "diffusion", "util", "run")]
+    for root in roots:
+        for base, _, files in os.walk(root):
+            for f in files:
+                if not f.endswith(".py"):
+                    continue
+                tree = ast.parse(open(os.path.join(base, f)).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or ""]
+                    assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), os.path.join(base, f)
+                    if isinstance(node, ast.Call) and getattr(node.func, "id", "") in ("__import__", "exec", "eval"):
+                        raise AssertionError("dynamic import/exec in product file %s" % os.path.join(base, f))
+
+
+# ------------------------------------------------------------------------------------------------ schedules
+@pytest.mark.parametrize("tag,resp", [("t1000", ""), ("ddim50", "ddim50"), ("ddim250", "ddim250")])
+def test_schedule_tables_bit_exact_vs_reference(golden, tag, resp):
+    g = golden("g1_schedule")
+    d = create_gaussian_diffusion(get_default_diffusion(), timestep_respacing=resp)
+    assert d.timestep_map == list(g["%s.timestep_map" % tag])
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "posterior_variance", "posterior_log_variance_clipped",
+              "posterior_mean_coef1", "posterior_mean_coef2", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+              "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        np.testing.assert_array_equal(getattr(d, k), g["%s.%s" % (tag, k)], err_msg=k)
+    assert d.num_timesteps == len(g["%s.betas" % tag])
+
+
+def test_space_timesteps_sections():
+    assert space_timesteps(1000, [1000]) == set(range(1000))
+    assert space_timesteps(1000, "ddim50") == set(range(0, 1000, 20))
+    assert space_timesteps(1000, "ddim250") == set(range(0, 1000, 4))
+    assert space_timesteps(300, "10,15,20") == space_timesteps(300, [10, 15, 20])
+    assert len(space_timesteps(300, [10, 15, 20])) == 45 and max(space_timesteps(300, [10, 15, 20])) == 299
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+    with pytest.raises(ValueError):
+        space_timesteps(10, [20])
+
+
+# ------------------------------------------------------------------------------------------------ state_dict
+@pytest.mark.parametrize("datatype,C", [("proxd", 13), ("humanise", 11)])
+def test_state_dict_contract(datatype, C):
+    want = json.load(open(os.path.join(GOLDEN, "g0_state_dict_c%d.json" % C)))
+    m, _ = create_model_and_diffusion(datatype, use_cuda=False)
+    got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+    assert got == want                                  # names, shapes, dtypes and order of the reference
+    res = m.load_state_dict(make_synthetic_state_dict(max_cats=C), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    sd = make_synthetic_state_dict(max_cats=C)
+    sd["clip_model.positional_embedding"] = torch.zeros(77, 512)   # real checkpoints also carry the CLIP tower
+    m.load_state_dict(sd, strict=True)
+
+
+def test_constructor_signature_matches_reference():
+    import inspect
+    from lsdm_amd.model.sdm import SceneDiffusionModel
+    sig = inspect.signature(SceneDiffusionModel.__init__)
+    names = list(sig.parameters)[1:]
+    assert names == ["seg_len", "modality", "clip_version", "clip_dim", "dropout", "n_layer", "n_head", "f_vert", "dim_ff",
+                     "cat_emb", "mesh_ds_dir", "posa_path", "latent_dim", "cond_mask_prob", "device", "vert_dims", "obj_cat",
+                     "data_rep", "njoints", "use_cuda", "pcd_points", "pcd_dim", "xyz_dim", "max_cats", "translation_params",
+                     "pcd_backbone_type", "human_backbone_type", "text_encoder_type", "kwargs"]
+    assert sig.parameters["max_cats"].default == 13 and sig.parameters["clip_dim"].default == 768
+    fwd = list(inspect.signature(SceneDiffusionModel.forward).parameters)
+    assert fwd[:8] == ["self", "x", "mask", "timesteps", "given_objs", "given_cats", "y", "force_mask"]
+
+
+# ------------------------------------------------------------------------------------------------ CLI / config[0]
+class OracleBackend:
+    """Test-only sampler: the CPU oracle behind the CLI's backend protocol (the product default is HipBackend)."""
+
+    def __init__(self, args, text_encoder):
+        from oracle import cpu_ref
+        self.smp = cpu_ref.Sampler(make_synthetic_state_dict(seed=0), timestep_respacing=args.timestep_respacing or None)
+        self.text_encoder, self.use_ddim = text_encoder, args.use_ddim
+
+    def sample(self, shape, mask, given_objs, given_cats, y):
+        out = self.smp.sample_loop(shape, mask, given_objs, given_cats, self.text_encoder(list(y)), use_ddim=self.use_ddim)
+        return out, self.smp.saved_cat, self.smp.saved_guiding_points
+
+
+def test_cli_plumbing_synthetic_proxd_test(tmp_path):
+    """BASELINE configs[0]: run.test_sdm on 4 synthetic proxd_test samples, DDIM, CPU (plumbing + file outputs).
+    ddim50 when LSDM_FULL_CONFIG0=1 (about 4 minutes of oracle time), ddim5 otherwise."""
+    import run.test_sdm as cli
+    resp = "ddim50" if os.environ.get("LSDM_FULL_CONFIG0") == "1" else "ddim5"
+    out = tmp_path / "out"
+    rc = cli.main([str(tmp_path / "data"), "--synthetic", "4", "--device", "cpu", "--use_ddim", "--timestep_respacing", resp,
+                   "--output_dir", str(out), "--fix_ori", "--test_on_valid_set", "--model_name", "sdm"], backend_factory=OracleBackend)
+    assert rc == 0
+    lines = open(out / "results.txt").read().splitlines()
+    assert len(lines) == 4 + 5
+    assert all(re.fullmatch(r"Chamfer distance for seq Scene\d\d_\d{5}_01: \d+\.\d{4}", l) for l in lines[:4])
+    for l, prefix in zip(lines[4:], ("Final Chamfer distance: ", "Final EMD: ", "Final F1 score: ", "Category accuracy: ", "Top 3 accuracy: ")):
+        assert l.startswith(prefix) and re.fullmatch(r"-?\d+\.\d{4}", l[len(prefix):])
+    for sub in ("predictions", "guiding_points"):
+        files = sorted(os.listdir(out / sub))
+        assert len(files) == 4
+        a = np.load(out / sub / files[0])
+        assert a.shape == (1024, 3) and a.dtype == np.float32 and np.isfinite(a).all()
+    # dataset format: third context line unstripped / no trailing newline (Q14), human slot mask 0
+    from lsdm_amd.data import ProxTextDataset
+    ds = ProxTextDataset(str(tmp_path / "data" / "proxd_test"), objs_data_dir=str(tmp_path / "data" / "objs"))
+    mask, verts, cats, tgt, tcat, prompt = ds[0]
+    assert mask[0] == 0 and mask.sum() >= 1 and verts.shape == (9, 1024, 3) and cats.shape == (9, 13) and cats[0, 0] == 1
+    assert tgt.shape == (1024, 3) and tcat.sum() == 1 and prompt.startswith("synthetic prompt")
+
+
+def test_metrics_known_answers():
+    from lsdm_amd.metrics import accuracy, calculate_fscore, chamfer_distance, emd
+    a = torch.tensor([[[0.0, 0, 0], [1, 0, 0]]])
+    b = torch.tensor([[[0.0, 0, 0], [1, 0, 0.5]]])
+    assert abs(float(chamfer_distance(a, b)) - 0.25) < 1e-6          # (0 + .25)/2 + (0 + .25)/2
+    assert abs(emd(a, b) - 0.25) < 1e-6
+    f, p, r = calculate_fscore(a[0], b[0], th=0.1)
+    assert (f, p, r) == (0.5, 0.5, 0.5)
+    out = torch.tensor([[0.1, 0.5, 0.2, 0.2], [0.7, 0.1, 0.1, 0.1]])
+    assert [float(v) for v in accuracy(out, torch.tensor([2, 0]), topk=(1, 3))] == [50.0, 100.0]
