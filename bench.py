@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the dense stacks (geometry and sampler arithmetic are always fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -87,7 +89,7 @@ def main():
     from lsdm_amd.util.model_util import create_model_and_diffusion
 
     B, K, W, C = a.batch, a.steps, a.warmup, 13
-    model, diffusion = create_model_and_diffusion("proxd", device=local_rank)
+    model, diffusion = create_model_and_diffusion("proxd", device=local_rank, precision=a.precision)
     model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
     ctx = model._context()
     model._reserve(B)
@@ -164,7 +166,7 @@ def main():
             "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
             "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch)",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "sample_steps_per_s": world * B * K / dt,
             "config": {"workload": "BASELINE configs[2] shapes (B=%d chains/GPU, 8 objects + human x 1024 pts, C=13, cosine T=1000, "
                                    "p_sample steps t=%d..%d) in fp32 (the parity-tested precision of configs[1]); strict per-step "

@@ -43,6 +43,13 @@ typedef enum {
     LSDM_MODE_DDIM = 2      /* forward + DDIM step                      (gaussian_diffusion.py:790-811) */
 } lsdm_mode;
 
+typedef enum {
+    LSDM_PREC_F32 = 0,      /* exact fp32 products: v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain)            */
+    LSDM_PREC_BF16X3 = 1,   /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate:
+                             * fp32-class results (dropped term 2^-18 relative) at 5.3x the f32 MFMA rate       */
+    LSDM_PREC_BF16 = 2      /* plain bf16 products, fp32 accumulate; level features stored as bf16             */
+} lsdm_precision;
+
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
 int lsdm_create(lsdm_ctx** out, int device);
 int lsdm_destroy(lsdm_ctx* ctx);
@@ -53,6 +60,10 @@ const char* lsdm_last_error(const lsdm_ctx* ctx);
 /* `name` is a state_dict key of SURVEY.md Appendix A; `data` is a HOST fp32 pointer (num_batches_tracked and the
  * duplicate pe alias are ignored).  Shapes are checked in lsdm_finalize_params. */
 int lsdm_set_param(lsdm_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
+/* arithmetic of the dense (1x1-conv / Linear) stacks; geometry (FPS, ball query, 3-NN), normalisations, softmaxes and
+ * the sampler update are always fp32.  Call before lsdm_finalize_params / lsdm_reserve (changing it invalidates both). */
+int lsdm_set_precision(lsdm_ctx* ctx, int precision);
+int lsdm_get_precision(const lsdm_ctx* ctx);
 /* folds eval-mode BatchNorm into the 1x1 convolutions, packs the MFMA operands, uploads.  max_cats = C. */
 int lsdm_finalize_params(lsdm_ctx* ctx, int max_cats);
 /* per-timestep fp32 tables of the (possibly respaced) diffusion process, length T each:

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsdm_hip.so")
 
 MODE_FORWARD, MODE_P_SAMPLE, MODE_DDIM = 0, 1, 2
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
 
 
 class LsdmError(RuntimeError):
@@ -24,6 +25,8 @@ _SIGNATURES = {
     "lsdm_destroy": (_i, [_vp]),
     "lsdm_last_error": (C.c_char_p, [_vp]),
     "lsdm_set_param": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i]),
+    "lsdm_set_precision": (_i, [_vp, _i]),
+    "lsdm_get_precision": (_i, [_vp]),
     "lsdm_finalize_params": (_i, [_vp, _i]),
     "lsdm_set_schedule": (_i, [_vp, _i] + [_vp] * 7),
     "lsdm_reserve": (_i, [_vp, _i]),

@@ -40,6 +40,10 @@ struct lsdm_ctx {
     std::vector<void*> allocs;  // parameter arena
     // device parameter blocks
     Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
+    int prec = LSDM_PREC_F32;           // arithmetic of the dense layers (lsdm_set_precision)
+    DenseH sa_h[4][3], fp_h[4][3], head_h[1];  // split-bf16 operands of the same layers (prec != F32)
+    void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
+    void* fpo_b[3] = {};
     CondParams cond{};
     PosaParams posa{};
     SceneAttnParams sattn{};
@@ -156,7 +160,72 @@ std::vector<float> pack_weight(const std::vector<float>& W, int N, int K) {
     return p;
 }
 
-// (conv|linear) [+ eval BatchNorm folded: y = (Wx + b - mean) * gamma / sqrt(var + eps) + beta] -> packed Dense
+uint16_t f2bf(float f) {  // round-to-nearest-even fp32 -> bf16 (what v_cvt_pk_bf16_f32 does)
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf2f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// split-bf16 MFMA operand layout (bf16_core.hpp): Wp[kb][n][np][16], k = 16*kb + j; column k of the packed matrix is
+// column perm[k] of W (perm empty = identity); K zero-padded to a multiple of 16.  np = 2: hi and lo planes.
+std::vector<uint16_t> pack_weight_h(const std::vector<float>& W, int N, int K, int np, const std::vector<int>& perm) {
+    const int Kp = (K + 15) / 16 * 16;
+    std::vector<uint16_t> p((size_t)Kp * N * np, 0);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float v = W[(size_t)n * K + (perm.empty() ? k : perm[k])];
+            const uint16_t hi = f2bf(v);
+            const size_t at = ((size_t)(k / 16) * N + n) * np * 16 + (k % 16);
+            p[at] = hi;
+            if (np == 2) p[at + 16] = f2bf(v - bf2f(hi));
+        }
+    return p;
+}
+
+// (conv|linear) [+ eval BatchNorm folded: y = (Wx + b - mean) * gamma / sqrt(var + eps) + beta] -> W (N,K), bias (N)
+bool fold_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname, const std::string& bn, int N, int K,
+                std::vector<float>& W, std::vector<float>& Bv) {
+    const HostTensor* w = find(c, wname, {N, K});
+    const HostTensor* b = find(c, bname, {N});
+    if (!w || !b) return false;
+    W = w->data;
+    Bv = b->data;
+    if (!bn.empty()) {
+        const HostTensor* g = find(c, bn + ".weight", {N});
+        const HostTensor* be = find(c, bn + ".bias", {N});
+        const HostTensor* mu = find(c, bn + ".running_mean", {N});
+        const HostTensor* var = find(c, bn + ".running_var", {N});
+        if (!g || !be || !mu || !var) return false;
+        for (int n = 0; n < N; ++n) {
+            const double s = (double)g->data[n] / std::sqrt((double)var->data[n] + 1e-5);
+            for (int k = 0; k < K; ++k) W[(size_t)n * K + k] = (float)((double)W[(size_t)n * K + k] * s);
+            Bv[n] = (float)(((double)Bv[n] - (double)mu->data[n]) * s + (double)be->data[n]);
+        }
+    }
+    return true;
+}
+
+bool load_dense_h(lsdm_ctx* c, const std::string& wname, const std::string& bname, const std::string& bn, int N, int K, int np,
+                  const std::vector<int>& perm, DenseH* out) {
+    std::vector<float> W, Bv;
+    if (!fold_dense(c, wname, bname, bn, N, K, W, Bv)) return false;
+    std::vector<uint16_t> p = pack_weight_h(W, N, K, np, perm);
+    static_assert(sizeof(float) == 2 * sizeof(uint16_t), "upload granularity");
+    if (p.size() % 2) p.push_back(0);
+    out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(p.data()), p.size() / 2));
+    out->b = upload(c, Bv.data(), Bv.size());
+    return out->w && out->b;
+}
+
+// (conv|linear) [+ eval BatchNorm] -> packed Dense of the f32 MFMA core
 bool load_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname, const std::string& bn, int N, int K, Dense* out) {
     const HostTensor* w = find(c, wname, {N, K});
     const HostTensor* b = find(c, bname, {N});
@@ -195,7 +264,10 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
 }
 
 // geometry + dense stages of get_backbone.forward on `num_clouds` clouds
+int run_scene_encoder_h(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st);
+
 int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
+    if (c->prec != LSDM_PREC_F32) return run_scene_encoder_h(c, clouds, starts, nc, out, st);
     prof_mark(c, K_FPS, st);
     launch_fps_chain(clouds, starts, nc, c->idx, c->xyz, st);
     const float* lvl_xyz[5] = {clouds, c->xyz[0], c->xyz[1], c->xyz[2], c->xyz[3]};
@@ -226,6 +298,46 @@ int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, i
     prof_mark(c, K_FP1, st);
     launch_fp(1, nc, nullptr, c->fpo2, c->nn_idx[3], c->nn_w[3], c->fp[3], c->head, out, st);
     return check_launch(c, "scene encoder");
+}
+
+// same stage sequence on the split-bf16 core; bf16x3 keeps the fp32 feature tensors, bf16 uses the bf16 ones
+int run_scene_encoder_h(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
+    const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
+    void* feat[4];
+    void* fpo[3];
+    for (int l = 0; l < 4; ++l) feat[l] = np == 2 ? (void*)c->feat[l] : c->feat_b[l];
+    fpo[0] = np == 2 ? (void*)c->fpo4 : c->fpo_b[0];
+    fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
+    fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
+    prof_mark(c, K_FPS, st);
+    launch_fps_chain(clouds, starts, nc, c->idx, c->xyz, st);
+    const float* lvl_xyz[5] = {clouds, c->xyz[0], c->xyz[1], c->xyz[2], c->xyz[3]};
+    const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
+    for (int l = 0; l < 4; ++l) {
+        const float r2 = (float)(kRadius[l] * kRadius[l]);
+        prof_mark(c, K_BALL1 + l, st);
+        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], nc, kSrcN[l], kS[l], r2, c->ball[l], st);
+        prof_mark(c, K_SA1 + l, st);
+        launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], c->ball[l], c->sa_h[l], feat[l], st);
+    }
+    const Lin head2{c->head[1].w, c->head[1].b};
+    prof_mark(c, K_NN4, st);
+    launch_three_nn(c->xyz[2], c->xyz[3], nc, 64, 16, c->nn_idx[0], c->nn_w[0], st);
+    prof_mark(c, K_FP4, st);
+    launch_fp_h(np, 4, nc, feat[2], feat[3], c->nn_idx[0], c->nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
+    prof_mark(c, K_NN3, st);
+    launch_three_nn(c->xyz[1], c->xyz[2], nc, 256, 64, c->nn_idx[1], c->nn_w[1], st);
+    prof_mark(c, K_FP3, st);
+    launch_fp_h(np, 3, nc, feat[1], fpo[0], c->nn_idx[1], c->nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
+    prof_mark(c, K_NN2, st);
+    launch_three_nn(c->xyz[0], c->xyz[1], nc, 1024, 256, c->nn_idx[2], c->nn_w[2], st);
+    prof_mark(c, K_FP2, st);
+    launch_fp_h(np, 2, nc, feat[0], fpo[1], c->nn_idx[2], c->nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
+    prof_mark(c, K_NN1, st);
+    launch_three_nn(clouds, c->xyz[0], nc, 1024, 1024, c->nn_idx[3], c->nn_w[3], st);
+    prof_mark(c, K_FP1, st);
+    launch_fp_h(np, 1, nc, nullptr, fpo[2], c->nn_idx[3], c->nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
+    return check_launch(c, "scene encoder (bf16 core)");
 }
 
 int run_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
@@ -295,6 +407,24 @@ int lsdm_set_param(lsdm_ctx* c, const char* name, const float* data, const int64
     return LSDM_OK;
 }
 
+int lsdm_set_precision(lsdm_ctx* c, int precision) {
+    if (!c || precision < LSDM_PREC_F32 || precision > LSDM_PREC_BF16) return fail(c, LSDM_ERR_ARG, "lsdm_set_precision: bad precision %d", precision);
+    if (precision != c->prec) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipDeviceSynchronize());
+        // operand packing and the workspace element types depend on it
+        c->prec = precision;
+        c->finalized = false;
+        for (void* p : c->ws_allocs) (void)hipFree(p);
+        c->ws_allocs.clear();
+        c->ws_named.clear();
+        c->cap_B = 0;
+    }
+    return LSDM_OK;
+}
+
+int lsdm_get_precision(const lsdm_ctx* c) { return c ? c->prec : LSDM_ERR_ARG; }
+
 int lsdm_finalize_params(lsdm_ctx* c, int C) {
     if (!c || C <= 0 || C > 512) return fail(c, LSDM_ERR_ARG, "lsdm_finalize_params: bad max_cats");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -327,6 +457,35 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
         }
     }
     ok = ok && load_dense(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, &c->head[0]);
+    if (c->prec != LSDM_PREC_F32) {
+        const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
+        for (int l = 0; l < 4 && ok; ++l) {
+            int last = sa_in[l];
+            for (int i = 0; i < 3 && ok; ++i) {
+                const std::string p = std::string("pcd_backbone.") + sa_names[l];
+                // first layer: the kernels order K as [features (D) || xyz - centroid (3)], the reference as [xyz (3) || features]
+                std::vector<int> perm;
+                if (i == 0) {
+                    const int D = last - 3;
+                    for (int k = 0; k < D; ++k) perm.push_back(3 + k);
+                    for (int k = 0; k < 3; ++k) perm.push_back(k);
+                }
+                ok = load_dense_h(c, p + ".mlp_convs." + std::to_string(i) + ".weight", p + ".mlp_convs." + std::to_string(i) + ".bias",
+                                  p + ".mlp_bns." + std::to_string(i), sa_mlp[l][i], last, np, perm, &c->sa_h[l][i]);
+                last = sa_mlp[l][i];
+            }
+        }
+        for (int l = 0; l < 4 && ok; ++l) {
+            int last = fp_in[l];
+            for (int i = 0; i < 3 && ok && fp_mlp[l][i]; ++i) {
+                const std::string p = std::string("pcd_backbone.") + fp_names[l];
+                ok = load_dense_h(c, p + ".mlp_convs." + std::to_string(i) + ".weight", p + ".mlp_convs." + std::to_string(i) + ".bias",
+                                  p + ".mlp_bns." + std::to_string(i), fp_mlp[l][i], last, np, {}, &c->fp_h[l][i]);
+                last = fp_mlp[l][i];
+            }
+        }
+        ok = ok && load_dense_h(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, np, {}, &c->head_h[0]);
+    }
     if (ok) {
         Lin l{};
         ok = load_lin(c, "pcd_backbone.conv2", 3, 128, &l);
@@ -450,6 +609,13 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->tr = ws_alloc<float>(c, "tr", nc * 12)) && (c->w = ws_alloc<float>(c, "w", nc)) &&
          (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) && (c->h2p = ws_alloc<float>(c, "h2p", (size_t)B * 256 * 512)) &&
          (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->tbuf = ws_alloc<int64_t>(c, "tbuf", (size_t)B));
+    if (ok && c->prec == LSDM_PREC_BF16) {
+        // 2-byte elements: ws_alloc<uint16_t>
+        for (int l = 0; l < 4 && ok; ++l)
+            ok = (c->feat_b[l] = ws_alloc<uint16_t>(c, (std::string("feat_bf") + lv[l]).c_str(), nc * kS[l] * kFeatC[l])) != nullptr;
+        ok = ok && (c->fpo_b[0] = ws_alloc<uint16_t>(c, "fp4_bf", nc * 64 * 256)) && (c->fpo_b[1] = ws_alloc<uint16_t>(c, "fp3_bf", nc * 256 * 256)) &&
+             (c->fpo_b[2] = ws_alloc<uint16_t>(c, "fp2_bf", nc * 1024 * 128));
+    }
     if (!ok) return LSDM_ERR_HIP;
     c->cap_B = B;
     return LSDM_OK;

@@ -1,0 +1,167 @@
+// Split-bf16 MFMA tile core (gfx950): the dense layers of the path on v_mfma_f32_32x32x16_bf16.
+//
+// fp32 operands are carried as one or two bf16 planes:
+//   NP = 2 ("bf16x3"): a = a_hi + a_lo (a_hi = bf16(a), a_lo = bf16(a - a_hi)); a product a*w is evaluated as
+//                      a_lo*w_hi + a_hi*w_lo + a_hi*w_hi with fp32 accumulation (the dropped a_lo*w_lo term is
+//                      2^-18 relative) -- fp32-class results at 16/3 = 5.3x the rate of the f32-input MFMA;
+//   NP = 1 ("bf16")  : a_hi*w_hi only, the full 16x rate.
+// Layout conventions
+//   * activations live in LDS as [row = point][k] bf16 with a leading dimension of 8*odd elements (16*odd bytes):
+//     the ds_read_b128 of a fragment (32 rows x 2 k-halves) is bank-conflict free.  The lo plane follows the hi
+//     plane at a fixed element offset (`plane`).
+//   * weights are packed on the host as Wp[kb][n][NP][16] (k = 16*kb + j, K zero-padded to 16), so one wave's fragment
+//     load of a 32-column block is a contiguous 1 KiB (NP = 1) / 2 KiB (NP = 2) segment served from L2.
+//   * both operands index k as (lane>>5)*8 + j, j = 0..7 (one 16-byte load per lane per plane).
+//   * a layer is evaluated TRANSPOSED by default (weights = MFMA A operand, activations = B operand), D[n][point]:
+//     a lane then owns 4 consecutive output channels of one point per accumulator quad, so the epilogue
+//     (bias + activation + bf16 split) packs 4 channels into one 8-byte LDS store of the next layer's operand.
+//     The last layer of a stack may use the direct orientation D[point][n] (max-pool over points in-lane; 32
+//     consecutive channels per half-wave for global stores).
+#pragma once
+#include "common.hpp"
+
+namespace lsdm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct DenseH {  // packed bf16 planes Wp[kb][n][NP][16] + fp32 bias[n]
+    const __bf16* w;
+    const float* b;
+};
+
+__host__ __device__ constexpr int round16(int k) { return (k + 15) / 16 * 16; }
+// LDS leading dimension (bf16 elements) for a logical width k (multiple of 8): (ld/8) odd
+__host__ __device__ constexpr int ldh(int k) { return ((k / 8) % 2 == 1) ? k : k + 8; }
+__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+__device__ __forceinline__ float bf_hi_as_float(__bf16 h) { return (float)h; }
+
+// split 4 fp32 values into bf16 hi (and lo) quads
+template <int NP>
+__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, bf16x4& hi, bf16x4& lo) {
+    hi[0] = (__bf16)v0; hi[1] = (__bf16)v1; hi[2] = (__bf16)v2; hi[3] = (__bf16)v3;
+    if constexpr (NP == 2) {
+        lo[0] = (__bf16)(v0 - (float)hi[0]); lo[1] = (__bf16)(v1 - (float)hi[1]);
+        lo[2] = (__bf16)(v2 - (float)hi[2]); lo[3] = (__bf16)(v3 - (float)hi[3]);
+    }
+}
+
+// store 4 consecutive fp32 values as bf16 planes at dst (8-byte aligned)
+template <int NP>
+__device__ __forceinline__ void store_split4(__bf16* dst, int plane, float v0, float v1, float v2, float v3) {
+    bf16x4 hi, lo;
+    split4<NP>(v0, v1, v2, v3, hi, lo);
+    *reinterpret_cast<bf16x4*>(dst) = hi;
+    if constexpr (NP == 2) *reinterpret_cast<bf16x4*>(dst + plane) = lo;
+}
+
+// value of an LDS activation (hi [+ lo])
+template <int NP>
+__device__ __forceinline__ float lds_val(const __bf16* p, int plane) {
+    float v = (float)p[0];
+    if constexpr (NP == 2) v += (float)p[plane];
+    return v;
+}
+
+// acc[rb] += X[rb-th 32-point block, k-blocks kb0..kb1) (x) W(columns cb*32 .. +32)
+//   X     : LDS hi plane, row 0 of the wave's first point block, k = x_kb_off*16 at column 0
+//   WA    : true  -> D[n][point]  (weights are the A operand)
+//           false -> D[point][n]  (activations are the A operand)
+template <int RB, int NP, bool WA>
+__device__ __forceinline__ void mma_kloop_h(f32x16 (&acc)[RB], const __bf16* X, int ldx, int plane, const __bf16* __restrict__ Wp,
+                                            int N, int cb, int kb0, int kb1, int x_kb_off, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const __bf16* xp = X + i * ldx + 8 * h;
+    const __bf16* wp = Wp + ((size_t)(cb * 32 + i) * NP) * 16 + 8 * h;
+    const size_t ws = (size_t)N * NP * 16;
+    bf16x8 wh_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)kb0 * ws);
+    bf16x8 wl_n = wh_n;
+    if constexpr (NP == 2) wl_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)kb0 * ws + 16);
+#pragma unroll 1
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const bf16x8 wh = wh_n, wl = wl_n;
+        if (kb + 1 < kb1) {
+            wh_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)(kb + 1) * ws);
+            if constexpr (NP == 2) wl_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)(kb + 1) * ws + 16);
+        }
+        bf16x8 xh[RB], xl[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const __bf16* p = xp + rb * 32 * ldx + (kb - x_kb_off) * 16;
+            xh[rb] = *reinterpret_cast<const bf16x8*>(p);
+            if constexpr (NP == 2) xl[rb] = *reinterpret_cast<const bf16x8*>(p + plane);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if constexpr (WA) {
+                if constexpr (NP == 2) {
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[rb], acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[rb], acc[rb], 0, 0, 0);
+                }
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[rb], acc[rb], 0, 0, 0);
+            } else {
+                if constexpr (NP == 2) {
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], wh, acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], wl, acc[rb], 0, 0, 0);
+                }
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], wh, acc[rb], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int RB>
+__device__ __forceinline__ void acc_zero_h(f32x16 (&acc)[RB]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+}
+
+// Work split of a (TM points) x (N channels) layer over NW waves: channel blocks first, then point groups.
+template <int NW, int TM, int N>
+struct SplitH {
+    static constexpr int RBT = TM / 32, CB = N / 32;
+    static constexpr int CSTEP = (CB >= NW) ? NW : CB;   // channel blocks processed concurrently
+    static constexpr int WPC = NW / CSTEP;               // waves sharing one channel block (split points)
+    static constexpr int RB = RBT / WPC;                 // point blocks per wave
+    static_assert(TM % 32 == 0 && N % 32 == 0, "tile dims");
+    static_assert(NW % CSTEP == 0 && RBT % WPC == 0 && RB >= 1, "tile split");
+};
+
+// epilogue of a transposed (WA) layer: bias + activation + split -> LDS [point][channel]
+template <int ACT, int RB, int NP>
+__device__ __forceinline__ void store_lds_h(const f32x16 (&acc)[RB], int rb0, int cb, const float* __restrict__ bias, __bf16* out,
+                                            int ldo, int plane, int lane) {
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = cb * 32 + 8 * q + 4 * h;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            store_split4<NP>(out + ((rb0 + rb) * 32 + p) * ldo + n, plane, apply_act<ACT>(acc[rb][4 * q + 0] + bv[0]),
+                             apply_act<ACT>(acc[rb][4 * q + 1] + bv[1]), apply_act<ACT>(acc[rb][4 * q + 2] + bv[2]),
+                             apply_act<ACT>(acc[rb][4 * q + 3] + bv[3]));
+        }
+    }
+}
+
+// One dense layer, whole K resident in LDS: out(LDS) = act(W x X + bias), transposed orientation
+template <int NW, int TM, int K, int N, int ACT, int NP>
+__device__ __forceinline__ void layer_lds_h(const __bf16* X, int ldx, int xplane, DenseH L, __bf16* out, int ldo, int oplane) {
+    using TS = SplitH<NW, TM, N>;
+    static_assert(K % 16 == 0, "K must be padded to 16");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
+#pragma unroll 1
+    for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
+        f32x16 acc[TS::RB];
+        acc_zero_h(acc);
+        mma_kloop_h<TS::RB, NP, true>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb, 0, K / 16, 0, lane);
+        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, L.b, out, ldo, oplane, lane);
+    }
+}
+
+}  // namespace lsdm

@@ -19,6 +19,9 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 __device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
 __device__ __forceinline__ float reluf(float v) { return v > 0.0f ? v : 0.0f; }
 
+// C/D map of the 32x32 MFMA shapes (dtype-independent on gfx950): col = lane & 31, row = acc_row(r, lane)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
 
 template <int ACT>

@@ -1,0 +1,262 @@
+// PointNet++ scene encoder dense stages on the split-bf16 MFMA core (bf16_core.hpp), gfx950.
+//
+// Same stages and HBM tensors as encoder.hip (sa_kernel / fp_kernel restate pointnet2_utils.py:119-135,173-199 and
+// :299-312 + pointnet2.py:76-79); only the arithmetic of the 1x1-conv stacks differs:
+//   NP = 2  bf16x3 products with fp32 accumulation; level features stay fp32 in HBM (same workspace as the f32 path)
+//   NP = 1  plain bf16 products; level features are bf16 in HBM
+// Activations are split into bf16 planes once, when they are written to LDS (gather or layer epilogue), never per
+// MFMA.  The grouped (B,C,32,S) tensor never exists; the K order of the first SA layer is [features || xyz - centroid]
+// (the host permutes the weight columns) so that feature rows are copied as aligned 16-byte pieces.
+#include "bf16_core.hpp"
+#include "kernels.hpp"
+
+namespace lsdm {
+
+template <int NP> struct FeatT { typedef float type; };
+template <> struct FeatT<1> { typedef __bf16 type; };
+
+__device__ __forceinline__ f32x4 load4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4f(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(__bf16* p, float v) { *p = (__bf16)v; }
+
+// ---------------------------------------------------------------------------------------------
+template <int D, int C1, int C2, int C3, int TM, int NW, int NP>
+__global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__ src_xyz, const typename FeatT<NP>::type* __restrict__ src_feat,
+                                                        const float* __restrict__ new_xyz, const int* __restrict__ ball, int NSRC,
+                                                        int S, DenseH l1, DenseH l2, DenseH l3,
+                                                        typename FeatT<NP>::type* __restrict__ out) {
+    constexpr int NT = NW * 64;
+    constexpr int K0P = (D == 3) ? 16 : round16(D + 3);
+    constexpr int LDA = ldh(imax(K0P, C2)), LDB = ldh(C1);
+    constexpr int PA = TM * LDA, PB = TM * LDB;   // plane sizes (elements)
+    __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (PA + PB)];
+    __bf16* bufA = smem;
+    __bf16* bufB = smem + NP * PA;
+    const int c = blockIdx.y, tid = threadIdx.x;
+    const int s0 = blockIdx.x * (TM / 32);
+    const float* xyz = src_xyz + (size_t)c * NSRC * 3;
+    const int* bl = ball + ((size_t)c * S + s0) * kNSample;
+    const float* cen = new_xyz + ((size_t)c * S + s0) * 3;
+    if constexpr (D == 3) {
+        // sa1: the point features are the raw coordinates.  Row = [x y z | dx dy dz | 0 x 10]
+        for (int row = tid; row < TM; row += NT) {
+            const int idx = bl[row];
+            const float x = xyz[idx * 3 + 0], y = xyz[idx * 3 + 1], z = xyz[idx * 3 + 2];
+            const float* cp = cen + (row >> 5) * 3;
+            __bf16* dst = bufA + row * LDA;
+            store_split4<NP>(dst, PA, x, y, z, x - cp[0]);
+            store_split4<NP>(dst + 4, PA, y - cp[1], z - cp[2], 0.0f, 0.0f);
+            store_split4<NP>(dst + 8, PA, 0.0f, 0.0f, 0.0f, 0.0f);
+            store_split4<NP>(dst + 12, PA, 0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    } else {
+        const typename FeatT<NP>::type* feat = src_feat + (size_t)c * NSRC * D;
+        constexpr int CH = K0P / 4;
+#pragma unroll 2
+        for (int e = tid; e < TM * CH; e += NT) {
+            const int row = e / CH, ch = e - row * CH;
+            const int idx = bl[row];
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ch < D / 4) {
+                v = load4f(feat + (size_t)idx * D + 4 * ch);
+            } else if (ch == D / 4) {
+                const float* cp = cen + (row >> 5) * 3;
+                v[0] = xyz[idx * 3 + 0] - cp[0]; v[1] = xyz[idx * 3 + 1] - cp[1]; v[2] = xyz[idx * 3 + 2] - cp[2];
+            }
+            store_split4<NP>(bufA + row * LDA + 4 * ch, PA, v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    layer_lds_h<NW, TM, K0P, C1, ACT_RELU, NP>(bufA, LDA, PA, l1, bufB, LDB, PB);
+    __syncthreads();
+    layer_lds_h<NW, TM, C1, C2, ACT_RELU, NP>(bufB, LDB, PB, l2, bufA, LDA, PA);
+    __syncthreads();
+    // layer 3 in the direct orientation D[point][channel] + max over the 32 neighbours of each centroid
+    using TS = SplitH<NW, TM, C3>;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
+#pragma unroll 1
+    for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
+        f32x16 acc[TS::RB];
+        acc_zero_h(acc);
+        mma_kloop_h<TS::RB, NP, false>(acc, bufA + rg * TS::RB * 32 * LDA, LDA, PA, l3.w, C3, cb, 0, C2 / 16, 0, lane);
+        const int col = cb * 32 + (lane & 31);
+        const float bv = l3.b[col];
+#pragma unroll
+        for (int rb = 0; rb < TS::RB; ++rb) {
+            float m = acc[rb][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rb][r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            // relu(x + b) is monotone in x, so pooling before bias/ReLU is exact
+            if (lane < 32) store1(out + ((size_t)c * S + s0 + rg * TS::RB + rb) * C3 + col, reluf(m + bv));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FP stage: [points1 || sum_j w_j * points2[idx_j]] -> conv+BN+ReLU stack; K streamed through LDS in chunks of KC.
+// HEAD adds conv1+bn1+ReLU (128->128) and conv2 (128->3, fp32 VALU) and writes fp32.
+template <int D1, int D2, int C1, int C2, int C3, bool HEAD, int TM, int KC, int NW, int NP>
+__global__ __launch_bounds__(NW * 64) void fp_h_kernel(const typename FeatT<NP>::type* __restrict__ points1,
+                                                        const typename FeatT<NP>::type* __restrict__ points2,
+                                                        const int* __restrict__ nn_idx, const float* __restrict__ nn_w, int N, int S,
+                                                        DenseH l1, DenseH l2, DenseH l3, DenseH h1, Lin h2, void* __restrict__ out_v) {
+    typedef typename FeatT<NP>::type feat_t;
+    constexpr int NT = NW * 64;
+    constexpr int K0 = D1 + D2;
+    static_assert(K0 % KC == 0 && KC % 16 == 0 && D1 % 4 == 0, "chunking");
+    constexpr int LDX = ldh(KC), LDB = ldh(C1);
+    // two-layer form: the chunk buffer is dead when the layer-1 result is written, so both share one region;
+    // three-layer + head form: ping-pong between two 128-wide buffers
+    constexpr int PX = TM * LDX, PB = TM * LDB;
+    constexpr int SMEM = HEAD ? NP * (PX + PB) : NP * imax(PX, PB);
+    __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM];
+    __bf16* bufX = smem;
+    __bf16* bufB = HEAD ? smem + NP * PX : smem;
+    const int c = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = blockIdx.x * TM;
+    const feat_t* p1 = D1 > 0 ? points1 + ((size_t)c * N + n0) * D1 : nullptr;
+    const feat_t* p2 = points2 + (size_t)c * S * D2;
+    const int* ni = nn_idx + ((size_t)c * N + n0) * 3;
+    const float* nw = nn_w + ((size_t)c * N + n0) * 3;
+
+    using TS = SplitH<NW, TM, C1>;
+    constexpr int NCB = TS::CB / TS::CSTEP;
+    const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
+    f32x16 acc[NCB][TS::RB];
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) acc_zero_h(acc[q]);
+    for (int ch = 0; ch < K0 / KC; ++ch) {
+        if (ch > 0) __syncthreads();
+#pragma unroll 2
+        for (int e = tid; e < TM * (KC / 4); e += NT) {
+            const int row = e / (KC / 4), c4 = e - row * (KC / 4);
+            const int col = ch * KC + 4 * c4;
+            f32x4 v;
+            if (col < D1) {
+                v = load4f(p1 + (size_t)row * D1 + col);
+            } else {
+                const int cc = col - D1;
+                const float w0 = nw[row * 3 + 0], w1 = nw[row * 3 + 1], w2 = nw[row * 3 + 2];
+                const f32x4 f0 = load4f(p2 + (size_t)ni[row * 3 + 0] * D2 + cc);
+                const f32x4 f1 = load4f(p2 + (size_t)ni[row * 3 + 1] * D2 + cc);
+                const f32x4 f2 = load4f(p2 + (size_t)ni[row * 3 + 2] * D2 + cc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(f0[j], w0), __fmul_rn(f1[j], w1)), __fmul_rn(f2[j], w2));
+            }
+            store_split4<NP>(bufX + row * LDX + 4 * c4, PX, v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NCB; ++q)
+            mma_kloop_h<TS::RB, NP, true>(acc[q], bufX + rg * TS::RB * 32 * LDX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, ch * (KC / 16),
+                                          (ch + 1) * (KC / 16), ch * (KC / 16), lane);
+    }
+    if constexpr (!HEAD) __syncthreads();   // bufB aliases the chunk buffer
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, TS::RB, NP>(acc[q], rg * TS::RB, cb0 + q * TS::CSTEP, l1.b, bufB, LDB, PB, lane);
+    __syncthreads();
+
+    if constexpr (!HEAD) {
+        // last layer, direct orientation: 32 consecutive channels per half-wave -> global
+        feat_t* out = static_cast<feat_t*>(out_v);
+        using T2 = SplitH<NW, TM, C2>;
+        const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
+#pragma unroll 1
+        for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
+            f32x16 a2[T2::RB];
+            acc_zero_h(a2);
+            mma_kloop_h<T2::RB, NP, false>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, C1 / 16, 0, lane);
+            const int col = cb * 32 + (lane & 31);
+            const float bv = l2.b[col];
+#pragma unroll
+            for (int rb = 0; rb < T2::RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lane);
+                    store1(out + ((size_t)c * N + n0 + row) * C2 + col, reluf(a2[rb][r] + bv));
+                }
+        }
+    } else {
+        static_assert(!HEAD || (C1 == 128 && C2 == 128 && C3 == 128 && KC == 128), "head expects the fp1 widths");
+        float* out = static_cast<float*>(out_v);
+        layer_lds_h<NW, TM, C1, C2, ACT_RELU, NP>(bufB, LDB, PB, l2, bufX, LDX, PX);
+        __syncthreads();
+        layer_lds_h<NW, TM, C2, C3, ACT_RELU, NP>(bufX, LDX, PX, l3, bufB, LDB, PB);   // fp1 output
+        __syncthreads();
+        layer_lds_h<NW, TM, 128, 128, ACT_RELU, NP>(bufB, LDB, PB, h1, bufX, LDX, PX);  // conv1 + bn1 + ReLU (dropout = identity in eval)
+        __syncthreads();
+        // conv2: 128 -> 3, plain fp32 weights (3,128), VALU
+        for (int e = tid; e < TM * 3; e += NT) {
+            const int row = e / 3, ch3 = e - row * 3;
+            const __bf16* a = bufX + row * LDX;
+            const float* w = h2.w + ch3 * 128;
+            float s = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < 128; ++k) s = fmaf(lds_val<NP>(a + k, PX), w[k], s);
+            out[((size_t)c * N + n0 + row) * 3 + ch3] = s + h2.b[ch3];
+        }
+    }
+}
+
+// acc_row is defined in mlp_core.hpp for the f32 core; same C/D map here
+// (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+
+// ---------------------------------------------------------------------------------------------
+template <int NP>
+static void launch_sa_h_t(int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
+                          const DenseH* l, void* out, hipStream_t st) {
+    typedef typename FeatT<NP>::type F;
+    const F* sf = static_cast<const F*>(src_feat);
+    F* o = static_cast<F*>(out);
+    switch (level) {
+        case 0: hipLaunchKernelGGL((sa_h_kernel<3, 32, 32, 64, 128, 4, NP>), dim3(1024 / 4, nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
+                                   ball, 1024, 1024, l[0], l[1], l[2], o); break;
+        case 1: hipLaunchKernelGGL((sa_h_kernel<64, 64, 64, 128, 128, 4, NP>), dim3(256 / 4, nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
+                                   ball, 1024, 256, l[0], l[1], l[2], o); break;
+        case 2: hipLaunchKernelGGL((sa_h_kernel<128, 128, 128, 256, 64, 4, NP>), dim3(64 / 2, nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
+                                   ball, 256, 64, l[0], l[1], l[2], o); break;
+        case 3: hipLaunchKernelGGL((sa_h_kernel<256, 256, 256, 512, 64, 8, NP>), dim3(16 / 2, nc), dim3(512), 0, st, src_xyz, sf, new_xyz,
+                                   ball, 64, 16, l[0], l[1], l[2], o); break;
+    }
+}
+
+template <int NP>
+static void launch_fp_h_t(int which, int nc, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
+                          const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st) {
+    typedef typename FeatT<NP>::type F;
+    const F* p1 = static_cast<const F*>(points1);
+    const F* p2 = static_cast<const F*>(points2);
+    const DenseH none{nullptr, nullptr};
+    const Lin nol{nullptr, nullptr};
+    switch (which) {
+        case 4: hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, NP>), dim3(64 / 64, nc), dim3(256), 0, st, p1, p2,
+                                   nn_idx, nn_w, 64, 16, l[0], l[1], none, none, nol, out); break;
+        case 3: hipLaunchKernelGGL((fp_h_kernel<128, 256, 256, 256, 0, false, 64, 128, 4, NP>), dim3(256 / 64, nc), dim3(256), 0, st, p1, p2,
+                                   nn_idx, nn_w, 256, 64, l[0], l[1], none, none, nol, out); break;
+        case 2: hipLaunchKernelGGL((fp_h_kernel<64, 256, 256, 128, 0, false, 64, 64, 4, NP>), dim3(1024 / 64, nc), dim3(256), 0, st, p1, p2,
+                                   nn_idx, nn_w, 1024, 256, l[0], l[1], none, none, nol, out); break;
+        case 1: hipLaunchKernelGGL((fp_h_kernel<0, 128, 128, 128, 128, true, 64, 128, 4, NP>), dim3(1024 / 64, nc), dim3(256), 0, st, p1, p2,
+                                   nn_idx, nn_w, 1024, 1024, l[0], l[1], l[2], head1[0], head2, out); break;
+    }
+}
+
+void launch_sa_h(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
+                 const DenseH* l, void* out, hipStream_t st) {
+    if (np == 2) launch_sa_h_t<2>(level, nc, src_xyz, src_feat, new_xyz, ball, l, out, st);
+    else launch_sa_h_t<1>(level, nc, src_xyz, src_feat, new_xyz, ball, l, out, st);
+}
+
+void launch_fp_h(int np, int which, int nc, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
+                 const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st) {
+    if (np == 2) launch_fp_h_t<2>(which, nc, points1, points2, nn_idx, nn_w, l, head1, head2, out, st);
+    else launch_fp_h_t<1>(which, nc, points1, points2, nn_idx, nn_w, l, head1, head2, out, st);
+}
+
+}  // namespace lsdm

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bf16_core.hpp"
+
 namespace lsdm {
 
 struct Dense {  // folded (conv|linear)[+BN] layer for the MFMA core: packed weights Wp[kb][n][8], bias[n]
@@ -70,6 +72,11 @@ void launch_sa(int level, int num_clouds, const float* src_xyz, const float* src
                const Dense* l, float* out, hipStream_t st);
 void launch_fp(int which, int num_clouds, const float* points1, const float* points2, const int* nn_idx, const float* nn_w,
                const Dense* l, const Dense* head, float* out, hipStream_t st);
+// encoder_bf.hip (np = 2: bf16x3 with fp32 features, np = 1: bf16 with bf16 features)
+void launch_sa_h(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
+                 const DenseH* l, void* out, hipStream_t st);
+void launch_fp_h(int np, int which, int num_clouds, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
+                 const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st);
 // cond.hip
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st);

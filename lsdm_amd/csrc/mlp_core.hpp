@@ -19,8 +19,6 @@ namespace lsdm {
 // leading dimension for an LDS activation buffer of logical width k (multiple of 4): (ld/4) odd
 __host__ __device__ constexpr int lds_ld(int k) { return ((k / 4) % 2 == 1) ? k : k + 4; }
 
-__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
 // acc[rb] += A[rb*32 .. +32, kb0*8 .. kb1*8) * Wp(cols cb*32 .. +32)
 //   A  : LDS pointer to (row 0 of the first row block, k = 0)
 //   Wp : global pointer to packed weights of this layer; N = number of output columns of the layer

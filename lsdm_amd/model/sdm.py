@@ -12,10 +12,16 @@ Extensions (keyword-only, defaults preserve reference behaviour):
   * ``y`` may be a ``(B, 512)`` tensor of precomputed CLIP text features -- the boundary of this
     path (the reference re-runs ``clip_model.encode_text`` every step, model/sdm.py:147); a list of
     strings is encoded through ``self.text_encoder`` (the ``clip`` package when importable).
+  * ``precision=`` ("f32" | "bf16x3" | "bf16", also ``model.set_precision``; default from ``LSDM_PRECISION`` or
+    "f32") selects the arithmetic of the dense 1x1-conv / Linear stacks: exact fp32 MFMA, fp32 operands split into
+    bf16 hi+lo with 3 bf16 MFMAs per product (fp32-class results, same <= 1e-3 parity bar), or plain bf16 products.
+    Geometry, normalisations, softmaxes and the sampler arithmetic are fp32 in every mode.
   * ``forward(..., fps_starts=...)`` injects the four FPS start draws; by default they are drawn
     from the global CPU generator exactly where the reference draws them
     (model/pcd_backbone/pointnet2_utils.py:72 -- ``torch.randint`` without a device argument).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -48,6 +54,9 @@ class SceneDiffusionModel(nn.Module):
                  use_cuda=True, pcd_points=1024, pcd_dim=128, xyz_dim=3, max_cats=13, translation_params=12,
                  pcd_backbone_type="PNT2", human_backbone_type="POSA", text_encoder_type="CLIP", **kwargs):
         super().__init__()
+        self.precision = kwargs.pop("precision", None) or os.environ.get("LSDM_PRECISION", "f32")
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         if pcd_backbone_type != "PNT2" or human_backbone_type != "POSA":
             raise NotImplementedError("only the default PNT2 / POSA backbones are on the accelerated path "
                                       "(DGCNN / P2R are ablation options of the reference, SURVEY.md §2)")
@@ -95,6 +104,16 @@ class SceneDiffusionModel(nn.Module):
         self._dirty = True
         return out
 
+    def set_precision(self, precision):
+        """Arithmetic of the dense stacks: "f32", "bf16x3" or "bf16" (see the module docstring)."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
+        if precision != self.precision:
+            self.precision = precision
+            self._dirty = True
+            self._cap = 0
+        return self
+
     def refresh(self):
         """Re-uploads the parameters after they were modified in place."""
         self._dirty = True
@@ -106,6 +125,9 @@ class SceneDiffusionModel(nn.Module):
                                      "liblsdm_hip.so (no CPU fallback)")
             self._ctx = _lib.Context(self._device_index)
         if self._dirty:
+            if self._ctx.lib.lsdm_get_precision(self._ctx.handle) != _lib.PRECISIONS[self.precision]:
+                self._ctx.call("lsdm_set_precision", _lib.PRECISIONS[self.precision])   # drops the workspace
+                self._cap = 0
             for name, tensor in self.state_dict().items():
                 if name.endswith("num_batches_tracked") or name.startswith("embed_timestep.sequence_pos_encoder"):
                     continue

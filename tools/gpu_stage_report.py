@@ -38,8 +38,12 @@ def rep(name, got, ref):
 def main():
     B = int(os.environ.get("B", 3))
     sd = make_synthetic_state_dict(seed=0)
-    m, diff = create_model_and_diffusion("proxd")
+    m, diff = create_model_and_diffusion("proxd")   # precision from LSDM_PRECISION (f32 | bf16x3 | bf16)
     m.load_state_dict(sd)
+    print("precision:", m.precision)
+    bf = m.precision == "bf16"
+    fdt = torch.bfloat16 if bf else torch.float32
+    fname = (lambda n: n + "_bf") if bf else (lambda n: n)
     bt = make_synthetic_batch(B, seed=5)
     torch.manual_seed(11)
     x0 = torch.randn(B, 1024, 3)
@@ -62,13 +66,13 @@ def main():
         rep(n + ".fps_idx", ws(m, "fps_idx%d" % (l + 1), (nc, S[l]), torch.int32), taps[n + ".fps_idx"])
         rep(n + ".new_xyz", ws(m, "xyz%d" % (l + 1), (nc, S[l], 3)), taps[n + ".new_xyz"])
         rep(n + ".ball_idx", ws(m, "ball%d" % (l + 1), (nc, S[l], 32), torch.int32), taps[n + ".ball_idx"])
-        rep(n + ".new_points", ws(m, "feat%d" % (l + 1), (nc, S[l], Cc[l])), taps[n + ".new_points"])
+        rep(n + ".new_points", ws(m, ("feat_bf%d" if bf else "feat%d") % (l + 1), (nc, S[l], Cc[l]), fdt).float(), taps[n + ".new_points"])
     for i, (n, N) in enumerate((("fp4", 64), ("fp3", 256), ("fp2", 1024), ("fp1", 1024))):
         rep(n + ".nn_idx", ws(m, "nn_idx%d" % (i + 1), (nc, N, 3), torch.int32), taps[n + ".nn_idx"])
         rep(n + ".nn_w", ws(m, "nn_w%d" % (i + 1), (nc, N, 3)), taps[n + ".nn_w"])
-    rep("fp4.out", ws(m, "fp4", (nc, 64, 256)), taps["fp4.out"])
-    rep("fp3.out", ws(m, "fp3", (nc, 256, 256)), taps["fp3.out"])
-    rep("fp2.out", ws(m, "fp2", (nc, 1024, 128)), taps["fp2.out"])
+    rep("fp4.out", ws(m, fname("fp4"), (nc, 64, 256), fdt).float(), taps["fp4.out"])
+    rep("fp3.out", ws(m, fname("fp3"), (nc, 256, 256), fdt).float(), taps["fp3.out"])
+    rep("fp2.out", ws(m, fname("fp2"), (nc, 1024, 128), fdt).float(), taps["fp2.out"])
     rep("pcd", ws(m, "pcd", (B, 9, 3072)), taps["pcd"])
     rep("e0", ws(m, "e0", (B, 256)), torch.cat([taps["ets"], taps["enc"]], 1))
     rep("w", ws(m, "w", (B, 9)), taps["w"])
