@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense stacks (geometry and sampler arithmetic are always fp32)")
+    ap.add_argument("--no-pipeline", action="store_true", help="run front and back of every step on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -93,6 +94,7 @@ def main():
     model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
     ctx = model._context()
     model._reserve(B)
+    ctx.call("lsdm_set_pipeline", 0 if a.no_pipeline else 1)
     model._set_schedule((id(diffusion), diffusion.num_timesteps), diffusion._device_tables())
     bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=a.seed + rank, max_cats=C, num_objects=8).items()}
     # RNG stream of the reference: x_T, then per step 4 FPS randints + randn, host generator

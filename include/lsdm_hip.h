@@ -102,6 +102,10 @@ int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, in
                       const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,
                       float* out_guiding, void* stream);
 
+/* lsdm_sample_steps overlaps the x-independent front of step k+1 (conditioning vectors, FPS / ball query / 3-NN) with
+ * the dense stages of step k on an internal second stream (default on).  Results are identical either way. */
+int lsdm_set_pipeline(lsdm_ctx* ctx, int enable);
+
 /* ---- stage entry points (parity tests against the oracle's taps; same kernels the hot path launches) -------- */
 /* farthest_point_sample x4 chained (pointnet2_utils.py:60-81): idx_l (num_clouds,S_l) int32, xyz_l (num_clouds,S_l,3),
  * S = 1024,256,64,16 */

@@ -48,6 +48,7 @@ struct lsdm_ctx {
     PosaParams posa{};
     SceneAttnParams sattn{};
     DenoiseParams den{};
+    DenoiseHParams den_h{};
     Lin up0{};
     Dense up2{};
     StepCoefs sched{};
@@ -56,20 +57,30 @@ struct lsdm_ctx {
     int cap_B = 0;
     std::vector<void*> ws_allocs;
     std::map<std::string, std::pair<void*, int64_t>> ws_named;
-    int* idx[4] = {};
-    float* xyz[4] = {};
-    int* ball[4] = {};
+    // Everything a step computes WITHOUT x (conditioning vectors + PointNet++ geometry) lives in a FrontSet; there are
+    // two so that the front of step k+1 can run on the auxiliary stream while the dense stages of step k read set k&1.
+    struct FrontSet {
+        int* idx[4] = {};
+        float* xyz[4] = {};
+        int* ball[4] = {};
+        int* nn_idx[4] = {};
+        float* nn_w[4] = {};
+        float *e0 = nullptr, *tr = nullptr, *w = nullptr, *h2p = nullptr;
+        int64_t* tbuf = nullptr;
+    } fs[2];
     float* feat[4] = {};
-    int* nn_idx[4] = {};
-    float* nn_w[4] = {};
     float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
-    float *hm = nullptr, *e0 = nullptr, *tr = nullptr, *w = nullptr, *o12 = nullptr, *h2p = nullptr, *xs = nullptr;
-    int64_t* tbuf = nullptr;
+    float *hm = nullptr, *o12 = nullptr, *xs = nullptr;
+    bool pipeline = true;             // lsdm_sample_steps: overlap front(k+1) with back(k) on two streams
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_front[2] = {}, ev_back[2] = {};
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
-    std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-step marker)
+    std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-phase marker)
+    std::vector<int> prof_st;   // stream the event was recorded on (0 = caller's, 1 = auxiliary)
     size_t prof_cur = 0;
+    int prof_stream = 0;
 };
 
 namespace {
@@ -111,8 +122,10 @@ void prof_mark(lsdm_ctx* c, int id, hipStream_t st) {
         if (hipEventCreate(&e) != hipSuccess) { c->prof_on = false; return; }
         c->prof_ev.push_back(e);
         c->prof_id.push_back(id);
+        c->prof_st.push_back(0);
     }
     c->prof_id[c->prof_cur] = id;
+    c->prof_st[c->prof_cur] = c->prof_stream;
     (void)hipEventRecord(c->prof_ev[c->prof_cur++], st);
 }
 
@@ -264,44 +277,50 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
 }
 
 // geometry + dense stages of get_backbone.forward on `num_clouds` clouds
-int run_scene_encoder_h(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st);
+typedef lsdm_ctx::FrontSet FrontSet;
 
-int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
-    if (c->prec != LSDM_PREC_F32) return run_scene_encoder_h(c, clouds, starts, nc, out, st);
+// PointNet++ geometry of `nc` clouds into a front set: FPS chain, 4 ball queries, 4 three-NN searches (x-independent)
+void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, hipStream_t st) {
     prof_mark(c, K_FPS, st);
-    launch_fps_chain(clouds, starts, nc, c->idx, c->xyz, st);
-    const float* lvl_xyz[5] = {clouds, c->xyz[0], c->xyz[1], c->xyz[2], c->xyz[3]};
-    const float* lvl_feat[5] = {clouds, c->feat[0], c->feat[1], c->feat[2], c->feat[3]};
+    launch_fps_chain(clouds, starts, nc, f.idx, f.xyz, st);
+    const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
     for (int l = 0; l < 4; ++l) {
         // radius ** 2 is a double in the reference and is compared against fp32 distances (Q13)
         const float r2 = (float)(kRadius[l] * kRadius[l]);
         prof_mark(c, K_BALL1 + l, st);
-        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], nc, kSrcN[l], kS[l], r2, c->ball[l], st);
-        prof_mark(c, K_SA1 + l, st);
-        launch_sa(l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], c->ball[l], c->sa[l], c->feat[l], st);
+        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], nc, kSrcN[l], kS[l], r2, f.ball[l], st);
     }
     // fp4: l3 <- l4 ; fp3: l2 <- l3 ; fp2: l1 <- l2 ; fp1: l0 <- l1
     prof_mark(c, K_NN4, st);
-    launch_three_nn(c->xyz[2], c->xyz[3], nc, 64, 16, c->nn_idx[0], c->nn_w[0], st);
-    prof_mark(c, K_FP4, st);
-    launch_fp(4, nc, c->feat[2], c->feat[3], c->nn_idx[0], c->nn_w[0], c->fp[0], nullptr, c->fpo4, st);
+    launch_three_nn(f.xyz[2], f.xyz[3], nc, 64, 16, f.nn_idx[0], f.nn_w[0], st);
     prof_mark(c, K_NN3, st);
-    launch_three_nn(c->xyz[1], c->xyz[2], nc, 256, 64, c->nn_idx[1], c->nn_w[1], st);
-    prof_mark(c, K_FP3, st);
-    launch_fp(3, nc, c->feat[1], c->fpo4, c->nn_idx[1], c->nn_w[1], c->fp[1], nullptr, c->fpo3, st);
+    launch_three_nn(f.xyz[1], f.xyz[2], nc, 256, 64, f.nn_idx[1], f.nn_w[1], st);
     prof_mark(c, K_NN2, st);
-    launch_three_nn(c->xyz[0], c->xyz[1], nc, 1024, 256, c->nn_idx[2], c->nn_w[2], st);
-    prof_mark(c, K_FP2, st);
-    launch_fp(2, nc, c->feat[0], c->fpo3, c->nn_idx[2], c->nn_w[2], c->fp[2], nullptr, c->fpo2, st);
+    launch_three_nn(f.xyz[0], f.xyz[1], nc, 1024, 256, f.nn_idx[2], f.nn_w[2], st);
     prof_mark(c, K_NN1, st);
-    launch_three_nn(clouds, c->xyz[0], nc, 1024, 1024, c->nn_idx[3], c->nn_w[3], st);
-    prof_mark(c, K_FP1, st);
-    launch_fp(1, nc, nullptr, c->fpo2, c->nn_idx[3], c->nn_w[3], c->fp[3], c->head, out, st);
-    return check_launch(c, "scene encoder");
+    launch_three_nn(clouds, f.xyz[0], nc, 1024, 1024, f.nn_idx[3], f.nn_w[3], st);
 }
 
-// same stage sequence on the split-bf16 core; bf16x3 keeps the fp32 feature tensors, bf16 uses the bf16 ones
-int run_scene_encoder_h(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
+// dense stages of get_backbone.forward (4 x SA, 4 x FP + head) on the geometry of a front set
+void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int nc, float* out, hipStream_t st) {
+    const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
+    if (c->prec == LSDM_PREC_F32) {
+        const float* lvl_feat[5] = {clouds, c->feat[0], c->feat[1], c->feat[2], c->feat[3]};
+        for (int l = 0; l < 4; ++l) {
+            prof_mark(c, K_SA1 + l, st);
+            launch_sa(l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa[l], c->feat[l], st);
+        }
+        prof_mark(c, K_FP4, st);
+        launch_fp(4, nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp[0], nullptr, c->fpo4, st);
+        prof_mark(c, K_FP3, st);
+        launch_fp(3, nc, c->feat[1], c->fpo4, f.nn_idx[1], f.nn_w[1], c->fp[1], nullptr, c->fpo3, st);
+        prof_mark(c, K_FP2, st);
+        launch_fp(2, nc, c->feat[0], c->fpo3, f.nn_idx[2], f.nn_w[2], c->fp[2], nullptr, c->fpo2, st);
+        prof_mark(c, K_FP1, st);
+        launch_fp(1, nc, nullptr, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp[3], c->head, out, st);
+        return;
+    }
+    // split-bf16 core: bf16x3 keeps the fp32 feature tensors, bf16 uses the bf16 ones
     const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
     void* feat[4];
     void* fpo[3];
@@ -309,54 +328,65 @@ int run_scene_encoder_h(lsdm_ctx* c, const float* clouds, const int64_t* starts,
     fpo[0] = np == 2 ? (void*)c->fpo4 : c->fpo_b[0];
     fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
     fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
-    prof_mark(c, K_FPS, st);
-    launch_fps_chain(clouds, starts, nc, c->idx, c->xyz, st);
-    const float* lvl_xyz[5] = {clouds, c->xyz[0], c->xyz[1], c->xyz[2], c->xyz[3]};
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     for (int l = 0; l < 4; ++l) {
-        const float r2 = (float)(kRadius[l] * kRadius[l]);
-        prof_mark(c, K_BALL1 + l, st);
-        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], nc, kSrcN[l], kS[l], r2, c->ball[l], st);
         prof_mark(c, K_SA1 + l, st);
-        launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], c->ball[l], c->sa_h[l], feat[l], st);
+        launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
     }
     const Lin head2{c->head[1].w, c->head[1].b};
-    prof_mark(c, K_NN4, st);
-    launch_three_nn(c->xyz[2], c->xyz[3], nc, 64, 16, c->nn_idx[0], c->nn_w[0], st);
     prof_mark(c, K_FP4, st);
-    launch_fp_h(np, 4, nc, feat[2], feat[3], c->nn_idx[0], c->nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
-    prof_mark(c, K_NN3, st);
-    launch_three_nn(c->xyz[1], c->xyz[2], nc, 256, 64, c->nn_idx[1], c->nn_w[1], st);
+    launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
     prof_mark(c, K_FP3, st);
-    launch_fp_h(np, 3, nc, feat[1], fpo[0], c->nn_idx[1], c->nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
-    prof_mark(c, K_NN2, st);
-    launch_three_nn(c->xyz[0], c->xyz[1], nc, 1024, 256, c->nn_idx[2], c->nn_w[2], st);
+    launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
     prof_mark(c, K_FP2, st);
-    launch_fp_h(np, 2, nc, feat[0], fpo[1], c->nn_idx[2], c->nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
-    prof_mark(c, K_NN1, st);
-    launch_three_nn(clouds, c->xyz[0], nc, 1024, 1024, c->nn_idx[3], c->nn_w[3], st);
+    launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_mark(c, K_FP1, st);
-    launch_fp_h(np, 1, nc, nullptr, fpo[2], c->nn_idx[3], c->nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
-    return check_launch(c, "scene encoder (bf16 core)");
+    launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
+}
+
+int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
+    run_geometry(c, c->fs[0], clouds, starts, nc, st);
+    run_encoder_dense(c, c->fs[0], clouds, nc, out, st);
+    return check_launch(c, "scene encoder");
+}
+
+// FRONT of a step: everything that does not read x -- conditioning vectors, up-sampling layers 1-2, the human branch
+// (given_objs only: evaluated once per multi-step call) and the PointNet++ geometry.
+void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_objs, const float* given_cats,
+               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st) {
+    prof_mark(c, K_COND, st);
+    launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
+    prof_mark(c, K_UP12, st);
+    launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B, f.h2p, st);
+    if (!reuse_hm) {
+        prof_mark(c, K_POSA, st);
+        launch_posa(c->posa, given_objs, B, c->hm, st);
+    }
+    run_geometry(c, f, given_objs, starts, B * kO, st);
+    prof_mark(c, -1, st);
+}
+
+// BACK of a step: dense encoder stages, collapsed scene attention, the fused per-point denoiser + sampler update
+void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
+              const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
+    run_encoder_dense(c, f, given_objs, B * kO, c->pcd, st);
+    prof_mark(c, K_SATTN, st);
+    launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
+    prof_mark(c, K_DENOISE, st);
+    if (c->prec == LSDM_PREC_F32)
+        launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm, f.h2p, noise, out_x0, out_guiding,
+                       out_sample, st);
+    else
+        launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm,
+                         f.h2p, noise, out_x0, out_guiding, out_sample, st);
+    prof_mark(c, -1, st);
 }
 
 int run_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
              const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat, float* out_x0,
-             float* out_guiding, float* out_sample, hipStream_t st) {
-    prof_mark(c, K_COND, st);
-    launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, c->e0, c->tr, c->w, st);
-    prof_mark(c, K_UP12, st);
-    launch_upsample12(c->e0, c->up0, c->up2.w, c->up2.b, B, c->h2p, st);
-    prof_mark(c, K_POSA, st);
-    launch_posa(c->posa, given_objs, B, c->hm, st);
-    int rc = run_scene_encoder(c, given_objs, starts, B * kO, c->pcd, st);
-    if (rc) return rc;
-    prof_mark(c, K_SATTN, st);
-    launch_scene_attn(c->sattn, c->pcd, c->w, c->tr, B, c->o12, st);
-    prof_mark(c, K_DENOISE, st);
-    launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, c->w, c->o12, c->hm, c->h2p, noise, out_x0, out_guiding,
-                   out_sample, st);
-    prof_mark(c, -1, st);
+             float* out_guiding, float* out_sample, hipStream_t st, bool reuse_hm = false) {
+    run_front(c, c->fs[0], B, t, mask, given_objs, given_cats, text, starts, out_cat, reuse_hm, st);
+    run_back(c, c->fs[0], mode, eta, B, x, t, mask, given_objs, noise, out_x0, out_guiding, out_sample, st);
     return check_launch(c, "step");
 }
 
@@ -391,6 +421,11 @@ int lsdm_destroy(lsdm_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->ws_allocs) (void)hipFree(p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    if (c->aux) {
+        (void)hipStreamDestroy(c->aux);
+        (void)hipEventDestroy(c->ev_fork);
+        for (int s = 0; s < 2; ++s) { (void)hipEventDestroy(c->ev_front[s]); (void)hipEventDestroy(c->ev_back[s]); }
+    }
     delete c;
     return LSDM_OK;
 }
@@ -558,6 +593,30 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
          load_dense(c, "input_process.combination_extraction.2.weight", "input_process.combination_extraction.2.bias", "", 128, 192, &c->den.cex2) &&
          load_dense(c, "output_process.pose_final.0.weight", "output_process.pose_final.0.bias", "", 64, 128, &c->den.fin0) &&
          load_lin(c, "output_process.pose_final.2", 3, 64, &c->den.fin2) && load_lin(c, "point_wise_trans_layer.0", 3, 15, &c->den.pwt);
+    if (ok && c->prec != LSDM_PREC_F32) {
+        const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
+        const HostTensor* w4 = find(c, "upsampling_layer.4.weight", {1024, 512});
+        ok = w4 != nullptr;
+        if (ok) {
+            std::vector<uint16_t> hi(w4->data.size()), lo(w4->data.size());
+            for (size_t i = 0; i < hi.size(); ++i) {
+                hi[i] = f2bf(w4->data[i]);
+                lo[i] = f2bf(w4->data[i] - bf2f(hi[i]));
+            }
+            c->den_h.up4_h = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(hi.data()), hi.size() / 2));
+            c->den_h.up4_l = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(lo.data()), lo.size() / 2));
+            c->den_h.up4_b = c->den.up4_b;
+            c->den_h.pose0 = c->den.pose0;
+            c->den_h.fin2 = c->den.fin2;
+            c->den_h.pwt = c->den.pwt;
+            ok = c->den_h.up4_h && c->den_h.up4_l;
+        }
+        ok = ok && load_dense_h(c, "combine_extraction.0.weight", "combine_extraction.0.bias", "", 128, 256, np, {}, &c->den_h.comb) &&
+             load_dense_h(c, "input_process.pose_embedding.2.weight", "input_process.pose_embedding.2.bias", "", 128, 64, np, {}, &c->den_h.pose2) &&
+             load_dense_h(c, "input_process.combination_extraction.0.weight", "input_process.combination_extraction.0.bias", "", 192, 256, np, {}, &c->den_h.cex0) &&
+             load_dense_h(c, "input_process.combination_extraction.2.weight", "input_process.combination_extraction.2.bias", "", 128, 192, np, {}, &c->den_h.cex2) &&
+             load_dense_h(c, "output_process.pose_final.0.weight", "output_process.pose_final.0.bias", "", 64, 128, np, {}, &c->den_h.fin0);
+    }
     if (!ok) return c->err.empty() ? fail(c, LSDM_ERR_PARAM, "parameter upload failed") : LSDM_ERR_PARAM;
     c->finalized = true;
     return LSDM_OK;
@@ -592,23 +651,28 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
     const size_t nc = (size_t)B * kO;
     bool ok = true;
     const char* lv[4] = {"1", "2", "3", "4"};
-    for (int l = 0; l < 4 && ok; ++l) {
-        ok = (c->idx[l] = ws_alloc<int>(c, (std::string("fps_idx") + lv[l]).c_str(), nc * kS[l])) &&
-             (c->xyz[l] = ws_alloc<float>(c, (std::string("xyz") + lv[l]).c_str(), nc * kS[l] * 3)) &&
-             (c->ball[l] = ws_alloc<int>(c, (std::string("ball") + lv[l]).c_str(), nc * kS[l] * 32)) &&
-             (c->feat[l] = ws_alloc<float>(c, (std::string("feat") + lv[l]).c_str(), nc * kS[l] * kFeatC[l]));
-    }
+    for (int l = 0; l < 4 && ok; ++l)
+        ok = (c->feat[l] = ws_alloc<float>(c, (std::string("feat") + lv[l]).c_str(), nc * kS[l] * kFeatC[l])) != nullptr;
     const int nn_n[4] = {64, 256, 1024, 1024};
-    for (int l = 0; l < 4 && ok; ++l) {
-        ok = (c->nn_idx[l] = ws_alloc<int>(c, (std::string("nn_idx") + lv[l]).c_str(), nc * nn_n[l] * 3)) &&
-             (c->nn_w[l] = ws_alloc<float>(c, (std::string("nn_w") + lv[l]).c_str(), nc * nn_n[l] * 3));
+    for (int s = 0; s < 2 && ok; ++s) {
+        // set 0 keeps the plain names (parity tests read them after single-step calls); set 1 is suffixed
+        lsdm_ctx::FrontSet& f = c->fs[s];
+        const std::string sx = s == 0 ? "" : "_b";
+        for (int l = 0; l < 4 && ok; ++l) {
+            ok = (f.idx[l] = ws_alloc<int>(c, (std::string("fps_idx") + lv[l] + sx).c_str(), nc * kS[l])) &&
+                 (f.xyz[l] = ws_alloc<float>(c, (std::string("xyz") + lv[l] + sx).c_str(), nc * kS[l] * 3)) &&
+                 (f.ball[l] = ws_alloc<int>(c, (std::string("ball") + lv[l] + sx).c_str(), nc * kS[l] * 32)) &&
+                 (f.nn_idx[l] = ws_alloc<int>(c, (std::string("nn_idx") + lv[l] + sx).c_str(), nc * nn_n[l] * 3)) &&
+                 (f.nn_w[l] = ws_alloc<float>(c, (std::string("nn_w") + lv[l] + sx).c_str(), nc * nn_n[l] * 3));
+        }
+        ok = ok && (f.e0 = ws_alloc<float>(c, ("e0" + sx).c_str(), (size_t)B * 256)) && (f.tr = ws_alloc<float>(c, ("tr" + sx).c_str(), nc * 12)) &&
+             (f.w = ws_alloc<float>(c, ("w" + sx).c_str(), nc)) && (f.h2p = ws_alloc<float>(c, ("h2p" + sx).c_str(), (size_t)B * 256 * 512)) &&
+             (f.tbuf = ws_alloc<int64_t>(c, ("tbuf" + sx).c_str(), (size_t)B));
     }
     ok = ok && (c->fpo4 = ws_alloc<float>(c, "fp4", nc * 64 * 256)) && (c->fpo3 = ws_alloc<float>(c, "fp3", nc * 256 * 256)) &&
          (c->fpo2 = ws_alloc<float>(c, "fp2", nc * 1024 * 128)) && (c->pcd = ws_alloc<float>(c, "pcd", nc * kN * 3)) &&
-         (c->hm = ws_alloc<float>(c, "hm", (size_t)B * kN * 3)) && (c->e0 = ws_alloc<float>(c, "e0", (size_t)B * 256)) &&
-         (c->tr = ws_alloc<float>(c, "tr", nc * 12)) && (c->w = ws_alloc<float>(c, "w", nc)) &&
-         (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) && (c->h2p = ws_alloc<float>(c, "h2p", (size_t)B * 256 * 512)) &&
-         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->tbuf = ws_alloc<int64_t>(c, "tbuf", (size_t)B));
+         (c->hm = ws_alloc<float>(c, "hm", (size_t)B * kN * 3)) && (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) &&
+         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3));
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)
@@ -649,14 +713,55 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     float* cur = x;
     float* nxt = c->xs;
     const size_t xn = (size_t)B * kN * 3;
+    const bool piped = c->pipeline && K > 1;
+    if (piped && !c->aux) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int s = 0; s < 2; ++s) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_front[s], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_back[s], hipEventDisableTiming));
+        }
+    }
+    // The front of a step (conditioning + geometry) reads neither x nor the previous step's results, so front(k+1) runs
+    // on the auxiliary stream while the dense stages of step k occupy the matrix cores; the only serial chain left is
+    // back(k) -> back(k+1) through x.  Front sets alternate; front(k+2) waits for back(k) to release its set.
+    hipStream_t fst = piped ? c->aux : st;
+    if (piped) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    }
+    c->prof_stream = piped ? 1 : 0;
+    auto front = [&](int k) {
+        lsdm_ctx::FrontSet& f = c->fs[piped ? (k & 1) : 0];
+        hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, fst, f.tbuf, (int64_t)(t_first - k), B);
+        run_front(c, f, B, f.tbuf, mask, given_objs, given_cats, text, starts + (size_t)k * 4 * B * kO, out_cat, /*reuse_hm=*/k > 0, fst);
+    };
     for (int k = 0; k < K; ++k) {
-        hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, c->tbuf, (int64_t)(t_first - k), B);
-        rc = run_step(c, mode, eta, B, cur, mask, c->tbuf, given_objs, given_cats, text, starts + (size_t)k * 4 * B * kO,
-                      noise + (size_t)k * xn, out_cat, out_x0, out_guiding, nxt, st);
+        const int s = piped ? (k & 1) : 0;
+        if (piped) {
+            c->prof_stream = 1;
+            if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_back[s], 0));
+            front(k);
+            HIP_TRY(c, hipEventRecord(c->ev_front[s], c->aux));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_front[s], 0));
+            c->prof_stream = 0;
+        } else {
+            front(k);
+        }
+        run_back(c, c->fs[s], mode, eta, B, cur, c->fs[s].tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
+        if (piped) HIP_TRY(c, hipEventRecord(c->ev_back[s], st));
+        rc = check_launch(c, "sample step");
         if (rc) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
+    c->prof_stream = 0;
     if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return LSDM_OK;
+}
+
+int lsdm_set_pipeline(lsdm_ctx* c, int enable) {
+    if (!c) return LSDM_ERR_ARG;
+    c->pipeline = enable != 0;
     return LSDM_OK;
 }
 
@@ -716,11 +821,15 @@ int lsdm_profile_end(lsdm_ctx* c, int capacity, double* total_ms, int64_t* launc
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     for (int k = 0; k < K_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; if (macs_per_unit) macs_per_unit[k] = kKernelMacs[k]; }
+    // an interval runs from an event to the next event recorded on the SAME stream
     for (size_t i = 0; i + 1 < c->prof_cur; ++i) {
         const int id = c->prof_id[i];
         if (id < 0) continue;
+        size_t j = i + 1;
+        while (j < c->prof_cur && c->prof_st[j] != c->prof_st[i]) ++j;
+        if (j >= c->prof_cur) continue;
         float ms = 0.0f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[j]));
         total_ms[id] += ms;
         launches[id] += 1;
     }

@@ -68,47 +68,65 @@ __device__ __forceinline__ float lds_val(const __bf16* p, int plane) {
 //   X     : LDS hi plane, row 0 of the wave's first point block, k = x_kb_off*16 at column 0
 //   WA    : true  -> D[n][point]  (weights are the A operand)
 //           false -> D[point][n]  (activations are the A operand)
-template <int RB, int NP, bool WA>
+template <int RB, int NP, bool WA, int NKB>
 __device__ __forceinline__ void mma_kloop_h(f32x16 (&acc)[RB], const __bf16* X, int ldx, int plane, const __bf16* __restrict__ Wp,
-                                            int N, int cb, int kb0, int kb1, int x_kb_off, int lane) {
+                                            int N, int cb, int kb0, int lane) {
+    // NKB k-blocks starting at weight k-block kb0; X points at the LDS column of the first of them.
+    // Loads are grouped U k-blocks at a time and the next group's weight fragments (L2, ~300+ cycles) are requested
+    // before the current group's MFMAs, so one wave keeps the matrix pipe fed through the short K loops of this path.
+    constexpr int U = NKB <= 5 ? NKB : (NKB % 4 == 0 ? 4 : (NKB % 3 == 0 ? 3 : 4));
+    constexpr int NG = NKB / U, TAIL = NKB % U;
     const int i = lane & 31, h = lane >> 5;
     const __bf16* xp = X + i * ldx + 8 * h;
-    const __bf16* wp = Wp + ((size_t)(cb * 32 + i) * NP) * 16 + 8 * h;
     const size_t ws = (size_t)N * NP * 16;
-    bf16x8 wh_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)kb0 * ws);
-    bf16x8 wl_n = wh_n;
-    if constexpr (NP == 2) wl_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)kb0 * ws + 16);
+    const __bf16* wp = Wp + ((size_t)(cb * 32 + i) * NP) * 16 + 8 * h + (size_t)kb0 * ws;
+    bf16x8 wh[U], wl[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        wh[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws);
+        if constexpr (NP == 2) wl[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws + 16);
+    }
 #pragma unroll 1
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const bf16x8 wh = wh_n, wl = wl_n;
-        if (kb + 1 < kb1) {
-            wh_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)(kb + 1) * ws);
-            if constexpr (NP == 2) wl_n = *reinterpret_cast<const bf16x8*>(wp + (size_t)(kb + 1) * ws + 16);
-        }
-        bf16x8 xh[RB], xl[RB];
+    for (int g = 0; g < NG; ++g) {
+        bf16x8 ch[U], cl[U];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const __bf16* p = xp + rb * 32 * ldx + (kb - x_kb_off) * 16;
-            xh[rb] = *reinterpret_cast<const bf16x8*>(p);
-            if constexpr (NP == 2) xl[rb] = *reinterpret_cast<const bf16x8*>(p + plane);
-        }
+        for (int u = 0; u < U; ++u) { ch[u] = wh[u]; if constexpr (NP == 2) cl[u] = wl[u]; }
+        if (g + 1 < NG) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            if constexpr (WA) {
-                if constexpr (NP == 2) {
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[rb], acc[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[rb], acc[rb], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                wh[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws);
+                if constexpr (NP == 2) wl[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws + 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this group's MFMAs
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8 xh[RB], xl[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const __bf16* p = xp + rb * 32 * ldx + (g * U + u) * 16;
+                xh[rb] = *reinterpret_cast<const bf16x8*>(p);
+                if constexpr (NP == 2) xl[rb] = *reinterpret_cast<const bf16x8*>(p + plane);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                if constexpr (WA) {
+                    if constexpr (NP == 2) {
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[u], xl[rb], acc[rb], 0, 0, 0);
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl[u], xh[rb], acc[rb], 0, 0, 0);
+                    }
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch[u], xh[rb], acc[rb], 0, 0, 0);
+                } else {
+                    if constexpr (NP == 2) {
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], ch[u], acc[rb], 0, 0, 0);
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], cl[u], acc[rb], 0, 0, 0);
+                    }
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], ch[u], acc[rb], 0, 0, 0);
                 }
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[rb], acc[rb], 0, 0, 0);
-            } else {
-                if constexpr (NP == 2) {
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], wh, acc[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], wl, acc[rb], 0, 0, 0);
-                }
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], wh, acc[rb], 0, 0, 0);
             }
         }
     }
+    if constexpr (TAIL > 0) mma_kloop_h<RB, NP, WA, TAIL>(acc, X + NG * U * 16, ldx, plane, Wp, N, cb, kb0 + NG * U, lane);
 }
 
 template <int RB>
@@ -120,47 +138,57 @@ __device__ __forceinline__ void acc_zero_h(f32x16 (&acc)[RB]) {
 }
 
 // Work split of a (TM points) x (N channels) layer over NW waves: channel blocks first, then point groups.
-template <int NW, int TM, int N>
+template <int NW, int TM, int N, int CS = 0>
 struct SplitH {
     static constexpr int RBT = TM / 32, CB = N / 32;
-    static constexpr int CSTEP = (CB >= NW) ? NW : CB;   // channel blocks processed concurrently
+    static constexpr int CSTEP = CS > 0 ? CS : ((CB >= NW) ? NW : CB);   // channel blocks processed concurrently
     static constexpr int WPC = NW / CSTEP;               // waves sharing one channel block (split points)
     static constexpr int RB = RBT / WPC;                 // point blocks per wave
     static_assert(TM % 32 == 0 && N % 32 == 0, "tile dims");
     static_assert(NW % CSTEP == 0 && RBT % WPC == 0 && RB >= 1, "tile split");
 };
 
+// bias quads of a 32-channel block in the lane order of the transposed epilogue (requested before the K loop so that
+// their latency hides behind the MFMAs)
+__device__ __forceinline__ void load_bias_h(f32x4 (&bv)[4], const float* __restrict__ bias, int cb, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bias + cb * 32 + 8 * q + 4 * (lane >> 5));
+}
+
 // epilogue of a transposed (WA) layer: bias + activation + split -> LDS [point][channel]
 template <int ACT, int RB, int NP>
-__device__ __forceinline__ void store_lds_h(const f32x16 (&acc)[RB], int rb0, int cb, const float* __restrict__ bias, __bf16* out,
-                                            int ldo, int plane, int lane) {
+__device__ __forceinline__ void store_lds_h(const f32x16 (&acc)[RB], int rb0, int cb, const f32x4 (&bv)[4], __bf16* out, int ldo,
+                                            int plane, int lane) {
     const int p = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = cb * 32 + 8 * q + 4 * h;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            store_split4<NP>(out + ((rb0 + rb) * 32 + p) * ldo + n, plane, apply_act<ACT>(acc[rb][4 * q + 0] + bv[0]),
-                             apply_act<ACT>(acc[rb][4 * q + 1] + bv[1]), apply_act<ACT>(acc[rb][4 * q + 2] + bv[2]),
-                             apply_act<ACT>(acc[rb][4 * q + 3] + bv[3]));
+            store_split4<NP>(out + ((rb0 + rb) * 32 + p) * ldo + n, plane, apply_act<ACT>(acc[rb][4 * q + 0] + bv[q][0]),
+                             apply_act<ACT>(acc[rb][4 * q + 1] + bv[q][1]), apply_act<ACT>(acc[rb][4 * q + 2] + bv[q][2]),
+                             apply_act<ACT>(acc[rb][4 * q + 3] + bv[q][3]));
         }
     }
 }
 
 // One dense layer, whole K resident in LDS: out(LDS) = act(W x X + bias), transposed orientation
-template <int NW, int TM, int K, int N, int ACT, int NP>
+// (waves >= NW of a larger workgroup take no part)
+template <int NW, int TM, int K, int N, int ACT, int NP, int CS = 0>
 __device__ __forceinline__ void layer_lds_h(const __bf16* X, int ldx, int xplane, DenseH L, __bf16* out, int ldo, int oplane) {
-    using TS = SplitH<NW, TM, N>;
+    using TS = SplitH<NW, TM, N, CS>;
     static_assert(K % 16 == 0, "K must be padded to 16");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= NW) return;
     const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
 #pragma unroll 1
     for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
         f32x16 acc[TS::RB];
         acc_zero_h(acc);
-        mma_kloop_h<TS::RB, NP, true>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb, 0, K / 16, 0, lane);
-        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, L.b, out, ldo, oplane, lane);
+        f32x4 bv[4];
+        load_bias_h(bv, L.b, cb, lane);
+        mma_kloop_h<TS::RB, NP, true, K / 16>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb, 0, lane);
+        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, bv, out, ldo, oplane, lane);
     }
 }
 

@@ -239,8 +239,11 @@ __global__ __launch_bounds__(1024) void posa_kernel(PosaParams P, const float* _
 
 // ---------------------------------------------------------------------------------------------
 // rows r = b*256 + c carry the scalar e0[r]; h1 = GELU(w1*e + b1) (128), h2 = GELU(W2 h1 + b2) (512)
-// output packed for denoise_kernel: h2p[b][kb = k/8][c][k%8]
-__global__ __launch_bounds__(256) void upsample12_kernel(const float* __restrict__ e0, Lin up0, Dense up2, float* __restrict__ h2p) {
+// output packed as the per-sample "weight" operand of the third layer inside the denoise kernel:
+//   NP = 0 : fp32  h2p[b][kb = k/8][c][k%8]                  (denoise_kernel, mlp_core.hpp)
+//   NP = 1,2: bf16 h2p[b][kb = k/16][c][plane][k%16]         (denoise_h_kernel, bf16_core.hpp; plane 1 = lo part)
+template <int NP>
+__global__ __launch_bounds__(256) void upsample12_kernel(const float* __restrict__ e0, Lin up0, Dense up2, void* __restrict__ h2p_v) {
     constexpr int TM = 64, LDA = lds_ld(128);
     __shared__ __attribute__((aligned(16))) float bufA[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -263,7 +266,15 @@ __global__ __launch_bounds__(256) void upsample12_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = c0 + rb * 32 + acc_row(r, lane);
-                h2p[(((size_t)b * 64 + (k >> 3)) * 256 + c) * 8 + (k & 7)] = gelu(acc[rb][r] + bv);
+                const float v = gelu(acc[rb][r] + bv);
+                if constexpr (NP == 0) {
+                    static_cast<float*>(h2p_v)[(((size_t)b * 64 + (k >> 3)) * 256 + c) * 8 + (k & 7)] = v;
+                } else {
+                    __bf16* dst = static_cast<__bf16*>(h2p_v) + ((((size_t)b * 32 + (k >> 4)) * 256 + c) * NP) * 16 + (k & 15);
+                    const __bf16 hi = (__bf16)v;
+                    dst[0] = hi;
+                    if constexpr (NP == 2) dst[16] = (__bf16)(v - (float)hi);
+                }
             }
     }
 }
@@ -342,8 +353,12 @@ void launch_cond(const CondParams& P, const int64_t* t, const float* text, const
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st) {
     hipLaunchKernelGGL(posa_kernel, dim3(B), dim3(1024), 0, st, P, given_objs, hm);
 }
-void launch_upsample12(const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, float* h2p, hipStream_t st) {
-    hipLaunchKernelGGL(upsample12_kernel, dim3(B * 256 / 64), dim3(256), 0, st, e0, up0, Dense{up2_wp, up2_b}, h2p);
+void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, void* h2p, hipStream_t st) {
+    const dim3 grid(B * 256 / 64), block(256);
+    const Dense up2{up2_wp, up2_b};
+    if (np == 0) hipLaunchKernelGGL(upsample12_kernel<0>, grid, block, 0, st, e0, up0, up2, h2p);
+    else if (np == 1) hipLaunchKernelGGL(upsample12_kernel<1>, grid, block, 0, st, e0, up0, up2, h2p);
+    else hipLaunchKernelGGL(upsample12_kernel<2>, grid, block, 0, st, e0, up0, up2, h2p);
 }
 void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st) {
     hipLaunchKernelGGL(scene_attn_kernel, dim3(B * kSlots), dim3(256), 0, st, P, pcd, w, tr, o);

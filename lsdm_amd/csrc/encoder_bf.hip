@@ -56,19 +56,38 @@ __global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__
         }
     } else {
         const typename FeatT<NP>::type* feat = src_feat + (size_t)c * NSRC * D;
-        constexpr int CH = K0P / 4;
-#pragma unroll 2
-        for (int e = tid; e < TM * CH; e += NT) {
+        // (1) feature columns: TM x D/4 aligned 4-channel pieces, branch-free; every index load, then every row
+        //     load of the thread is in flight before the first LDS store
+        constexpr int CH = D / 4;
+        static_assert((TM * CH) % NT == 0, "gather tiling");
+        constexpr int ITER = TM * CH / NT;
+        int gidx[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) gidx[it] = bl[(tid + it * NT) / CH];
+        f32x4 gv[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + it * NT;
+            gv[it] = load4f(feat + (size_t)gidx[it] * D + 4 * (e % CH));
+        }
+        // (2) the 16-wide tail [dx dy dz 0 ...] of each row
+        f32x4 tv = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (tid < TM) {
+            const int idx = bl[tid];
+            const float* cp = cen + (tid >> 5) * 3;
+            tv[0] = xyz[idx * 3 + 0] - cp[0]; tv[1] = xyz[idx * 3 + 1] - cp[1]; tv[2] = xyz[idx * 3 + 2] - cp[2];
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + it * NT;
             const int row = e / CH, ch = e - row * CH;
-            const int idx = bl[row];
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (ch < D / 4) {
-                v = load4f(feat + (size_t)idx * D + 4 * ch);
-            } else if (ch == D / 4) {
-                const float* cp = cen + (row >> 5) * 3;
-                v[0] = xyz[idx * 3 + 0] - cp[0]; v[1] = xyz[idx * 3 + 1] - cp[1]; v[2] = xyz[idx * 3 + 2] - cp[2];
-            }
-            store_split4<NP>(bufA + row * LDA + 4 * ch, PA, v[0], v[1], v[2], v[3]);
+            store_split4<NP>(bufA + row * LDA + 4 * ch, PA, gv[it][0], gv[it][1], gv[it][2], gv[it][3]);
+        }
+        if (tid < TM) {
+            __bf16* dst = bufA + tid * LDA + D;
+            store_split4<NP>(dst, PA, tv[0], tv[1], tv[2], 0.0f);
+#pragma unroll
+            for (int j = 1; j < (K0P - D) / 4; ++j) store_split4<NP>(dst + 4 * j, PA, 0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     __syncthreads();
@@ -84,9 +103,9 @@ __global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__
     for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
         f32x16 acc[TS::RB];
         acc_zero_h(acc);
-        mma_kloop_h<TS::RB, NP, false>(acc, bufA + rg * TS::RB * 32 * LDA, LDA, PA, l3.w, C3, cb, 0, C2 / 16, 0, lane);
         const int col = cb * 32 + (lane & 31);
         const float bv = l3.b[col];
+        mma_kloop_h<TS::RB, NP, false, C2 / 16>(acc, bufA + rg * TS::RB * 32 * LDA, LDA, PA, l3.w, C3, cb, 0, lane);
 #pragma unroll
         for (int rb = 0; rb < TS::RB; ++rb) {
             float m = acc[rb][0];
@@ -130,37 +149,71 @@ __global__ __launch_bounds__(NW * 64) void fp_h_kernel(const typename FeatT<NP>:
     constexpr int NCB = TS::CB / TS::CSTEP;
     const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
     f32x16 acc[NCB][TS::RB];
+    f32x4 bv1[NCB][4];
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) acc_zero_h(acc[q]);
+    for (int q = 0; q < NCB; ++q) { acc_zero_h(acc[q]); load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane); }
     for (int ch = 0; ch < K0 / KC; ++ch) {
         if (ch > 0) __syncthreads();
-#pragma unroll 2
-        for (int e = tid; e < TM * (KC / 4); e += NT) {
-            const int row = e / (KC / 4), c4 = e - row * (KC / 4);
-            const int col = ch * KC + 4 * c4;
-            f32x4 v;
-            if (col < D1) {
-                v = load4f(p1 + (size_t)row * D1 + col);
-            } else {
-                const int cc = col - D1;
-                const float w0 = nw[row * 3 + 0], w1 = nw[row * 3 + 1], w2 = nw[row * 3 + 2];
-                const f32x4 f0 = load4f(p2 + (size_t)ni[row * 3 + 0] * D2 + cc);
-                const f32x4 f1 = load4f(p2 + (size_t)ni[row * 3 + 1] * D2 + cc);
-                const f32x4 f2 = load4f(p2 + (size_t)ni[row * 3 + 2] * D2 + cc);
+        static_assert((TM * (KC / 4)) % NT == 0 && (D1 % KC == 0), "gather tiling: a chunk is all points1 or all interpolation");
+        constexpr int ITER = TM * (KC / 4) / NT;
+        if (ch * KC < D1) {   // uniform: plain copy of points1 columns
+            f32x4 gv[ITER];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(f0[j], w0), __fmul_rn(f1[j], w1)), __fmul_rn(f2[j], w2));
+            for (int it = 0; it < ITER; ++it) {
+                const int e = tid + it * NT;
+                const int row = e / (KC / 4), c4 = e - row * (KC / 4);
+                gv[it] = load4f(p1 + (size_t)row * D1 + ch * KC + 4 * c4);
             }
-            store_split4<NP>(bufX + row * LDX + 4 * c4, PX, v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int e = tid + it * NT;
+                const int row = e / (KC / 4), c4 = e - row * (KC / 4);
+                store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gv[it][0], gv[it][1], gv[it][2], gv[it][3]);
+            }
+        } else {              // inverse-distance interpolation of the three nearest coarse points
+            const int cc0 = ch * KC - D1;
+            constexpr int HALF = ITER > 4 ? ITER / 2 : ITER;   // bound the loads in flight (3 rows x 16 B each)
+            static_assert(ITER % HALF == 0, "gather tiling");
+#pragma unroll 1
+            for (int h0 = 0; h0 < ITER; h0 += HALF) {
+                int i0[HALF], i1[HALF], i2[HALF];
+                float w0[HALF], w1[HALF], w2[HALF];
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) {
+                    const int row = (tid + (h0 + it) * NT) / (KC / 4);
+                    i0[it] = ni[row * 3 + 0]; i1[it] = ni[row * 3 + 1]; i2[it] = ni[row * 3 + 2];
+                    w0[it] = nw[row * 3 + 0]; w1[it] = nw[row * 3 + 1]; w2[it] = nw[row * 3 + 2];
+                }
+                f32x4 f0[HALF], f1[HALF], f2[HALF];
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) {
+                    const int e = tid + (h0 + it) * NT;
+                    const int cc = cc0 + 4 * (e % (KC / 4));
+                    f0[it] = load4f(p2 + (size_t)i0[it] * D2 + cc);
+                    f1[it] = load4f(p2 + (size_t)i1[it] * D2 + cc);
+                    f2[it] = load4f(p2 + (size_t)i2[it] * D2 + cc);
+                }
+#pragma unroll
+                for (int it = 0; it < HALF; ++it) {
+                    const int e = tid + (h0 + it) * NT;
+                    const int row = e / (KC / 4), c4 = e - row * (KC / 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = __fadd_rn(__fadd_rn(__fmul_rn(f0[it][j], w0[it]), __fmul_rn(f1[it][j], w1[it])), __fmul_rn(f2[it][j], w2[it]));
+                    store_split4<NP>(bufX + row * LDX + 4 * c4, PX, v[0], v[1], v[2], v[3]);
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NCB; ++q)
-            mma_kloop_h<TS::RB, NP, true>(acc[q], bufX + rg * TS::RB * 32 * LDX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, ch * (KC / 16),
-                                          (ch + 1) * (KC / 16), ch * (KC / 16), lane);
+            mma_kloop_h<TS::RB, NP, true, KC / 16>(acc[q], bufX + rg * TS::RB * 32 * LDX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP,
+                                                   ch * (KC / 16), lane);
     }
     if constexpr (!HEAD) __syncthreads();   // bufB aliases the chunk buffer
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, TS::RB, NP>(acc[q], rg * TS::RB, cb0 + q * TS::CSTEP, l1.b, bufB, LDB, PB, lane);
+    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, TS::RB, NP>(acc[q], rg * TS::RB, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
     __syncthreads();
 
     if constexpr (!HEAD) {
@@ -172,9 +225,9 @@ __global__ __launch_bounds__(NW * 64) void fp_h_kernel(const typename FeatT<NP>:
         for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
             f32x16 a2[T2::RB];
             acc_zero_h(a2);
-            mma_kloop_h<T2::RB, NP, false>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, C1 / 16, 0, lane);
             const int col = cb * 32 + (lane & 31);
             const float bv = l2.b[col];
+            mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
 #pragma unroll
             for (int rb = 0; rb < T2::RB; ++rb)
 #pragma unroll

@@ -51,6 +51,14 @@ struct DenoiseParams {
     Lin pwt;              // point_wise_trans_layer.0         15 -> 3    GELU
 };
 
+struct DenoiseHParams {  // split-bf16 operands of the same layers (denoise_bf.hip)
+    const __bf16* up4_h;  // upsampling_layer.4.weight (1024,512) as bf16 hi / lo planes, row-major (the "activation" operand)
+    const __bf16* up4_l;
+    const float* up4_b;
+    DenseH comb, pose2, cex0, cex2, fin0;
+    Lin pose0, fin2, pwt;
+};
+
 struct StepCoefs {  // per-timestep fp32 tables (gathered by t inside the kernel); see diffusion/schedule.py
     const float* coef1;     // posterior_mean_coef1
     const float* coef2;     // posterior_mean_coef2
@@ -81,11 +89,17 @@ void launch_fp_h(int np, int which, int num_clouds, const void* points1, const v
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st);
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st);
-void launch_upsample12(const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, float* h2p, hipStream_t st);
+// np = 0: fp32 operand for denoise_kernel; 1 / 2: bf16 planes for denoise_h_kernel
+void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, void* h2p, hipStream_t st);
 void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st);
 // denoise.hip
 void launch_denoise(const DenoiseParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
                     const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const float* h2p,
                     const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
+
+// denoise_bf.hip
+void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
+                      const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2p,
+                      const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
 
 }  // namespace lsdm
