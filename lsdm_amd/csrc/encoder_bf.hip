@@ -12,6 +12,21 @@
 
 namespace lsdm {
 
+// Optional phase timing (make PHASE=1): lane 0 of every workgroup adds its s_memtime deltas per phase to a device array.
+#ifdef LSDM_PHASE_TIMING
+__device__ unsigned long long g_phase[64 * 64];   // 64 spread copies of 64 slots (no same-address contention)
+#define PHASE_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime(); unsigned long long pd_[8] = {}
+#define PHASE_MARK(slot)                                                                  \
+    do {                                                                                  \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();                       \
+        pd_[(slot) & 7] += n_ - pt_;                                                      \
+        pt_ = n_;                                                                         \
+    } while (0)
+#else
+#define PHASE_T0() do {} while (0)
+#define PHASE_MARK(slot) do {} while (0)
+#endif
+
 template <int NP> struct FeatT { typedef float type; };
 template <> struct FeatT<1> { typedef __bf16 type; };
 
@@ -25,8 +40,8 @@ __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store1(__bf16* p, float v) { *p = (__bf16)v; }
 
 // ---------------------------------------------------------------------------------------------
-template <int D, int C1, int C2, int C3, int TM, int NW, int NP>
-__global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__ src_xyz, const typename FeatT<NP>::type* __restrict__ src_feat,
+template <int D, int C1, int C2, int C3, int TM, int NW, int NP, int WPS = 1>
+__global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restrict__ src_xyz, const typename FeatT<NP>::type* __restrict__ src_feat,
                                                         const float* __restrict__ new_xyz, const int* __restrict__ ball, int NSRC,
                                                         int S, DenseH l1, DenseH l2, DenseH l3,
                                                         typename FeatT<NP>::type* __restrict__ out) {
@@ -42,6 +57,8 @@ __global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__
     const float* xyz = src_xyz + (size_t)c * NSRC * 3;
     const int* bl = ball + ((size_t)c * S + s0) * kNSample;
     const float* cen = new_xyz + ((size_t)c * S + s0) * 3;
+    constexpr int PS = (D == 3 ? 0 : D == 64 ? 8 : D == 128 ? 16 : 24);   // phase-timing slot base of this level
+    PHASE_T0();
     if constexpr (D == 3) {
         // sa1: the point features are the raw coordinates.  Row = [x y z | dx dy dz | 0 x 10]
         for (int row = tid; row < TM; row += NT) {
@@ -90,11 +107,17 @@ __global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__
             for (int j = 1; j < (K0P - D) / 4; ++j) store_split4<NP>(dst + 4 * j, PA, 0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
+    PHASE_MARK(PS + 0);   // gather issued + written (this wave)
     __syncthreads();
+    PHASE_MARK(PS + 1);   // barrier wait
     layer_lds_h<NW, TM, K0P, C1, ACT_RELU, NP>(bufA, LDA, PA, l1, bufB, LDB, PB);
+    PHASE_MARK(PS + 2);
     __syncthreads();
+    PHASE_MARK(PS + 3);
     layer_lds_h<NW, TM, C1, C2, ACT_RELU, NP>(bufB, LDB, PB, l2, bufA, LDA, PA);
+    PHASE_MARK(PS + 4);
     __syncthreads();
+    PHASE_MARK(PS + 5);
     // layer 3 in the direct orientation D[point][channel] + max over the 32 neighbours of each centroid
     using TS = SplitH<NW, TM, C3>;
     const int wave = tid >> 6, lane = tid & 63;
@@ -116,13 +139,46 @@ __global__ __launch_bounds__(NW * 64) void sa_h_kernel(const float* __restrict__
             if (lane < 32) store1(out + ((size_t)c * S + s0 + rg * TS::RB + rb) * C3 + col, reluf(m + bv));
         }
     }
+    PHASE_MARK(PS + 6);
+#ifdef LSDM_PHASE_TIMING
+    if (threadIdx.x == 0) {
+        unsigned long long* g = g_phase + ((blockIdx.x + blockIdx.y * 7) & 63) * 64 + PS;
+        for (int i = 0; i < 7; ++i) atomicAdd(g + i, pd_[i]);
+        atomicAdd(g + 7, 1ull);
+    }
+#endif
 }
+
+#ifdef LSDM_PHASE_TIMING
+__global__ void calib_kernel(unsigned long long* out) {
+    const unsigned long long w0 = wall_clock64(), m0 = __builtin_amdgcn_s_memtime(), c0 = clock64();
+    while (wall_clock64() - w0 < 100000ull) {}   // 1 ms of the 100 MHz constant clock
+    out[0] = __builtin_amdgcn_s_memtime() - m0;
+    out[1] = clock64() - c0;
+    out[2] = wall_clock64() - w0;
+}
+extern "C" int lsdm_debug_calibrate(unsigned long long* out3) {
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, 24) != hipSuccess) return -1;
+    hipLaunchKernelGGL(calib_kernel, dim3(1), dim3(64), 0, 0, d);
+    const int rc = hipMemcpy(out3, d, 24, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    (void)hipFree(d);
+    return rc;
+}
+extern "C" int lsdm_debug_phase_counters(unsigned long long* out, int reset) {
+    static unsigned long long h[64 * 64], z[64 * 64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return -1;
+    for (int s = 0; s < 64; ++s) { out[s] = 0; for (int c = 0; c < 64; ++c) out[s] += h[c * 64 + s]; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // FP stage: [points1 || sum_j w_j * points2[idx_j]] -> conv+BN+ReLU stack; K streamed through LDS in chunks of KC.
 // HEAD adds conv1+bn1+ReLU (128->128) and conv2 (128->3, fp32 VALU) and writes fp32.
-template <int D1, int D2, int C1, int C2, int C3, bool HEAD, int TM, int KC, int NW, int NP>
-__global__ __launch_bounds__(NW * 64) void fp_h_kernel(const typename FeatT<NP>::type* __restrict__ points1,
+template <int D1, int D2, int C1, int C2, int C3, bool HEAD, int TM, int KC, int NW, int NP, int WPS = 1>
+__global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT<NP>::type* __restrict__ points1,
                                                         const typename FeatT<NP>::type* __restrict__ points2,
                                                         const int* __restrict__ nn_idx, const float* __restrict__ nn_w, int N, int S,
                                                         DenseH l1, DenseH l2, DenseH l3, DenseH h1, Lin h2, void* __restrict__ out_v) {
@@ -172,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void fp_h_kernel(const typename FeatT<NP>:
             }
         } else {              // inverse-distance interpolation of the three nearest coarse points
             const int cc0 = ch * KC - D1;
-            constexpr int HALF = ITER > 4 ? ITER / 2 : ITER;   // bound the loads in flight (3 rows x 16 B each)
+            constexpr int HALF = ITER > 2 ? 2 : ITER;   // bound the loads in flight (3 rows x 16 B each per iteration)
             static_assert(ITER % HALF == 0, "gather tiling");
 #pragma unroll 1
             for (int h0 = 0; h0 < ITER; h0 += HALF) {
