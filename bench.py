@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense stacks (geometry and sampler arithmetic are always fp32)")
-    ap.add_argument("--no-pipeline", action="store_true", help="run front and back of every step on one stream")
+    ap.add_argument("--pipeline", action="store_true", help="EXPERIMENTAL two-stream overlap of front(k+1) with back(k); off: see include/lsdm_hip.h")
+    ap.add_argument("--no-hoisted", action="store_true", help="skip the extra hoisted-conditioning measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -94,7 +95,7 @@ def main():
     model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
     ctx = model._context()
     model._reserve(B)
-    ctx.call("lsdm_set_pipeline", 0 if a.no_pipeline else 1)
+    ctx.call("lsdm_set_pipeline", 1 if a.pipeline else 0)
     model._set_schedule((id(diffusion), diffusion.num_timesteps), diffusion._device_tables())
     bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=a.seed + rank, max_cats=C, num_objects=8).items()}
     # RNG stream of the reference: x_T, then per step 4 FPS randints + randn, host generator
@@ -146,6 +147,28 @@ def main():
         dt = float(tmax)
     assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
 
+    # Separate, clearly labelled figure (never `value`): hoisted-conditioning mode -- FPS starts pinned,
+    # scene conditioning evaluated once per call, then K steps of embedding MLPs + fused denoiser/sampler update.
+    hoisted = None
+    if not a.no_hoisted:
+        KH = max(K, 50)
+        nh = noise[:1].expand(KH, -1, -1, -1).contiguous()      # any resident noise; values do not affect timing
+        xh = x.clone()
+
+        def run_h():
+            ctx.call("lsdm_sample_steps_hoisted", _lib.MODE_P_SAMPLE, 0.0, B, T - 1, KH, p(xh), p(bt["mask"]), p(bt["given_objs"]),
+                     p(bt["given_cats"]), p(bt["text_features"]), p(starts[0]), p(nh), p(out_cat), p(out_x0), p(out_g), stream)
+        run_h()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_h()
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t1
+        hoisted = {"value": KH / dth, "unit": "denoising-steps/sec per GPU (B=%d)" % B, "steps": KH, "ms_per_step": dth / KH * 1e3,
+                   "note": "NOT the headline metric: conditioning (human branch, PointNet++ geometry + dense stages, scene attention) "
+                           "evaluated once per call with pinned FPS starts, included in the timed call; equals the reference only with "
+                           "its per-step FPS re-draw pinned (tests: g6_hoisted golden)"}
+
     if rank == 0:
         units = {"ball": B * 9, "sa_": B * 9, "three": B * 9, "fp_k": B * 9, "fps": B * 9}
         rows = []
@@ -181,6 +204,8 @@ def main():
                                         "note": "14.58 GFLOP per sample-step (SURVEY.md 8d) x B / ms_per_step, TFLOP/s vs fp32 MFMA peak"},
                          "kernels": [{"name": r["name"], "avg_ms": round(r["avg_ms"], 4), "tflops": round(r["tflops"], 2)} for r in rows]},
         }
+        if hoisted:
+            res["hoisted_conditioning"] = hoisted
         if not a.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
             res["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, C)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -71,9 +72,10 @@ struct lsdm_ctx {
     float* feat[4] = {};
     float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
     float *hm = nullptr, *o12 = nullptr, *xs = nullptr;
-    bool pipeline = true;             // lsdm_sample_steps: overlap front(k+1) with back(k) on two streams
+    bool pipeline = false;            // lsdm_sample_steps: overlap front(k+1) with back(k) on two streams (see lsdm_set_pipeline)
     hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_front[2] = {}, ev_back[2] = {};
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_front, ev_back;   // one pair per step of a call (never re-recorded while a wait may be pending)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -329,17 +331,22 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
     fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
+    const int sync_after = getenv("LSDM_SYNC_AFTER") ? atoi(getenv("LSDM_SYNC_AFTER")) : 0;   // debug bisect
     for (int l = 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
         launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
+        if (sync_after == l + 1) (void)hipStreamSynchronize(st);
     }
     const Lin head2{c->head[1].w, c->head[1].b};
     prof_mark(c, K_FP4, st);
     launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
+    if (sync_after == 5) (void)hipStreamSynchronize(st);
     prof_mark(c, K_FP3, st);
     launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
+    if (sync_after == 6) (void)hipStreamSynchronize(st);
     prof_mark(c, K_FP2, st);
     launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
+    if (sync_after == 7) (void)hipStreamSynchronize(st);
     prof_mark(c, K_FP1, st);
     launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
 }
@@ -353,7 +360,8 @@ int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, i
 // FRONT of a step: everything that does not read x -- conditioning vectors, up-sampling layers 1-2, the human branch
 // (given_objs only: evaluated once per multi-step call) and the PointNet++ geometry.
 void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_objs, const float* given_cats,
-               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st) {
+               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st, hipStream_t geo_st = nullptr,
+               bool split = false) {
     prof_mark(c, K_COND, st);
     launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
     prof_mark(c, K_UP12, st);
@@ -362,16 +370,23 @@ void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* m
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->hm, st);
     }
-    run_geometry(c, f, given_objs, starts, B * kO, st);
+    run_geometry(c, f, given_objs, starts, B * kO, split ? geo_st : st);
     prof_mark(c, -1, st);
 }
 
-// BACK of a step: dense encoder stages, collapsed scene attention, the fused per-point denoiser + sampler update
-void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
-              const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
+// conditioning that depends on the scene only: dense encoder stages + collapsed scene attention (needs f.w, f.tr)
+void run_scene_conditioning(lsdm_ctx* c, const FrontSet& f, int B, const float* given_objs, hipStream_t st) {
+    const int dbg = getenv("LSDM_PIPE_DEBUG") ? atoi(getenv("LSDM_PIPE_DEBUG")) : 0;
     run_encoder_dense(c, f, given_objs, B * kO, c->pcd, st);
+    if (dbg & 4) (void)hipStreamSynchronize(st);
     prof_mark(c, K_SATTN, st);
     launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
+    if (dbg & 8) (void)hipStreamSynchronize(st);
+}
+
+// the fused per-point denoiser + sampler update (the only stage that reads x)
+void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
+                 const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
     prof_mark(c, K_DENOISE, st);
     if (c->prec == LSDM_PREC_F32)
         launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm, f.h2p, noise, out_x0, out_guiding,
@@ -379,6 +394,24 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
     else
         launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm,
                          f.h2p, noise, out_x0, out_guiding, out_sample, st);
+    prof_mark(c, -1, st);
+}
+
+// BACK of a step: dense encoder stages, collapsed scene attention, the fused per-point denoiser + sampler update
+void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
+              const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
+    run_scene_conditioning(c, f, B, given_objs, st);
+    run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st);
+}
+
+// t-dependent conditioning only (timestep/text/category MLPs + up-sampling layers 1-2) -- the per-step front of the
+// hoisted-conditioning mode
+void run_light_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_cats, const float* text,
+                     float* out_cat, hipStream_t st) {
+    prof_mark(c, K_COND, st);
+    launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
+    prof_mark(c, K_UP12, st);
+    launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B, f.h2p, st);
     prof_mark(c, -1, st);
 }
 
@@ -424,7 +457,8 @@ int lsdm_destroy(lsdm_ctx* c) {
     if (c->aux) {
         (void)hipStreamDestroy(c->aux);
         (void)hipEventDestroy(c->ev_fork);
-        for (int s = 0; s < 2; ++s) { (void)hipEventDestroy(c->ev_front[s]); (void)hipEventDestroy(c->ev_back[s]); }
+        for (hipEvent_t e : c->ev_front) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->ev_back) (void)hipEventDestroy(e);
     }
     delete c;
     return LSDM_OK;
@@ -717,10 +751,13 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     if (piped && !c->aux) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        for (int s = 0; s < 2; ++s) {
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_front[s], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_back[s], hipEventDisableTiming));
-        }
+    }
+    while (piped && (int)c->ev_front.size() < K) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->ev_front.push_back(a);
+        c->ev_back.push_back(b);
     }
     // The front of a step (conditioning + geometry) reads neither x nor the previous step's results, so front(k+1) runs
     // on the auxiliary stream while the dense stages of step k occupy the matrix cores; the only serial chain left is
@@ -731,30 +768,69 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
         HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     }
     c->prof_stream = piped ? 1 : 0;
+    const int dbg = getenv("LSDM_PIPE_DEBUG") ? atoi(getenv("LSDM_PIPE_DEBUG")) : 0;
     auto front = [&](int k) {
         lsdm_ctx::FrontSet& f = c->fs[piped ? (k & 1) : 0];
         hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, fst, f.tbuf, (int64_t)(t_first - k), B);
-        run_front(c, f, B, f.tbuf, mask, given_objs, given_cats, text, starts + (size_t)k * 4 * B * kO, out_cat, /*reuse_hm=*/k > 0, fst);
+        const bool split = piped && (dbg & 16);   // debug: geometry on the caller's stream, only cond/up12 on aux
+        run_front(c, f, B, f.tbuf, mask, given_objs, given_cats, text, starts + (size_t)k * 4 * B * kO, out_cat, /*reuse_hm=*/k > 0, fst, st,
+                  split);
     };
     for (int k = 0; k < K; ++k) {
         const int s = piped ? (k & 1) : 0;
         if (piped) {
             c->prof_stream = 1;
-            if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_back[s], 0));
+            if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_back[k - 2], 0));
             front(k);
-            HIP_TRY(c, hipEventRecord(c->ev_front[s], c->aux));
-            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_front[s], 0));
+            HIP_TRY(c, hipEventRecord(c->ev_front[k], c->aux));
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_front[k], 0));
+            if (dbg & 1) HIP_TRY(c, hipStreamSynchronize(c->aux));
             c->prof_stream = 0;
         } else {
             front(k);
         }
         run_back(c, c->fs[s], mode, eta, B, cur, c->fs[s].tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
-        if (piped) HIP_TRY(c, hipEventRecord(c->ev_back[s], st));
+        if (piped) HIP_TRY(c, hipEventRecord(c->ev_back[k], st));
+        if (dbg & 2) HIP_TRY(c, hipStreamSynchronize(st));
         rc = check_launch(c, "sample step");
         if (rc) return rc;
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
     c->prof_stream = 0;
+    if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return LSDM_OK;
+}
+
+int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+                              const float* given_objs, const float* given_cats, const float* text, const int64_t* starts,
+                              const float* noise, float* out_cat, float* out_x0, float* out_guiding, void* stream) {
+    int rc = check_ready(c, B, true);
+    if (rc) return rc;
+    if (mode != LSDM_MODE_P_SAMPLE && mode != LSDM_MODE_DDIM) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps_hoisted: bad mode %d", mode);
+    if (K <= 0 || t_first >= c->sched_T || t_first - K + 1 < 0) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps_hoisted: steps [%d..%d] outside schedule", t_first - K + 1, t_first);
+    if (!x || !mask || !given_objs || !given_cats || !text || !starts || !noise || !out_cat || !out_x0 || !out_guiding)
+        return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps_hoisted: NULL tensor");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* cur = x;
+    float* nxt = c->xs;
+    const size_t xn = (size_t)B * kN * 3;
+    // once per call: everything that depends on (given_objs, text, cats, mask, FPS starts) only
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)t_first, B);
+    run_front(c, c->fs[0], B, c->fs[0].tbuf, mask, given_objs, given_cats, text, starts, out_cat, /*reuse_hm=*/false, st);
+    run_scene_conditioning(c, c->fs[0], B, given_objs, st);
+    // per step: t-dependent conditioning (front) + the denoiser (back).  fs[0] already holds step 0's front.
+    for (int k = 0; k < K; ++k) {
+        lsdm_ctx::FrontSet& f = c->fs[k & 1];
+        if (k > 0) {
+            hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f.tbuf, (int64_t)(t_first - k), B);
+            run_light_front(c, f, B, f.tbuf, mask, given_cats, text, out_cat, st);
+        }
+        run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
+        rc = check_launch(c, "hoisted sample step");
+        if (rc) return rc;
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
     if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
     return LSDM_OK;
 }

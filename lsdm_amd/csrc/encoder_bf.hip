@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     const float* xyz = src_xyz + (size_t)c * NSRC * 3;
     const int* bl = ball + ((size_t)c * S + s0) * kNSample;
     const float* cen = new_xyz + ((size_t)c * S + s0) * 3;
-    constexpr int PS = (D == 3 ? 0 : D == 64 ? 8 : D == 128 ? 16 : 24);   // phase-timing slot base of this level
+    [[maybe_unused]] constexpr int PS = (D == 3 ? 0 : D == 64 ? 8 : D == 128 ? 16 : 24);   // phase-timing slot base of this level
     PHASE_T0();
     if constexpr (D == 3) {
         // sa1: the point features are the raw coordinates.  Row = [x y z | dx dy dz | 0 x 10]

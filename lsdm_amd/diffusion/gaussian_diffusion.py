@@ -189,10 +189,60 @@ class GaussianDiffusion:
                                    noise_fn=lambda: self._noise_like(x, const_noise))
         return {"sample": sample, "pred_xstart": x0}
 
+    def _bulk_loop(self, mode, eta, model, shape, mask, given_objs, given_cats, y, noise, device, skip_timesteps, init_image,
+                   const_noise, hoist_conditioning, chunk_steps):
+        """Whole sampling loop with ``chunk_steps`` steps per library call.  The random numbers are drawn in the
+        reference's order (x_T; then per step the 4 FPS randints of pointnet2_utils.py:72 and randn_like of
+        gaussian_diffusion.py:545), only ahead of time for a chunk.  With ``hoist_conditioning`` the FPS starts are the
+        first step's draws for every step and the scene conditioning is evaluated once per chunk."""
+        inner = _unwrap(model)
+        if device is None:
+            device = next(inner.parameters()).device
+        B = shape[0]
+        if noise is not None:
+            img = noise
+        else:
+            img = th.randn(*shape).to(device) if self.host_rng else th.randn(*shape, device=device)
+        if skip_timesteps and init_image is None:
+            init_image = th.zeros_like(img)
+        t_first = self.num_timesteps - skip_timesteps - 1
+        if init_image is not None:
+            my_t = th.ones([B], device=device, dtype=th.long) * t_first
+            img = self.q_sample(init_image, my_t, img)
+        x = img.to(device=device, dtype=th.float32).contiguous().clone()
+        inner._set_schedule((id(self), self.num_timesteps), self._device_tables())
+        text = inner._encode_text(y, B, x.device)      # the same features every step: encoded once
+        from ..model.sdm import FPS_RANGES, NUM_SLOTS
+        draw_starts = lambda: th.stack([th.randint(0, n, (B * NUM_SLOTS,), dtype=th.long) for n in FPS_RANGES])
+        pinned, done, total = None, 0, t_first + 1
+        while done < total:
+            k = min(int(chunk_steps), total - done)
+            starts, noises = [], []
+            for _ in range(k):
+                if hoist_conditioning:
+                    if pinned is None:
+                        pinned = draw_starts()
+                else:
+                    starts.append(draw_starts())
+                noises.append(self._noise_like(x, const_noise))
+            inner._run_steps(mode, eta, x, mask, t_first - done, k, given_objs, given_cats, text,
+                             pinned if hoist_conditioning else th.stack(starts), th.stack(noises), hoisted=hoist_conditioning)
+            done += k
+        return x
+
     def p_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                       denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
                       init_image=None, randomize_class=False, cond_fn_with_grad=False, dump_steps=None,
-                      const_noise=False):
+                      const_noise=False, *, hoist_conditioning=False, chunk_steps=50):
+        """Reference signature (gaussian_diffusion.py:611-632) + two keyword-only extensions: ``chunk_steps`` (steps per
+        library call on the fused path; results do not depend on it) and ``hoist_conditioning`` (pin the FPS starts to
+        the first step's draws and evaluate the scene conditioning once -- not the stock reference's behaviour)."""
+        if (dump_steps is None and not progress and not randomize_class and not cond_fn_with_grad
+                and self._fusable(model, clip_denoised, denoised_fn, cond_fn)):
+            return self._bulk_loop(_lib.MODE_P_SAMPLE, 0.0, model, shape, mask, given_objs, given_cats, y, noise, device,
+                                   skip_timesteps, init_image, const_noise, hoist_conditioning, chunk_steps)
+        if hoist_conditioning:
+            raise NotImplementedError("hoist_conditioning needs the fused path (clip_denoised=False, no denoised_fn/cond_fn/dump_steps)")
         final, dump = None, []
         for i, sample in enumerate(self.p_sample_loop_progressive(
                 model, shape, mask, given_objs, given_cats, y, noise=noise, clip_denoised=clip_denoised,
@@ -243,9 +293,12 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
                          skip_timesteps=0, init_image=None, randomize_class=False, cond_fn_with_grad=False,
-                         dump_steps=None, const_noise=False):
+                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=50):
         if dump_steps is not None or const_noise:
             raise NotImplementedError()
+        if not progress and not randomize_class and not cond_fn_with_grad and self._fusable(model, clip_denoised, denoised_fn, cond_fn):
+            return self._bulk_loop(_lib.MODE_DDIM, eta, model, shape, mask, given_objs, given_cats, y, noise, device,
+                                   skip_timesteps, init_image, False, hoist_conditioning, chunk_steps)
         final = None
         for sample in self.ddim_sample_loop_progressive(
                 model, shape, mask, given_objs, given_cats, y, noise=noise, clip_denoised=clip_denoised,

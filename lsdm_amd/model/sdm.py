@@ -197,6 +197,31 @@ class SceneDiffusionModel(nn.Module):
         self.saved_guiding_points = out_guid
         return out_cat, out_x0, out_sample
 
+    def _run_steps(self, mode, eta, x, mask, t_first, K, given_objs, given_cats, text, starts, noise, hoisted=False):
+        """K consecutive sampler steps t = t_first .. t_first-K+1 in ONE library call (lsdm_sample_steps, or
+        lsdm_sample_steps_hoisted with one pinned (4,B*9) start tensor).  ``x`` (device, contiguous) holds the result;
+        ``starts`` (K,4,B*9) int64 and ``noise`` (K,B,1024,3) are the pre-drawn RNG streams of the K steps."""
+        B = x.shape[0]
+        dev = x.device
+        ctx = self._context()
+        self._reserve(B)
+        f32 = lambda v: v.to(device=dev, dtype=torch.float32).contiguous()
+        mask, given_objs, given_cats = f32(mask), f32(given_objs), f32(given_cats)
+        if given_objs.shape != (B, NUM_SLOTS, self.pcd_points, 3) or x.shape != (B, self.pcd_points, 3) \
+                or given_cats.shape != (B, NUM_SLOTS, self.max_cats):
+            raise ValueError("expected given_objs (B,9,1024,3), x (B,1024,3), given_cats (B,9,%d)" % self.max_cats)
+        starts = starts.to(device=dev, dtype=torch.long).contiguous()
+        noise = f32(noise)
+        assert noise.shape == (K, B, self.pcd_points, 3) and starts.shape == ((4, B * NUM_SLOTS) if hoisted else (K, 4, B * NUM_SLOTS))
+        out_cat = torch.empty(B, 1, self.max_cats, device=dev)
+        out_x0, out_guid = torch.empty_like(x), torch.empty_like(x)
+        p = lambda v: v.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ctx.call("lsdm_sample_steps_hoisted" if hoisted else "lsdm_sample_steps", mode, float(eta), B, int(t_first), int(K), p(x),
+                 p(mask), p(given_objs), p(given_cats), p(text), p(starts), p(noise), p(out_cat), p(out_x0), p(out_guid), stream)
+        self.saved_cat, self.saved_guiding_points = out_cat, out_guid
+        return out_x0
+
     def forward(self, x, mask, timesteps, given_objs, given_cats, y=None, force_mask=False, *, fps_starts=None):
         """x (B,1024,3) is mutated in place (x += guidance, model/sdm.py:204).  Returns (out_cat, x_out)."""
         out_cat, out_x0, _ = self._run(_lib.MODE_FORWARD, 0.0, x, mask, timesteps, given_objs, given_cats, y, fps_starts)

@@ -419,7 +419,7 @@ class Sampler:
         return {"sample": mean_pred + nz * sigma * noise, "pred_xstart": out["pred_xstart"]}
 
     def sample_loop(self, shape, mask, given_objs, given_cats, text_features, noise=None, skip_timesteps=0,
-                    init_image=None, use_ddim=False, on_step=None):
+                    init_image=None, use_ddim=False, on_step=None, hoist_conditioning=False):
         """p_sample_loop_progressive (gaussian_diffusion.py:684-759): init noise, optional q_sample of an
         init image (:721-728), descending t loop."""
         img = noise if noise is not None else torch.randn(*shape)
@@ -431,9 +431,12 @@ class Sampler:
             img = (_coef(self.tab["sqrt_alphas_cumprod"], t0, img) * init_image
                    + _coef(self.tab["sqrt_one_minus_alphas_cumprod"], t0, img) * img)
         step = self.ddim_sample if use_ddim else self.p_sample
+        pinned = None   # hoist_conditioning: the FPS starts of the first step are re-used by every step
         for i in indices:
             t = torch.tensor([i] * shape[0])
-            out = step(img, mask, t, given_objs, given_cats, text_features)
+            if hoist_conditioning and pinned is None:
+                pinned = draw_fps_starts(shape[0] * given_objs.shape[1])
+            out = step(img, mask, t, given_objs, given_cats, text_features, fps_starts=pinned)
             if on_step is not None:
                 on_step(i, out)
             img = out["sample"]

@@ -10,6 +10,7 @@ Golden sets:
   G2  one SceneDiffusionModel.forward, B=3 ragged masks, C in {13, 43}: outputs + module taps.
   G3  PointNet++ known answers on 3 clouds (one all-zero): FPS / ball-query / 3-NN indices, features.
   G4  short p_sample_loop chains (skip_timesteps = 1000-K) with per-step samples; B in {1,3,16}.
+  G6  hoisted conditioning: the reference with its FPS re-draw pinned to the first forward's starts, K = 4 steps.
   G5  DDIM-50: reference p_mean_variance + the arithmetic of gaussian_diffusion.py:790-811.
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
@@ -222,6 +223,32 @@ def g4():
         save("g4_chain_%s" % tag, samples=samples, saved_cat=cat, guiding=guid, meta=np.array([B, C, K, 100 + B, 40 + B]))
 
 
+def g6():
+    """Hoisted conditioning: the REAL reference with its per-forward FPS re-draw pinned -- torch.randint
+    (only used by farthest_point_sample on this path, pointnet2_utils.py:72) returns the first forward's four draws on
+    every later forward; everything else (noise stream, sampler) is the stock reference."""
+    diff = ref_diffusion()
+    B, C, K = 2, 13, 4
+    m = ref_model(C)
+    real, rec, n = torch.randint, [], [0]
+
+    def pinned(*a, **k):
+        i = n[0]
+        n[0] += 1
+        if i < 4:
+            rec.append(real(*a, **k))
+            return rec[i]
+        return rec[i % 4].clone()
+
+    torch.randint = pinned
+    try:
+        samples, cat, guid = _chain(m, diff, B, C, K, seed=77, bt_seed=78)
+    finally:
+        torch.randint = real
+    assert n[0] == 4 * K
+    save("g6_hoisted", samples=samples, saved_cat=cat, guiding=guid, starts=torch.stack(rec), meta=np.array([B, C, K, 77, 78]))
+
+
 def g5():
     """DDIM composed exactly as SURVEY.md A9: the reference's p_mean_variance on the respaced process,
     followed by the reference's ddim_sample arithmetic (gaussian_diffusion.py:790-811) re-evaluated
@@ -261,7 +288,7 @@ def long_chain(steps):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6")
     ap.add_argument("--long-steps", type=int, default=1000)
     a = ap.parse_args()
     todo = a.only.split(",")

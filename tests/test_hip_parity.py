@@ -319,6 +319,102 @@ def test_sample_steps_entry_point_equals_python_loop(sd13):
     assert maxabs(out_g, guid_loop) == 0.0
 
 
+# --------------------------------------------------------------------------------------- precision modes
+@pytest.mark.parametrize("precision,tol_feat,tol_out", [("bf16x3", 1e-3, 5e-4), ("bf16", 0.5, 5e-2)])
+def test_split_bf16_precisions_vs_oracle_and_reference_golden(golden, precision, tol_feat, tol_out):
+    """bf16x3 (fp32 operands split into bf16 hi+lo, 3 MFMAs per product) holds the SAME output bar as the exact-fp32 path
+    (<= 5e-4 here, north_star <= 1e-3); plain bf16 is a reduced-precision mode whose error is only bounded loosely.
+    Geometry is fp32 in every mode, so FPS / ball-query / 3-NN indices stay bit-exact."""
+    g = golden("g2_forward_c13")
+    sd = make_synthetic_state_dict(seed=0, max_cats=13)
+    m, _ = create_model_and_diffusion("proxd", precision=precision)
+    m.load_state_dict(sd)
+    bt = make_synthetic_batch(3, seed=5, max_cats=13)
+    starts = [s.long() for s in T(g["starts"])]
+    t = T(g["t"]).long()
+    x_ref = T(g["x_in"]).clone()
+    taps = {}
+    cat_o, out_o, guid_o = cpu_ref.forward(sd, x_ref, bt["mask"], t, bt["given_objs"], bt["given_cats"], bt["text_features"],
+                                           fps_starts=starts, taps=taps)
+    x = T(g["x_in"]).clone().to(DEV)
+    d = {k: v.to(DEV) for k, v in bt.items()}
+    out_cat, out = m(x, d["mask"], t.to(DEV), d["given_objs"], d["given_cats"], y=d["text_features"], fps_starts=starts)
+    torch.cuda.synchronize()
+    nc = 27
+    for l, S_ in enumerate((1024, 256, 64, 16)):
+        assert torch.equal(ws(m, "fps_idx%d" % (l + 1), (nc, S_), torch.int32).long(), taps["sa%d.fps_idx" % (l + 1)])
+        assert torch.equal(ws(m, "ball%d" % (l + 1), (nc, S_, 32), torch.int32).long(), taps["sa%d.ball_idx" % (l + 1)])
+    if precision == "bf16x3":   # fp32 feature tensors
+        assert maxabs(ws(m, "feat4", (nc, 16, 512)), taps["sa4.new_points"]) <= tol_feat
+        assert maxabs(ws(m, "fp2", (nc, 1024, 128)), taps["fp2.out"]) <= tol_feat
+    assert maxabs(ws(m, "pcd", (3, 9, 3072)), taps["pcd"]) <= tol_feat
+    assert maxabs(out_cat, cat_o) <= 1e-6
+    assert maxabs(x, x_ref) <= tol_out and maxabs(out, out_o) <= tol_out
+    assert maxabs(m.saved_guiding_points, guid_o) <= tol_out
+    assert maxabs(x, T(g["x_mut"])) <= tol_out and maxabs(out, T(g["out"])) <= tol_out      # the real reference's outputs
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_bulk_p_sample_loop_vs_reference_golden(golden, precision):
+    """p_sample_loop on the fused path runs `chunk_steps` steps per library call with the RNG stream pre-drawn in the
+    reference's order; G4 (B=3, K=4 recorded from the reference) with chunks of 3 + 1 steps; both parity precisions."""
+    g = golden("g4_chain_b3")
+    B, C_, K, seed, bt_seed = [int(v) for v in g["meta"]]
+    m, diff = create_model_and_diffusion("proxd", max_cats=C_, precision=precision)
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C_))
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=bt_seed, max_cats=C_).items()}
+    torch.manual_seed(seed)
+    out = diff.p_sample_loop(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], clip_denoised=False,
+                             skip_timesteps=1000 - K, chunk_steps=3)
+    assert maxabs(out, T(g["samples"][-1])) <= 1e-3
+    assert maxabs(m.saved_cat, T(g["saved_cat"])) <= 1e-6
+    assert maxabs(m.saved_guiding_points, T(g["guiding"])) <= 1e-3
+    if precision == "f32":
+        # identical kernels, identical RNG stream: the chunked loop equals the per-step progressive loop bit for bit
+        torch.manual_seed(seed)
+        last = None
+        for o in diff.p_sample_loop_progressive(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"],
+                                                clip_denoised=False, skip_timesteps=1000 - K):
+            last = o["sample"]
+        assert maxabs(out, last) == 0.0
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_hoisted_conditioning_vs_pinned_reference_golden(golden, precision):
+    """scene conditioning evaluated once with the first step's FPS starts.  G6 was recorded from the real
+    reference with its per-forward FPS re-draw pinned (oracle/make_goldens.py::g6)."""
+    g = golden("g6_hoisted")
+    B, C_, K, seed, bt_seed = [int(v) for v in g["meta"]]
+    m, diff = create_model_and_diffusion("proxd", max_cats=C_, precision=precision)
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C_))
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=bt_seed, max_cats=C_).items()}
+    torch.manual_seed(seed)
+    out = diff.p_sample_loop(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], clip_denoised=False,
+                             skip_timesteps=1000 - K, hoist_conditioning=True, chunk_steps=K)
+    assert maxabs(out, T(g["samples"][-1])) <= 1e-3
+    assert maxabs(m.saved_guiding_points, T(g["guiding"])) <= 1e-3
+    # chunking re-evaluates the conditioning with the same pinned starts: same result
+    torch.manual_seed(seed)
+    out2 = diff.p_sample_loop(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], clip_denoised=False,
+                              skip_timesteps=1000 - K, hoist_conditioning=True, chunk_steps=3)
+    assert maxabs(out2, out) == 0.0
+
+
+def test_multi_step_call_is_deterministic(sd13):
+    """K steps in one library call (the bench path), repeated: bit-identical results (single stream; the experimental
+    two-stream overlap stays off, include/lsdm_hip.h)."""
+    B, K = 2, 4
+    m, diff = create_model_and_diffusion("proxd", precision="bf16x3")
+    m.load_state_dict(sd13)
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=12).items()}
+    res = []
+    for _ in range(3):
+        torch.manual_seed(8)
+        res.append(diff.p_sample_loop(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"],
+                                      clip_denoised=False, skip_timesteps=1000 - K, chunk_steps=K).clone())
+    assert maxabs(res[0], res[1]) == 0.0 and maxabs(res[0], res[2]) == 0.0
+
+
 def test_run_to_run_determinism(sd13):
     m, _ = create_model_and_diffusion("proxd")
     m.load_state_dict(sd13)

@@ -129,6 +129,22 @@ def test_g4_short_chain(golden, tag):
     assert maxabs(smp.saved_guiding_points, g["guiding"]) <= 1e-4
 
 
+def test_g6_hoisted_conditioning(golden):
+    """the oracle with pinned FPS starts against the reference run with its FPS re-draw pinned."""
+    g = golden("g6_hoisted")
+    B, C, K, seed, bt_seed = [int(v) for v in g["meta"]]
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
+    smp = cpu_ref.Sampler(sd)
+    got = []
+    torch.manual_seed(seed)
+    smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=1000 - K,
+                    hoist_conditioning=True, on_step=lambda i, o: got.append(o["sample"].clone()))
+    for k in range(K):
+        assert maxabs(got[k], g["samples"][k]) <= 1e-4, k
+    assert maxabs(smp.saved_guiding_points, g["guiding"]) <= 1e-4
+
+
 def test_g5_ddim50(golden):
     g = golden("g5_ddim50")
     B, C, K, seed, bt_seed = [int(v) for v in g["meta"]]
