@@ -2,18 +2,27 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one p_sample iteration (SceneDiffusionModel.forward + posterior update) of the whole per-GPU batch
-(B = 64 chains, 9 slots x 1024 points, C = 13, cosine T = 1000), i.e. BASELINE.json configs[2]'s shapes evaluated in
-fp32 like configs[1] -- the precision every parity test covers (a bf16 number would be a reduced-precision figure).
-Inputs, weights and the RNG draws of the timed steps (host generator, reference order) are resident in HBM before
-the timed region; the K steps run inside ONE C-ABI call (lsdm_sample_steps).  Ranks are independent chain batches
-(seed = base + rank); the only collective is one all-gather of the final samples.
+A "step" is one p_sample iteration (SceneDiffusionModel.forward + posterior update) of the whole per-GPU batch:
+BASELINE.json configs[2] -- B = 64 chains, 9 slots x 1024 points (8 objects = the 8192-pt scene cloud, + the human
+branch), C = 13, cosine T = 1000 -- with STRICT per-step recompute of everything the reference recomputes (PointNet++
+with freshly drawn FPS starts, conditioning MLPs).  Inputs, weights and the RNG draws of the timed steps (host
+generator, reference order) are resident in HBM before the timed region; the K steps run inside ONE C-ABI call
+(lsdm_sample_steps) on one stream.  Ranks are independent chain batches (seed = base + rank); the only
+collective is one all-gather of the final samples.
+
+dtype (--precision): "bf16x3" (default) = fp32 operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32
+accumulation -- fp32-class results that hold the same <= 1e-3 parity bar as the exact path (tests/test_hip_parity.py;
+the live check below reports max-abs vs the CPU oracle); "f32" = exact v_mfma_f32_32x32x2_f32; "bf16" = plain bf16
+products (reduced precision, configs[2]'s wording).  Geometry and sampler arithmetic are fp32 in every mode.  The other
+two precisions are timed briefly and reported under "other_precisions"; they never enter `value`.
 
 The JSON line also carries
-  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events on the launch stream, live in the timed
-                 region) against the dense fp32 MFMA peak, plus whole-step figures;
-  cpu_baseline : the CPU oracle (oracle/cpu_ref.py, the checker -- never the product) timed on this host's cores on a
-                 bounded sample of the same workload.
+  roofline     : the dominant kernel's algorithmic FLOP/s (HIP events on the launch stream, live in the timed region)
+                 against the dense MFMA peak of the dtype (bf16x3 issues 3 MFMAs per algorithmic product, so its
+                 attainable fraction of the bf16 peak is 1/3), plus whole-step figures and HBM traffic from the PMC pass;
+  hoisted_conditioning : separate figure for the pinned-FPS / conditioning-evaluated-once mode (SURVEY.md 8f-1);
+  parity       : max-abs of one B=2 step against the CPU oracle, same seeds;
+  cpu_baseline : the CPU oracle (oracle/cpu_ref.py, the checker -- never the product) timed on this host's cores.
 """
 import argparse
 import json
@@ -27,7 +36,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md: dense peaks.  f32-input MFMA 157.3 TF; bf16 MFMA 2.5 PF (never the 2:1-sparse figure)
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
 GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
 
 
@@ -57,6 +67,70 @@ def cpu_baseline(batch, steps, C):
                       "scaled to B=64 by /64" % (steps, batch, C, threads, os.cpu_count(), dt)}
 
 
+def parity_check(precision, dev):
+    """One p_sample step at B=2 through the product path vs the CPU oracle on the same seeds (the checker)."""
+    from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
+    from lsdm_amd.util.model_util import create_model_and_diffusion
+    from oracle import cpu_ref
+    sd = make_synthetic_state_dict(seed=0)
+    model, diffusion = create_model_and_diffusion("proxd", device=dev.index, precision=precision)
+    model.load_state_dict(sd)
+    bt = make_synthetic_batch(2, seed=3)
+    t = torch.tensor([900, 900])
+    torch.manual_seed(1)
+    x0 = torch.randn(2, 1024, 3)
+    torch.manual_seed(2)
+    ref = cpu_ref.Sampler(sd).p_sample(x0.clone(), bt["mask"], t, bt["given_objs"], bt["given_cats"], bt["text_features"])
+    d = {k: v.to(dev) for k, v in bt.items()}
+    torch.manual_seed(2)
+    out = diffusion.p_sample(model, x0.clone().to(dev), d["mask"], t.to(dev), d["given_objs"], d["given_cats"], d["text_features"],
+                             clip_denoised=False)
+    torch.cuda.synchronize()
+    return {"max_abs_sample": float((out["sample"].cpu() - ref["sample"]).abs().max()),
+            "max_abs_pred_xstart": float((out["pred_xstart"].cpu() - ref["pred_xstart"]).abs().max()),
+            "against": "CPU oracle (oracle/cpu_ref.py, pinned to goldens recorded from the reference), one p_sample step, B=2, t=900"}
+
+
+class Runner:
+    """Model + resident inputs + RNG streams of one precision; run(t_first, k0, k) = k steps in one C-ABI call."""
+
+    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev, pipeline):
+        from lsdm_amd import _lib
+        from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
+        from lsdm_amd.util.model_util import create_model_and_diffusion
+        self._lib = _lib
+        self.B, self.C = B, C
+        self.model, self.diffusion = create_model_and_diffusion("proxd", device=local_rank, precision=precision)
+        self.model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
+        self.ctx = self.model._context()
+        self.model._reserve(B)
+        self.ctx.call("lsdm_set_pipeline", 1 if pipeline else 0)
+        self.model._set_schedule((id(self.diffusion), self.diffusion.num_timesteps), self.diffusion._device_tables())
+        self.bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=seed, max_cats=C, num_objects=8).items()}
+        # RNG stream of the reference: x_T, then per step 4 FPS randints + randn (SURVEY.md H1), host generator
+        torch.manual_seed(seed)
+        x = torch.randn(B, 1024, 3)
+        starts, noise = [], []
+        for _ in range(n_steps):
+            starts.append(torch.stack([torch.randint(0, n, (B * 9,), dtype=torch.long) for n in (1024, 1024, 256, 64)]))
+            noise.append(torch.randn(B, 1024, 3))
+        self.x = x.to(dev).contiguous()
+        self.starts = torch.stack(starts).to(dev).contiguous()
+        self.noise = torch.stack(noise).to(dev).contiguous()
+        self.out_cat = torch.empty(B, 1, C, device=dev)
+        self.out_x0, self.out_g = torch.empty_like(self.x), torch.empty_like(self.x)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        self.T = self.diffusion.num_timesteps
+
+    def run(self, t_first, k0, k, hoisted=False, x=None, noise=None):
+        p = lambda v: v.data_ptr()
+        bt = self.bt
+        x = self.x if x is None else x
+        self.ctx.call("lsdm_sample_steps_hoisted" if hoisted else "lsdm_sample_steps", self._lib.MODE_P_SAMPLE, 0.0, self.B, t_first, k,
+                      p(x), p(bt["mask"]), p(bt["given_objs"]), p(bt["given_cats"]), p(bt["text_features"]), p(self.starts[k0]),
+                      p(self.noise[k0] if noise is None else noise), p(self.out_cat), p(self.out_x0), p(self.out_g), self.stream)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,10 +138,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense stacks (geometry and sampler arithmetic are always fp32)")
     ap.add_argument("--pipeline", action="store_true", help="EXPERIMENTAL two-stream overlap of front(k+1) with back(k); off: see include/lsdm_hip.h")
     ap.add_argument("--no-hoisted", action="store_true", help="skip the extra hoisted-conditioning measurement")
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs in the other two precisions")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -85,61 +161,34 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
 
-    from lsdm_amd import _lib
     from lsdm_amd.parallel import gather_samples
-    from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
-    from lsdm_amd.util.model_util import create_model_and_diffusion
 
     B, K, W, C = a.batch, a.steps, a.warmup, 13
-    model, diffusion = create_model_and_diffusion("proxd", device=local_rank, precision=a.precision)
-    model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
-    ctx = model._context()
-    model._reserve(B)
-    ctx.call("lsdm_set_pipeline", 1 if a.pipeline else 0)
-    model._set_schedule((id(diffusion), diffusion.num_timesteps), diffusion._device_tables())
-    bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=a.seed + rank, max_cats=C, num_objects=8).items()}
-    # RNG stream of the reference: x_T, then per step 4 FPS randints + randn, host generator
-    torch.manual_seed(a.seed + rank)
-    x = torch.randn(B, 1024, 3)
-    starts, noise = [], []
-    for _ in range(W + K):
-        starts.append(torch.stack([torch.randint(0, n, (B * 9,), dtype=torch.long) for n in (1024, 1024, 256, 64)]))
-        noise.append(torch.randn(B, 1024, 3))
-    x = x.to(dev).contiguous()
-    starts = torch.stack(starts).to(dev).contiguous()
-    noise = torch.stack(noise).to(dev).contiguous()
-    out_cat = torch.empty(B, 1, C, device=dev)
-    out_x0, out_g = torch.empty_like(x), torch.empty_like(x)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    p = lambda v: v.data_ptr()
-
-    def run(t_first, k0, k):
-        ctx.call("lsdm_sample_steps", _lib.MODE_P_SAMPLE, 0.0, B, t_first, k, p(x), p(bt["mask"]), p(bt["given_objs"]),
-                 p(bt["given_cats"]), p(bt["text_features"]), p(starts[k0]), p(noise[k0]), p(out_cat), p(out_x0), p(out_g), stream)
 
     def log(msg):
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    T = diffusion.num_timesteps
+    r = Runner(a.precision, B, C, W + K, a.seed + rank, local_rank, dev, a.pipeline)
+    T = r.T
     log("inputs resident; warm-up %d steps" % W)
     if W:
-        run(T - 1, 0, W)
+        r.run(T - 1, 0, W)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    log("timing %d steps" % K)
-    ctx.profile_begin()
+    log("timing %d steps (%s)" % (K, a.precision))
+    r.ctx.profile_begin()
     t0 = time.perf_counter()
-    run(T - 1 - W, W, K)
-    gathered = gather_samples(x, dist)          # the path's only collective (RCCL all-gather over xGMI)
+    r.run(T - 1 - W, W, K)
+    gathered = gather_samples(r.x, dist)          # the path's only collective (RCCL all-gather over xGMI)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_end()
+    prof = r.ctx.profile_end()
     log("timed region %.3f s" % dt)
     if dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -147,70 +196,102 @@ def main():
         dt = float(tmax)
     assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
 
+    if rank != 0:
+        dist.barrier()                 # rank 0 finishes its untimed reporting legs, then everyone tears down together
+        dist.destroy_process_group()
+        return
+
+    # ---- everything below: rank 0 only, outside the timed region ----------------------------------------------------
     # Separate, clearly labelled figure (never `value`): hoisted-conditioning mode -- FPS starts pinned,
-    # scene conditioning evaluated once per call, then K steps of embedding MLPs + fused denoiser/sampler update.
+    # scene conditioning evaluated once per call, then KH steps of embedding MLPs + fused denoiser/sampler update.
     hoisted = None
     if not a.no_hoisted:
-        KH = max(K, 50)
-        nh = noise[:1].expand(KH, -1, -1, -1).contiguous()      # any resident noise; values do not affect timing
-        xh = x.clone()
-
-        def run_h():
-            ctx.call("lsdm_sample_steps_hoisted", _lib.MODE_P_SAMPLE, 0.0, B, T - 1, KH, p(xh), p(bt["mask"]), p(bt["given_objs"]),
-                     p(bt["given_cats"]), p(bt["text_features"]), p(starts[0]), p(nh), p(out_cat), p(out_x0), p(out_g), stream)
-        run_h()
+        KH = max(K, 100)
+        nh = r.noise[:1].expand(KH, -1, -1, -1).contiguous()      # resident noise; values do not affect timing
+        xh = r.x.clone()
+        r.run(T - 1, 0, KH, hoisted=True, x=xh, noise=nh)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        run_h()
+        r.run(T - 1, 0, KH, hoisted=True, x=xh, noise=nh)
         torch.cuda.synchronize()
         dth = time.perf_counter() - t1
         hoisted = {"value": KH / dth, "unit": "denoising-steps/sec per GPU (B=%d)" % B, "steps": KH, "ms_per_step": dth / KH * 1e3,
+                   "dtype": a.precision,
                    "note": "NOT the headline metric: conditioning (human branch, PointNet++ geometry + dense stages, scene attention) "
                            "evaluated once per call with pinned FPS starts, included in the timed call; equals the reference only with "
                            "its per-step FPS re-draw pinned (tests: g6_hoisted golden)"}
 
-    if rank == 0:
-        units = {"ball": B * 9, "sa_": B * 9, "three": B * 9, "fp_k": B * 9, "fps": B * 9}
-        rows = []
-        for r in prof:
-            if r["launches"] == 0:
+    per_launch_units = lambda name: B * 9 if name[:4] in ("ball", "sa_k", "thre", "fp_k", "fps_") else B
+    rows = []
+    for pr in prof:
+        if pr["launches"] == 0:
+            continue
+        avg_ms = pr["total_ms"] / pr["launches"]
+        flops = 2.0 * pr["macs_per_unit"] * per_launch_units(pr["name"])
+        rows.append(dict(name=pr["name"], avg_ms=avg_ms, launches=pr["launches"],
+                         tflops=flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, gflop=flops / 1e9))
+    rows.sort(key=lambda q: -q["avg_ms"])
+    mfma_rows = [q for q in rows if q["gflop"] > 1.0]          # the dominant MFMA kernel (FPS etc. carry no matrix work)
+    dom = mfma_rows[0]
+    step_ms = dt / K * 1e3
+    peak = PEAK_TFLOPS[a.precision]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(a.precision, {}).get(dom["name"])
+    whole = GFLOP_PER_SAMPLE_STEP * B / step_ms
+    res = {
+        "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
+        "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch per GPU; value sums the GPUs)",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "sample_steps_per_s": world * B * K / dt,
+        "config": {"workload": "BASELINE configs[2]: B=%d chains/GPU, 8 objects + human x 1024 pts (8192-pt scene cloud), C=13, random CLIP-text "
+                               "features, cosine T=1000, p_sample steps t=%d..%d; strict per-step recompute incl. PointNet++ with "
+                               "host-replayed RNG; one stream" % (B, T - 1 - W, T - W - K),
+                   "global_batch": B * world, "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
+        "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                     "frac": dom["tflops"] / peak, "traffic": traffic, "avg_launch_ms": dom["avg_ms"],
+                     "algorithmic_gflop_per_launch": dom["gflop"],
+                     "peak_note": {"f32": "dense f32-input MFMA (v_mfma_f32_32x32x2_f32)",
+                                   "bf16x3": "dense bf16 MFMA; 3 MFMAs per algorithmic product -> attainable frac 0.333",
+                                   "bf16": "dense bf16 MFMA"}[a.precision],
+                     "whole_step": {"achieved": whole, "frac": whole / peak, "frac_of_f32_mfma_peak": whole / PEAK_TFLOPS["f32"],
+                                    "note": "14.58 GFLOP per sample-step (SURVEY.md 8d) x B / ms_per_step"},
+                     "kernels": [{"name": q["name"], "avg_ms": round(q["avg_ms"], 4), "tflops": round(q["tflops"], 2)} for q in rows]},
+    }
+    if hoisted:
+        res["hoisted_conditioning"] = hoisted
+    del r
+    torch.cuda.empty_cache()
+    if not a.no_others:
+        others = {}
+        for prec in ("f32", "bf16x3", "bf16"):
+            if prec == a.precision:
                 continue
-            per_launch_units = B * 9 if r["name"][:4] in ("ball", "sa_k", "thre", "fp_k", "fps_") else B
-            avg_ms = r["total_ms"] / r["launches"]
-            flops = 2.0 * r["macs_per_unit"] * per_launch_units
-            rows.append(dict(name=r["name"], avg_ms=avg_ms, launches=r["launches"], tflops=flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                             gflop=flops / 1e9))
-        rows.sort(key=lambda r: -r["avg_ms"])
-        dom = rows[0]
-        step_ms = dt / K * 1e3
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom["name"])
-        res = {
-            "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
-            "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch)",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "sample_steps_per_s": world * B * K / dt,
-            "config": {"workload": "BASELINE configs[2] shapes (B=%d chains/GPU, 8 objects + human x 1024 pts, C=13, cosine T=1000, "
-                                   "p_sample steps t=%d..%d) in fp32 (the parity-tested precision of configs[1]); strict per-step "
-                                   "recompute incl. PointNet++ with host-replayed RNG" % (B, T - 1 - W, T - W - K),
-                       "global_batch": B * world, "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "avg_launch_ms": dom["avg_ms"],
-                         "algorithmic_gflop_per_launch": dom["gflop"],
-                         "whole_step": {"achieved": GFLOP_PER_SAMPLE_STEP * B / step_ms, "frac": GFLOP_PER_SAMPLE_STEP * B / step_ms / PEAK_FP32_MFMA_TFLOPS,
-                                        "note": "14.58 GFLOP per sample-step (SURVEY.md 8d) x B / ms_per_step, TFLOP/s vs fp32 MFMA peak"},
-                         "kernels": [{"name": r["name"], "avg_ms": round(r["avg_ms"], 4), "tflops": round(r["tflops"], 2)} for r in rows]},
-        }
-        if hoisted:
-            res["hoisted_conditioning"] = hoisted
-        if not a.no_cpu_baseline:
-            log("cpu baseline (oracle) ...")
-            res["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, C)
-        print(json.dumps(res))
+            log("short run in %s" % prec)
+            ko = 6 if prec == "f32" else 10
+            ro = Runner(prec, B, C, 2 + ko, a.seed, local_rank, dev, False)
+            ro.run(ro.T - 1, 0, 2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ro.run(ro.T - 3, 2, ko)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            others[prec] = {"value": ko / d1, "ms_per_step": d1 / ko * 1e3, "steps": ko, "n_gpus": 1,
+                            "whole_step_tflops": GFLOP_PER_SAMPLE_STEP * B / (d1 / ko * 1e3)}
+            del ro
+            torch.cuda.empty_cache()
+        res["other_precisions"] = others
+    if not a.no_parity:
+        log("parity check vs the CPU oracle")
+        res["parity"] = parity_check(a.precision, dev)
+    if not a.no_cpu_baseline:
+        log("cpu baseline (oracle) ...")
+        res["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, C)
+    print(json.dumps(res), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

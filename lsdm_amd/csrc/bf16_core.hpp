@@ -68,34 +68,52 @@ __device__ __forceinline__ float lds_val(const __bf16* p, int plane) {
 //   X     : LDS hi plane, row 0 of the wave's first point block, k = x_kb_off*16 at column 0
 //   WA    : true  -> D[n][point]  (weights are the A operand)
 //           false -> D[point][n]  (activations are the A operand)
+// k-blocks are processed in groups of U; the next group's weight fragments are requested before the current group's MFMAs
+__host__ __device__ constexpr int kgroup(int nkb) { return nkb <= 5 ? nkb : (nkb % 4 == 0 ? 4 : (nkb % 3 == 0 ? 3 : 4)); }
+
+template <int NP, int U>
+struct WFrag {   // weight fragments of one k-group for one 32-channel block (hi [+ lo] planes)
+    bf16x8 h[U];
+    bf16x8 l[NP == 2 ? U : 1];
+};
+
+// request the FIRST k-group of (layer Wp with N channels, channel block cb) -- callable long before the K loop
+// (ahead of a gather, or before the previous layer's epilogue) so that its L2 latency is off the critical path
+template <int NP, int NKB>
+__device__ __forceinline__ void wfrag_load(WFrag<NP, kgroup(NKB)>& w, const __bf16* __restrict__ Wp, int N, int cb, int kb0, int lane) {
+    constexpr int U = kgroup(NKB);
+    const size_t ws = (size_t)N * NP * 16;
+    const __bf16* wp = Wp + ((size_t)(cb * 32 + (lane & 31)) * NP) * 16 + 8 * (lane >> 5) + (size_t)kb0 * ws;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        w.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws);
+        if constexpr (NP == 2) w.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws + 16);
+    }
+}
+
+// acc[rb] += X[rb-th 32-point block, NKB k-blocks from weight k-block kb0) (x) W(channels cb*32 .. +32)
+//   X     : LDS hi plane, row 0 of the wave's first point block, at the column of the first k-block
+//   w     : the first k-group, already requested with wfrag_load (clobbered)
+//   WA    : true  -> D[n][point]  (weights are the MFMA A operand);  false -> D[point][n]
 template <int RB, int NP, bool WA, int NKB>
-__device__ __forceinline__ void mma_kloop_h(f32x16 (&acc)[RB], const __bf16* X, int ldx, int plane, const __bf16* __restrict__ Wp,
-                                            int N, int cb, int kb0, int lane) {
-    // NKB k-blocks starting at weight k-block kb0; X points at the LDS column of the first of them.
-    // Loads are grouped U k-blocks at a time and the next group's weight fragments (L2, ~300+ cycles) are requested
-    // before the current group's MFMAs, so one wave keeps the matrix pipe fed through the short K loops of this path.
-    constexpr int U = NKB <= 5 ? NKB : (NKB % 4 == 0 ? 4 : (NKB % 3 == 0 ? 3 : 4));
+__device__ __forceinline__ void mma_kloop_pre_h(f32x16 (&acc)[RB], const __bf16* X, int ldx, int plane, const __bf16* __restrict__ Wp,
+                                                int N, int cb, int kb0, int lane, WFrag<NP, kgroup(NKB)>& w) {
+    constexpr int U = kgroup(NKB);
     constexpr int NG = NKB / U, TAIL = NKB % U;
     const int i = lane & 31, h = lane >> 5;
     const __bf16* xp = X + i * ldx + 8 * h;
     const size_t ws = (size_t)N * NP * 16;
     const __bf16* wp = Wp + ((size_t)(cb * 32 + i) * NP) * 16 + 8 * h + (size_t)kb0 * ws;
-    bf16x8 wh[U], wl[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        wh[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws);
-        if constexpr (NP == 2) wl[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws + 16);
-    }
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
         bf16x8 ch[U], cl[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { ch[u] = wh[u]; if constexpr (NP == 2) cl[u] = wl[u]; }
+        for (int u = 0; u < U; ++u) { ch[u] = w.h[u]; if constexpr (NP == 2) cl[u] = w.l[u]; }
         if (g + 1 < NG) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                wh[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws);
-                if constexpr (NP == 2) wl[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws + 16);
+                w.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws);
+                if constexpr (NP == 2) w.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws + 16);
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this group's MFMAs
@@ -126,7 +144,19 @@ __device__ __forceinline__ void mma_kloop_h(f32x16 (&acc)[RB], const __bf16* X, 
             }
         }
     }
-    if constexpr (TAIL > 0) mma_kloop_h<RB, NP, WA, TAIL>(acc, X + NG * U * 16, ldx, plane, Wp, N, cb, kb0 + NG * U, lane);
+    if constexpr (TAIL > 0) {
+        WFrag<NP, kgroup(TAIL)> wt;
+        wfrag_load<NP, TAIL>(wt, Wp, N, cb, kb0 + NG * U, lane);
+        mma_kloop_pre_h<RB, NP, WA, TAIL>(acc, X + NG * U * 16, ldx, plane, Wp, N, cb, kb0 + NG * U, lane, wt);
+    }
+}
+
+template <int RB, int NP, bool WA, int NKB>
+__device__ __forceinline__ void mma_kloop_h(f32x16 (&acc)[RB], const __bf16* X, int ldx, int plane, const __bf16* __restrict__ Wp,
+                                            int N, int cb, int kb0, int lane) {
+    WFrag<NP, kgroup(NKB)> w;
+    wfrag_load<NP, NKB>(w, Wp, N, cb, kb0, lane);
+    mma_kloop_pre_h<RB, NP, WA, NKB>(acc, X, ldx, plane, Wp, N, cb, kb0, lane, w);
 }
 
 template <int RB>
@@ -183,6 +213,35 @@ __device__ __forceinline__ void layer_lds_h(const __bf16* X, int ldx, int xplane
     const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
 #pragma unroll 1
     for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
+        f32x16 acc[TS::RB];
+        acc_zero_h(acc);
+        f32x4 bv[4];
+        load_bias_h(bv, L.b, cb, lane);
+        mma_kloop_h<TS::RB, NP, true, K / 16>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb, 0, lane);
+        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, bv, out, ldo, oplane, lane);
+    }
+}
+
+// Same layer with the first channel block's first k-group and bias already in flight (w0, bv0), and a hook that runs
+// between the first block's K loop and its epilogue -- the place to request the NEXT layer's first k-group, so that the
+// weight fetch of layer l+1 overlaps the epilogue + barrier of layer l.
+template <int NW, int TM, int K, int N, int ACT, int NP, class Hook>
+__device__ __forceinline__ void layer_lds_pre_h(const __bf16* X, int ldx, int xplane, DenseH L, __bf16* out, int ldo, int oplane,
+                                                WFrag<NP, kgroup(K / 16)>& w0, f32x4 (&bv0)[4], Hook&& hook) {
+    using TS = SplitH<NW, TM, N>;
+    static_assert(K % 16 == 0, "K must be padded to 16");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= NW) { hook(); return; }
+    const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
+    {
+        f32x16 acc[TS::RB];
+        acc_zero_h(acc);
+        mma_kloop_pre_h<TS::RB, NP, true, K / 16>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb0, 0, lane, w0);
+        hook();
+        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb0, bv0, out, ldo, oplane, lane);
+    }
+#pragma unroll 1
+    for (int cb = cb0 + TS::CSTEP; cb < TS::CB; cb += TS::CSTEP) {
         f32x16 acc[TS::RB];
         acc_zero_h(acc);
         f32x4 bv[4];

@@ -57,6 +57,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     const float* xyz = src_xyz + (size_t)c * NSRC * 3;
     const int* bl = ball + ((size_t)c * S + s0) * kNSample;
     const float* cen = new_xyz + ((size_t)c * S + s0) * 3;
+    // weight fetches are chained one layer ahead: layer 1's first k-group is requested before the gather, layer l+1's
+    // before layer l's epilogue
+    using T1 = SplitH<NW, TM, C1>;
+    using T2 = SplitH<NW, TM, C2>;
+    using T3 = SplitH<NW, TM, C3>;
+    const int wave_ = tid >> 6, lane_ = tid & 63;
+    WFrag<NP, kgroup(K0P / 16)> w1;
+    f32x4 b1[4];
+    wfrag_load<NP, K0P / 16>(w1, l1.w, C1, wave_ % T1::CSTEP, 0, lane_);
+    load_bias_h(b1, l1.b, wave_ % T1::CSTEP, lane_);
     [[maybe_unused]] constexpr int PS = (D == 3 ? 0 : D == 64 ? 8 : D == 128 ? 16 : 24);   // phase-timing slot base of this level
     PHASE_T0();
     if constexpr (D == 3) {
@@ -110,17 +120,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     PHASE_MARK(PS + 0);   // gather issued + written (this wave)
     __syncthreads();
     PHASE_MARK(PS + 1);   // barrier wait
-    layer_lds_h<NW, TM, K0P, C1, ACT_RELU, NP>(bufA, LDA, PA, l1, bufB, LDB, PB);
+    WFrag<NP, kgroup(C1 / 16)> w2;
+    f32x4 b2[4];
+    layer_lds_pre_h<NW, TM, K0P, C1, ACT_RELU, NP>(bufA, LDA, PA, l1, bufB, LDB, PB, w1, b1, [&]() {
+        wfrag_load<NP, C1 / 16>(w2, l2.w, C2, wave_ % T2::CSTEP, 0, lane_);
+        load_bias_h(b2, l2.b, wave_ % T2::CSTEP, lane_);
+    });
     PHASE_MARK(PS + 2);
     __syncthreads();
     PHASE_MARK(PS + 3);
-    layer_lds_h<NW, TM, C1, C2, ACT_RELU, NP>(bufB, LDB, PB, l2, bufA, LDA, PA);
+    WFrag<NP, kgroup(C2 / 16)> w3;
+    layer_lds_pre_h<NW, TM, C1, C2, ACT_RELU, NP>(bufB, LDB, PB, l2, bufA, LDA, PA, w2, b2,
+                                                   [&]() { wfrag_load<NP, C2 / 16>(w3, l3.w, C3, wave_ % T3::CSTEP, 0, lane_); });
     PHASE_MARK(PS + 4);
     __syncthreads();
     PHASE_MARK(PS + 5);
     // layer 3 in the direct orientation D[point][channel] + max over the 32 neighbours of each centroid
-    using TS = SplitH<NW, TM, C3>;
-    const int wave = tid >> 6, lane = tid & 63;
+    using TS = T3;
+    const int wave = wave_, lane = lane_;
     const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
 #pragma unroll 1
     for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
@@ -128,7 +145,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
         acc_zero_h(acc);
         const int col = cb * 32 + (lane & 31);
         const float bv = l3.b[col];
-        mma_kloop_h<TS::RB, NP, false, C2 / 16>(acc, bufA + rg * TS::RB * 32 * LDA, LDA, PA, l3.w, C3, cb, 0, lane);
+        if (cb == cb0) mma_kloop_pre_h<TS::RB, NP, false, C2 / 16>(acc, bufA + rg * TS::RB * 32 * LDA, LDA, PA, l3.w, C3, cb, 0, lane, w3);
+        else mma_kloop_h<TS::RB, NP, false, C2 / 16>(acc, bufA + rg * TS::RB * 32 * LDA, LDA, PA, l3.w, C3, cb, 0, lane);
 #pragma unroll
         for (int rb = 0; rb < TS::RB; ++rb) {
             float m = acc[rb][0];
