@@ -94,7 +94,7 @@ def parity_check(precision, dev):
 class Runner:
     """Model + resident inputs + RNG streams of one precision; run(t_first, k0, k) = k steps in one C-ABI call."""
 
-    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev, pipeline):
+    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev):
         from lsdm_amd import _lib
         from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
         from lsdm_amd.util.model_util import create_model_and_diffusion
@@ -104,7 +104,6 @@ class Runner:
         self.model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
         self.ctx = self.model._context()
         self.model._reserve(B)
-        self.ctx.call("lsdm_set_pipeline", 1 if pipeline else 0)
         self.model._set_schedule((id(self.diffusion), self.diffusion.num_timesteps), self.diffusion._device_tables())
         self.bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=seed, max_cats=C, num_objects=8).items()}
         # RNG stream of the reference: x_T, then per step 4 FPS randints + randn, host generator
@@ -140,7 +139,6 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense stacks (geometry and sampler arithmetic are always fp32)")
-    ap.add_argument("--pipeline", action="store_true", help="EXPERIMENTAL two-stream overlap of front(k+1) with back(k); off: see include/lsdm_hip.h")
     ap.add_argument("--no-hoisted", action="store_true", help="skip the extra hoisted-conditioning measurement")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs in the other two precisions")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the CPU oracle")
@@ -169,7 +167,7 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    r = Runner(a.precision, B, C, W + K, a.seed + rank, local_rank, dev, a.pipeline)
+    r = Runner(a.precision, B, C, W + K, a.seed + rank, local_rank, dev)
     T = r.T
     log("inputs resident; warm-up %d steps" % W)
     if W:
@@ -271,7 +269,7 @@ def main():
                 continue
             log("short run in %s" % prec)
             ko = 6 if prec == "f32" else 10
-            ro = Runner(prec, B, C, 2 + ko, a.seed, local_rank, dev, False)
+            ro = Runner(prec, B, C, 2 + ko, a.seed, local_rank, dev)
             ro.run(ro.T - 1, 0, 2)
             torch.cuda.synchronize()
             t1 = time.perf_counter()

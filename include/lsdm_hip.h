@@ -94,7 +94,9 @@ int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* 
               const float* noise, float* out_cat, float* out_x0, float* out_guiding, float* out_sample, void* stream);
 
 /* K consecutive ancestral steps t = t_first, t_first-1, ... with device-resident RNG draws; `x` ping-pongs with
- * an internal buffer and holds the final sample on return.  Replaces the loop body of
+ * an internal buffer and holds the final sample on return.  The x-independent PointNet++ geometry (FPS, ball queries,
+ * 3-NN) of up to 4 consecutive steps is evaluated in one launch per stage ahead of those steps; results are identical
+ * to K single-step calls.  Replaces the loop body of
  * p_sample_loop_progressive (gaussian_diffusion.py:736-759) for a fixed batch.
  *   fps_start_steps (K,4,B*9) int64 ; noise_steps (K,B,1024,3) */
 int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
@@ -110,13 +112,6 @@ int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, in
 int lsdm_sample_steps_hoisted(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
                               const float* given_objs, const float* given_cats, const float* text_feat, const int64_t* fps_start,
                               const float* noise_steps, float* out_cat, float* out_x0, float* out_guiding, void* stream);
-
-/* EXPERIMENTAL, default OFF: lsdm_sample_steps can overlap the x-independent front of step k+1 (conditioning vectors,
- * FPS / ball query / 3-NN) with the dense stages of step k on an internal second stream.  On MI355X / ROCm 7.2 the FPS
- * kernel was observed to return (rarely, ~1-10 % of launches) a different valid selection when it runs concurrently
- * with the bf16-MFMA dense kernels of another queue -- also in an LDS-free, single-wave form, and never with the f32-MFMA
- * kernels or on one stream (tools/race_fps.py).  The cause was not found, so no reported number uses this mode. */
-int lsdm_set_pipeline(lsdm_ctx* ctx, int enable);
 
 /* ---- stage entry points (parity tests against the oracle's taps; same kernels the hot path launches) -------- */
 /* farthest_point_sample x4 chained (pointnet2_utils.py:60-81): idx_l (num_clouds,S_l) int32, xyz_l (num_clouds,S_l,3),

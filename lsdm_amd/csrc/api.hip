@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.hpp"
@@ -58,8 +59,10 @@ struct lsdm_ctx {
     int cap_B = 0;
     std::vector<void*> ws_allocs;
     std::map<std::string, std::pair<void*, int64_t>> ws_named;
-    // Everything a step computes WITHOUT x (conditioning vectors + PointNet++ geometry) lives in a FrontSet; there are
-    // two so that the front of step k+1 can run on the auxiliary stream while the dense stages of step k read set k&1.
+    // Everything a step computes WITHOUT x (conditioning vectors + PointNet++ geometry) lives in a FrontSet.  There are
+    // kGroup of them, carved out of contiguous allocations [kGroup][...], so that lsdm_sample_steps can evaluate the
+    // geometry of up to kGroup consecutive steps in ONE launch per stage (the fronts do not depend on x or on each other).
+    static constexpr int kGroup = 4;
     struct FrontSet {
         int* idx[4] = {};
         float* xyz[4] = {};
@@ -68,21 +71,15 @@ struct lsdm_ctx {
         float* nn_w[4] = {};
         float *e0 = nullptr, *tr = nullptr, *w = nullptr, *h2p = nullptr;
         int64_t* tbuf = nullptr;
-    } fs[2];
+    } fs[kGroup];
     float* feat[4] = {};
     float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
     float *hm = nullptr, *o12 = nullptr, *xs = nullptr;
-    bool pipeline = false;            // lsdm_sample_steps: overlap front(k+1) with back(k) on two streams (see lsdm_set_pipeline)
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr;
-    std::vector<hipEvent_t> ev_front, ev_back;   // one pair per step of a call (never re-recorded while a wait may be pending)
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-phase marker)
-    std::vector<int> prof_st;   // stream the event was recorded on (0 = caller's, 1 = auxiliary)
     size_t prof_cur = 0;
-    int prof_stream = 0;
 };
 
 namespace {
@@ -124,10 +121,8 @@ void prof_mark(lsdm_ctx* c, int id, hipStream_t st) {
         if (hipEventCreate(&e) != hipSuccess) { c->prof_on = false; return; }
         c->prof_ev.push_back(e);
         c->prof_id.push_back(id);
-        c->prof_st.push_back(0);
     }
     c->prof_id[c->prof_cur] = id;
-    c->prof_st[c->prof_cur] = c->prof_stream;
     (void)hipEventRecord(c->prof_ev[c->prof_cur++], st);
 }
 
@@ -281,26 +276,30 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
 // geometry + dense stages of get_backbone.forward on `num_clouds` clouds
 typedef lsdm_ctx::FrontSet FrontSet;
 
-// PointNet++ geometry of `nc` clouds into a front set: FPS chain, 4 ball queries, 4 three-NN searches (x-independent)
-void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, hipStream_t st) {
+// PointNet++ geometry of `g` consecutive steps x `nc` clouds into front sets f, f+1, ..., f+g-1 (contiguous memory):
+// FPS chain, 4 ball queries, 4 three-NN searches -- one launch each for the whole group (x-independent work).
+// `starts` is the (g,4,nc) slice of the per-step start draws.
+void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, int g, hipStream_t st) {
+    const int tot = nc * g;
     prof_mark(c, K_FPS, st);
-    launch_fps_chain(clouds, starts, nc, f.idx, f.xyz, st);
+    launch_fps_chain(clouds, starts, tot, nc, f.idx, f.xyz, st);
     const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
     for (int l = 0; l < 4; ++l) {
         // radius ** 2 is a double in the reference and is compared against fp32 distances (Q13)
         const float r2 = (float)(kRadius[l] * kRadius[l]);
         prof_mark(c, K_BALL1 + l, st);
-        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], nc, kSrcN[l], kS[l], r2, f.ball[l], st);
+        launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], tot, kSrcN[l], kS[l], r2, f.ball[l], l == 0 ? nc : 0, st);
     }
     // fp4: l3 <- l4 ; fp3: l2 <- l3 ; fp2: l1 <- l2 ; fp1: l0 <- l1
     prof_mark(c, K_NN4, st);
-    launch_three_nn(f.xyz[2], f.xyz[3], nc, 64, 16, f.nn_idx[0], f.nn_w[0], st);
+    launch_three_nn(f.xyz[2], f.xyz[3], tot, 64, 16, f.nn_idx[0], f.nn_w[0], 0, st);
     prof_mark(c, K_NN3, st);
-    launch_three_nn(f.xyz[1], f.xyz[2], nc, 256, 64, f.nn_idx[1], f.nn_w[1], st);
+    launch_three_nn(f.xyz[1], f.xyz[2], tot, 256, 64, f.nn_idx[1], f.nn_w[1], 0, st);
     prof_mark(c, K_NN2, st);
-    launch_three_nn(f.xyz[0], f.xyz[1], nc, 1024, 256, f.nn_idx[2], f.nn_w[2], st);
+    launch_three_nn(f.xyz[0], f.xyz[1], tot, 1024, 256, f.nn_idx[2], f.nn_w[2], 0, st);
     prof_mark(c, K_NN1, st);
-    launch_three_nn(clouds, f.xyz[0], nc, 1024, 1024, f.nn_idx[3], f.nn_w[3], st);
+    launch_three_nn(clouds, f.xyz[0], tot, 1024, 1024, f.nn_idx[3], f.nn_w[3], nc, st);
+    prof_mark(c, -1, st);
 }
 
 // dense stages of get_backbone.forward (4 x SA, 4 x FP + head) on the geometry of a front set
@@ -331,37 +330,32 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
     fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
-    const int sync_after = getenv("LSDM_SYNC_AFTER") ? atoi(getenv("LSDM_SYNC_AFTER")) : 0;   // debug bisect
     for (int l = 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
         launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
-        if (sync_after == l + 1) (void)hipStreamSynchronize(st);
     }
     const Lin head2{c->head[1].w, c->head[1].b};
     prof_mark(c, K_FP4, st);
     launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
-    if (sync_after == 5) (void)hipStreamSynchronize(st);
     prof_mark(c, K_FP3, st);
     launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
-    if (sync_after == 6) (void)hipStreamSynchronize(st);
     prof_mark(c, K_FP2, st);
     launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
-    if (sync_after == 7) (void)hipStreamSynchronize(st);
     prof_mark(c, K_FP1, st);
     launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
 }
 
 int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
-    run_geometry(c, c->fs[0], clouds, starts, nc, st);
+    run_geometry(c, c->fs[0], clouds, starts, nc, 1, st);
     run_encoder_dense(c, c->fs[0], clouds, nc, out, st);
     return check_launch(c, "scene encoder");
 }
 
 // FRONT of a step: everything that does not read x -- conditioning vectors, up-sampling layers 1-2, the human branch
-// (given_objs only: evaluated once per multi-step call) and the PointNet++ geometry.
+// (given_objs only: evaluated once per multi-step call) and, unless the caller batched it for a group of steps
+// (with_geometry = false), the PointNet++ geometry.
 void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_objs, const float* given_cats,
-               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st, hipStream_t geo_st = nullptr,
-               bool split = false) {
+               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st, bool with_geometry = true) {
     prof_mark(c, K_COND, st);
     launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
     prof_mark(c, K_UP12, st);
@@ -370,18 +364,15 @@ void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* m
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->hm, st);
     }
-    run_geometry(c, f, given_objs, starts, B * kO, split ? geo_st : st);
     prof_mark(c, -1, st);
+    if (with_geometry) run_geometry(c, f, given_objs, starts, B * kO, 1, st);
 }
 
 // conditioning that depends on the scene only: dense encoder stages + collapsed scene attention (needs f.w, f.tr)
 void run_scene_conditioning(lsdm_ctx* c, const FrontSet& f, int B, const float* given_objs, hipStream_t st) {
-    const int dbg = getenv("LSDM_PIPE_DEBUG") ? atoi(getenv("LSDM_PIPE_DEBUG")) : 0;
     run_encoder_dense(c, f, given_objs, B * kO, c->pcd, st);
-    if (dbg & 4) (void)hipStreamSynchronize(st);
     prof_mark(c, K_SATTN, st);
     launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
-    if (dbg & 8) (void)hipStreamSynchronize(st);
 }
 
 // the fused per-point denoiser + sampler update (the only stage that reads x)
@@ -454,12 +445,6 @@ int lsdm_destroy(lsdm_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->ws_allocs) (void)hipFree(p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    if (c->aux) {
-        (void)hipStreamDestroy(c->aux);
-        (void)hipEventDestroy(c->ev_fork);
-        for (hipEvent_t e : c->ev_front) (void)hipEventDestroy(e);
-        for (hipEvent_t e : c->ev_back) (void)hipEventDestroy(e);
-    }
     delete c;
     return LSDM_OK;
 }
@@ -688,20 +673,32 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
     for (int l = 0; l < 4 && ok; ++l)
         ok = (c->feat[l] = ws_alloc<float>(c, (std::string("feat") + lv[l]).c_str(), nc * kS[l] * kFeatC[l])) != nullptr;
     const int nn_n[4] = {64, 256, 1024, 1024};
-    for (int s = 0; s < 2 && ok; ++s) {
-        // set 0 keeps the plain names (parity tests read them after single-step calls); set 1 is suffixed
-        lsdm_ctx::FrontSet& f = c->fs[s];
-        const std::string sx = s == 0 ? "" : "_b";
+    {
+        // front sets: one allocation per tensor, [kGroup][...]; set 0 carries the plain workspace names (the parity
+        // tests read them after single-step calls), the views of sets 1.. are registered with a "_g<j>" suffix
+        constexpr int G = lsdm_ctx::kGroup;
+        auto grouped = [&](const std::string& name, size_t per_set, auto** slot0, size_t elem) -> bool {
+            typedef typename std::remove_pointer<typename std::remove_pointer<decltype(slot0)>::type>::type T;
+            T* base = ws_alloc<T>(c, name.c_str(), per_set * G);
+            if (!base) return false;
+            c->ws_named[name] = {base, (int64_t)per_set};
+            for (int j = 0; j < G; ++j) {
+                T** slot = reinterpret_cast<T**>(reinterpret_cast<char*>(slot0) + (size_t)j * sizeof(lsdm_ctx::FrontSet));
+                *slot = base + (size_t)j * per_set;
+                if (j > 0) c->ws_named[name + "_g" + std::to_string(j)] = {*slot, (int64_t)per_set};
+            }
+            (void)elem;
+            return true;
+        };
+        lsdm_ctx::FrontSet& f0 = c->fs[0];
         for (int l = 0; l < 4 && ok; ++l) {
-            ok = (f.idx[l] = ws_alloc<int>(c, (std::string("fps_idx") + lv[l] + sx).c_str(), nc * kS[l])) &&
-                 (f.xyz[l] = ws_alloc<float>(c, (std::string("xyz") + lv[l] + sx).c_str(), nc * kS[l] * 3)) &&
-                 (f.ball[l] = ws_alloc<int>(c, (std::string("ball") + lv[l] + sx).c_str(), nc * kS[l] * 32)) &&
-                 (f.nn_idx[l] = ws_alloc<int>(c, (std::string("nn_idx") + lv[l] + sx).c_str(), nc * nn_n[l] * 3)) &&
-                 (f.nn_w[l] = ws_alloc<float>(c, (std::string("nn_w") + lv[l] + sx).c_str(), nc * nn_n[l] * 3));
+            ok = grouped(std::string("fps_idx") + lv[l], nc * kS[l], &f0.idx[l], 4) && grouped(std::string("xyz") + lv[l], nc * kS[l] * 3, &f0.xyz[l], 4) &&
+                 grouped(std::string("ball") + lv[l], nc * kS[l] * 32, &f0.ball[l], 4) &&
+                 grouped(std::string("nn_idx") + lv[l], nc * nn_n[l] * 3, &f0.nn_idx[l], 4) &&
+                 grouped(std::string("nn_w") + lv[l], nc * nn_n[l] * 3, &f0.nn_w[l], 4);
         }
-        ok = ok && (f.e0 = ws_alloc<float>(c, ("e0" + sx).c_str(), (size_t)B * 256)) && (f.tr = ws_alloc<float>(c, ("tr" + sx).c_str(), nc * 12)) &&
-             (f.w = ws_alloc<float>(c, ("w" + sx).c_str(), nc)) && (f.h2p = ws_alloc<float>(c, ("h2p" + sx).c_str(), (size_t)B * 256 * 512)) &&
-             (f.tbuf = ws_alloc<int64_t>(c, ("tbuf" + sx).c_str(), (size_t)B));
+        ok = ok && grouped("e0", (size_t)B * 256, &f0.e0, 4) && grouped("tr", nc * 12, &f0.tr, 4) && grouped("w", nc, &f0.w, 4) &&
+             grouped("h2p", (size_t)B * 256 * 512, &f0.h2p, 4) && grouped("tbuf", (size_t)B, &f0.tbuf, 8);
     }
     ok = ok && (c->fpo4 = ws_alloc<float>(c, "fp4", nc * 64 * 256)) && (c->fpo3 = ws_alloc<float>(c, "fp3", nc * 256 * 256)) &&
          (c->fpo2 = ws_alloc<float>(c, "fp2", nc * 1024 * 128)) && (c->pcd = ws_alloc<float>(c, "pcd", nc * kN * 3)) &&
@@ -747,56 +744,23 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     float* cur = x;
     float* nxt = c->xs;
     const size_t xn = (size_t)B * kN * 3;
-    const bool piped = c->pipeline && K > 1;
-    if (piped && !c->aux) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    }
-    while (piped && (int)c->ev_front.size() < K) {
-        hipEvent_t a = nullptr, b = nullptr;
-        HIP_TRY(c, hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        c->ev_front.push_back(a);
-        c->ev_back.push_back(b);
-    }
-    // The front of a step (conditioning + geometry) reads neither x nor the previous step's results, so front(k+1) runs
-    // on the auxiliary stream while the dense stages of step k occupy the matrix cores; the only serial chain left is
-    // back(k) -> back(k+1) through x.  Front sets alternate; front(k+2) waits for back(k) to release its set.
-    hipStream_t fst = piped ? c->aux : st;
-    if (piped) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, st));
-        HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-    }
-    c->prof_stream = piped ? 1 : 0;
-    const int dbg = getenv("LSDM_PIPE_DEBUG") ? atoi(getenv("LSDM_PIPE_DEBUG")) : 0;
-    auto front = [&](int k) {
-        lsdm_ctx::FrontSet& f = c->fs[piped ? (k & 1) : 0];
-        hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, fst, f.tbuf, (int64_t)(t_first - k), B);
-        const bool split = piped && (dbg & 16);   // debug: geometry on the caller's stream, only cond/up12 on aux
-        run_front(c, f, B, f.tbuf, mask, given_objs, given_cats, text, starts + (size_t)k * 4 * B * kO, out_cat, /*reuse_hm=*/k > 0, fst, st,
-                  split);
-    };
-    for (int k = 0; k < K; ++k) {
-        const int s = piped ? (k & 1) : 0;
-        if (piped) {
-            c->prof_stream = 1;
-            if (k >= 2) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->ev_back[k - 2], 0));
-            front(k);
-            HIP_TRY(c, hipEventRecord(c->ev_front[k], c->aux));
-            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_front[k], 0));
-            if (dbg & 1) HIP_TRY(c, hipStreamSynchronize(c->aux));
-            c->prof_stream = 0;
-        } else {
-            front(k);
+    const int nc = B * kO;
+    // Steps are processed in groups of up to kGroup: the geometry of the whole group (it reads neither x nor anything a
+    // step produces) is evaluated first, one launch per stage over group x B x 9 clouds, then the steps run in order.
+    for (int k0 = 0; k0 < K; k0 += lsdm_ctx::kGroup) {
+        const int g = K - k0 < lsdm_ctx::kGroup ? K - k0 : lsdm_ctx::kGroup;
+        run_geometry(c, c->fs[0], given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st);
+        for (int j = 0; j < g; ++j) {
+            const int k = k0 + j;
+            lsdm_ctx::FrontSet& f = c->fs[j];
+            hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f.tbuf, (int64_t)(t_first - k), B);
+            run_front(c, f, B, f.tbuf, mask, given_objs, given_cats, text, nullptr, out_cat, /*reuse_hm=*/k > 0, st, /*with_geometry=*/false);
+            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
+            rc = check_launch(c, "sample step");
+            if (rc) return rc;
+            float* tmp = cur; cur = nxt; nxt = tmp;
         }
-        run_back(c, c->fs[s], mode, eta, B, cur, c->fs[s].tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
-        if (piped) HIP_TRY(c, hipEventRecord(c->ev_back[k], st));
-        if (dbg & 2) HIP_TRY(c, hipStreamSynchronize(st));
-        rc = check_launch(c, "sample step");
-        if (rc) return rc;
-        float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    c->prof_stream = 0;
     if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
     return LSDM_OK;
 }
@@ -835,19 +799,13 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
     return LSDM_OK;
 }
 
-int lsdm_set_pipeline(lsdm_ctx* c, int enable) {
-    if (!c) return LSDM_ERR_ARG;
-    c->pipeline = enable != 0;
-    return LSDM_OK;
-}
-
 int lsdm_fps(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, int32_t* i1, int32_t* i2, int32_t* i3, int32_t* i4,
              float* x1, float* x2, float* x3, float* x4, void* stream) {
     if (!c || !clouds || !starts || nc <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_fps: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     int* idx[4] = {i1, i2, i3, i4};
     float* xyz[4] = {x1, x2, x3, x4};
-    launch_fps_chain(clouds, starts, nc, idx, xyz, static_cast<hipStream_t>(stream));
+    launch_fps_chain(clouds, starts, nc, nc, idx, xyz, static_cast<hipStream_t>(stream));
     return check_launch(c, "fps");
 }
 
@@ -856,7 +814,7 @@ int lsdm_ball_query(lsdm_ctx* c, const float* xyz, const float* new_xyz, int nc,
     if (N != 1024 && N != 256 && N != 64) return fail(c, LSDM_ERR_ARG, "lsdm_ball_query: N must be 1024, 256 or 64");
     HIP_TRY(c, hipSetDevice(c->device));
     const float r2 = (float)(radius * radius);
-    launch_ball_query(xyz, new_xyz, nc, N, S, r2, out, static_cast<hipStream_t>(stream));
+    launch_ball_query(xyz, new_xyz, nc, N, S, r2, out, 0, static_cast<hipStream_t>(stream));
     return check_launch(c, "ball_query");
 }
 
@@ -864,7 +822,7 @@ int lsdm_three_nn(lsdm_ctx* c, const float* fine, const float* coarse, int nc, i
     if (!c || !fine || !coarse || !idx || !w || nc <= 0 || N <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_three_nn: bad argument");
     if (S != 1024 && S != 256 && S != 64 && S != 16) return fail(c, LSDM_ERR_ARG, "lsdm_three_nn: S must be 1024, 256, 64 or 16");
     HIP_TRY(c, hipSetDevice(c->device));
-    launch_three_nn(fine, coarse, nc, N, S, idx, w, static_cast<hipStream_t>(stream));
+    launch_three_nn(fine, coarse, nc, N, S, idx, w, 0, static_cast<hipStream_t>(stream));
     return check_launch(c, "three_nn");
 }
 
@@ -897,15 +855,11 @@ int lsdm_profile_end(lsdm_ctx* c, int capacity, double* total_ms, int64_t* launc
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     for (int k = 0; k < K_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; if (macs_per_unit) macs_per_unit[k] = kKernelMacs[k]; }
-    // an interval runs from an event to the next event recorded on the SAME stream
     for (size_t i = 0; i + 1 < c->prof_cur; ++i) {
         const int id = c->prof_id[i];
         if (id < 0) continue;
-        size_t j = i + 1;
-        while (j < c->prof_cur && c->prof_st[j] != c->prof_st[i]) ++j;
-        if (j >= c->prof_cur) continue;
         float ms = 0.0f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[j]));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
         total_ms[id] += ms;
         launches[id] += 1;
     }

@@ -72,9 +72,13 @@ struct StepCoefs {  // per-timestep fp32 tables (gathered by t inside the kernel
 enum StepMode { MODE_FORWARD = 0, MODE_P_SAMPLE = 1, MODE_DDIM = 2 };
 
 // geometry.hip
-void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int* const idx[4], float* const xyz[4], hipStream_t st);
-void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, hipStream_t st);
-void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, hipStream_t st);
+// num_clouds = clouds of the launch; nc_step = clouds per step (num_clouds = G * nc_step for a G-step geometry batch);
+// src_mod / fine_mod = nc_step when the operand is the level-0 input cloud (shared by the steps), else 0
+void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],
+                      hipStream_t st);
+void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod, hipStream_t st);
+void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,
+                     hipStream_t st);
 // encoder.hip
 void launch_sa(int level, int num_clouds, const float* src_xyz, const float* src_feat, const float* new_xyz, const int* ball,
                const Dense* l, float* out, hipStream_t st);

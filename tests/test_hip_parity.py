@@ -121,6 +121,31 @@ def test_fps_ball_threenn_index_exact(model13, sd13, golden):
         assert maxabs(ow[keep], taps[name + ".nn_w"][keep]) <= 1e-6, name
 
 
+def test_fps_one_wave_per_cloud_form_index_exact(model13, sd13):
+    """Launches of >= 1024 clouds (the geometry of several steps batched into one launch) run FPS with one wave per cloud;
+    same selections as the oracle, including the degenerate all-zero cloud."""
+    ctx = model13._ctx
+    base = _clouds()
+    reps = 231                                   # 5 x 231 = 1155 clouds
+    clouds = base.repeat(reps, 1, 1)
+    nc = clouds.shape[0]
+    torch.manual_seed(33)
+    starts5 = cpu_ref.draw_fps_starts(5)
+    taps = {}
+    cpu_ref.scene_encoder(sd13, base, starts5, taps)
+    starts = torch.stack([s.repeat(reps) for s in starts5])
+    d_clouds, d_starts = clouds.to(DEV).contiguous(), starts.to(DEV).contiguous()
+    S = (1024, 256, 64, 16)
+    idx = [torch.empty(nc, s, dtype=torch.int32, device=DEV) for s in S]
+    xyz = [torch.empty(nc, s, 3, device=DEV) for s in S]
+    ctx.call("lsdm_fps", d_clouds.data_ptr(), d_starts.data_ptr(), nc, *[i.data_ptr() for i in idx], *[x.data_ptr() for x in xyz], None)
+    torch.cuda.synchronize()
+    for l in range(4):
+        want = taps["sa%d.fps_idx" % (l + 1)].repeat(reps, 1)
+        assert torch.equal(idx[l].cpu().long(), want), l
+        assert maxabs(xyz[l], taps["sa%d.new_xyz" % (l + 1)].repeat(reps, 1, 1)) == 0.0
+
+
 def test_geometry_matches_reference_goldens(model13, golden):
     """G3: indices recorded from the real reference's farthest_point_sample / query_ball_point."""
     g = golden("g3_pointnet")
@@ -285,6 +310,49 @@ def test_ddim50_vs_reference_golden(golden):
                                bt["text_features"], clip_denoised=False)
         img = out["sample"]
         assert maxabs(img, T(g["samples"][k])) <= 1e-3, k
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_humanise_two_prompts_ddim250_vs_oracle(precision):
+    """BASELINE configs[4] shapes: get_default_model_humanise (C = 11), N = 1024, two prompts per scene (= two chains that
+    share given_objs and differ in the text feature), 'ddim250' (stride 4, Q8: the model sees the respaced index)."""
+    C_, K = 11, 3
+    sd = make_synthetic_state_dict(seed=0, max_cats=C_)
+    m, _ = create_model_and_diffusion("humanise", precision=precision)
+    assert m.max_cats == C_
+    m.load_state_dict(sd)
+    diff = create_gaussian_diffusion(get_default_diffusion(), timestep_respacing="ddim250")
+    assert diff.num_timesteps == 250
+    one = make_synthetic_batch(1, seed=31, max_cats=C_)
+    bt = {k: v.repeat(2, *([1] * (v.dim() - 1))).contiguous() for k, v in one.items()}
+    bt["text_features"] = make_synthetic_batch(2, seed=32, max_cats=C_)["text_features"]      # 2 prompts, same scene
+    smp = cpu_ref.Sampler(sd, timestep_respacing="ddim250")
+    torch.manual_seed(9)
+    ref = smp.sample_loop([2, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=250 - K,
+                          use_ddim=True)
+    d = {k: v.to(DEV) for k, v in bt.items()}
+    torch.manual_seed(9)
+    out = diff.ddim_sample_loop(m, [2, 1024, 3], d["mask"], d["given_objs"], d["given_cats"], d["text_features"], clip_denoised=False,
+                                skip_timesteps=250 - K)
+    assert maxabs(out, ref) <= 1e-3
+    assert maxabs(m.saved_guiding_points, smp.saved_guiding_points) <= 1e-3
+    assert maxabs(m.saved_cat, smp.saved_cat) <= 1e-6
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_config2_b16_c43_chain_vs_reference_golden(golden, precision):
+    """BASELINE configs[1]: B = 16, 43 classes, p_sample_loop; the last of K = 2 steps recorded from the real reference."""
+    g = golden("g4_chain_b16c43")
+    B, C_, K, seed, bt_seed = [int(v) for v in g["meta"]]
+    m, diff = create_model_and_diffusion("proxd", max_cats=C_, precision=precision)
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C_))
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=bt_seed, max_cats=C_).items()}
+    torch.manual_seed(seed)
+    out = diff.p_sample_loop(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], clip_denoised=False,
+                             skip_timesteps=1000 - K)
+    assert maxabs(out, T(g["samples"][-1])) <= 1e-3
+    assert maxabs(m.saved_cat, T(g["saved_cat"])) <= 1e-6
+    assert maxabs(m.saved_guiding_points, T(g["guiding"])) <= 1e-3
 
 
 def test_sample_steps_entry_point_equals_python_loop(sd13):

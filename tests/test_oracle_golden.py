@@ -110,6 +110,20 @@ def test_g3_square_distance_rounding(golden):
 
 
 # ---------------------------------------------------------------- G4
+def test_g4_config2_b16_c43(golden):
+    """BASELINE configs[1] shapes (B = 16, 43 classes): last of K = 2 steps recorded from the real reference."""
+    g = golden("g4_chain_b16c43")
+    B, C, K, seed, bt_seed = [int(v) for v in g["meta"]]
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
+    smp = cpu_ref.Sampler(sd)
+    torch.manual_seed(seed)
+    final = smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=1000 - K)
+    assert maxabs(final, g["samples"][-1]) <= 1e-4
+    assert maxabs(smp.saved_cat, g["saved_cat"]) <= 1e-6
+    assert maxabs(smp.saved_guiding_points, g["guiding"]) <= 1e-4
+
+
 @pytest.mark.parametrize("tag", ["b1", "b3"])
 def test_g4_short_chain(golden, tag):
     g = golden("g4_chain_%s" % tag)
