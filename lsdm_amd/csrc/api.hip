@@ -44,6 +44,8 @@ struct lsdm_ctx {
     Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
     int prec = LSDM_PREC_F32;           // arithmetic of the dense layers (lsdm_set_precision)
     DenseH sa_h[4][3], fp_h[4][3], head_h[1];  // split-bf16 operands of the same layers (prec != F32)
+    bool sa_reg = getenv("LSDM_SA_REG") ? atoi(getenv("LSDM_SA_REG")) != 0 : true;   // debug switch: sa1/sa2 kernel form
+    DenseH sa_r[3];                     // sa1 / sa2 as LDS-resident fragment blobs of the register-chained kernel (encoder_reg.hip)
     void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
     void* fpo_b[3] = {};
     CondParams cond{};
@@ -223,6 +225,50 @@ bool fold_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname,
     return true;
 }
 
+// Fragment blob of the register-chained SA kernel (encoder_reg.hip) for one level: three layers, each as
+// [nb = n/32][k-step s][plane][lane = n%32 + 32*h][8] bf16 with k-slot (s, h, j) -> input channel
+//   layer 1 : 16*s + 8*h + j in the kernel's K order [features (D) || xyz - centroid (3) || 0]
+//   layer 2,3: 32*(s/2) + 8*(2*(s%2) + j/4) + 4*h + j%4  -- the channels a lane owns in accumulator registers
+//              8*(s%2) .. 8*(s%2)+7 of block s/2 of the previous layer's transposed product
+// followed (separately) by the fp32 biases [b1 | b2 | b3], BatchNorm folded.
+bool build_sa_reg_blob(lsdm_ctx* c, const std::string& prefix, int D, const int (&mlp)[3], int np, DenseH* out) {
+    std::vector<uint16_t> blob;
+    std::vector<float> biases;
+    int K = D + 3;
+    for (int li = 0; li < 3; ++li) {
+        const int N = mlp[li];
+        std::vector<float> W, Bv;
+        if (!fold_dense(c, prefix + ".mlp_convs." + std::to_string(li) + ".weight", prefix + ".mlp_convs." + std::to_string(li) + ".bias",
+                        prefix + ".mlp_bns." + std::to_string(li), N, K, W, Bv))
+            return false;
+        const int KS = li == 0 ? (D == 3 ? 1 : (D + 16) / 16) : K / 16;
+        for (int nb = 0; nb < N / 32; ++nb)
+            for (int s = 0; s < KS; ++s)
+                for (int pl = 0; pl < np; ++pl)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = nb * 32 + (lane & 31), h = lane >> 5;
+                            float v = 0.0f;
+                            if (li == 0) {
+                                const int k = 16 * s + 8 * h + j;            // kernel order: features first, then dxyz
+                                if (k < D) v = W[(size_t)n * K + 3 + k];      // reference order: [xyz - centroid (3) || features (D)]
+                                else if (k < D + 3) v = W[(size_t)n * K + (k - D)];
+                            } else {
+                                const int ch = 32 * (s / 2) + 8 * (2 * (s % 2) + j / 4) + 4 * h + j % 4;
+                                v = W[(size_t)n * K + ch];
+                            }
+                            const uint16_t hi = f2bf(v);
+                            blob.push_back(pl == 0 ? hi : f2bf(v - bf2f(hi)));
+                        }
+        biases.insert(biases.end(), Bv.begin(), Bv.end());
+        K = N;
+    }
+    if (blob.size() % 2) blob.push_back(0);
+    out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
+    out->b = upload(c, biases.data(), biases.size());
+    return out->w && out->b;
+}
+
 bool load_dense_h(lsdm_ctx* c, const std::string& wname, const std::string& bname, const std::string& bn, int N, int K, int np,
                   const std::vector<int>& perm, DenseH* out) {
     std::vector<float> W, Bv;
@@ -332,7 +378,10 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     for (int l = 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
-        launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
+        if (l < 3 && c->sa_reg)
+            launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
+        else
+            launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
     }
     const Lin head2{c->head[1].w, c->head[1].b};
     prof_mark(c, K_FP4, st);
@@ -539,6 +588,9 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
             }
         }
         ok = ok && load_dense_h(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, np, {}, &c->head_h[0]);
+        ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], np, &c->sa_r[0]) &&
+             build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
+             build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]);
     }
     if (ok) {
         Lin l{};

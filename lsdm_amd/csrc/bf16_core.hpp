@@ -30,6 +30,19 @@ struct DenseH {  // packed bf16 planes Wp[kb][n][NP][16] + fp32 bias[n]
     const float* b;
 };
 
+// element type of the level features in HBM: fp32 for bf16x3 (same workspace as the f32 path), bf16 for plain bf16
+template <int NP> struct FeatT { typedef float type; };
+template <> struct FeatT<1> { typedef __bf16 type; };
+
+__device__ __forceinline__ f32x4 load4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4f(const __bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(__bf16* p, float v) { *p = (__bf16)v; }
+
 __host__ __device__ constexpr int round16(int k) { return (k + 15) / 16 * 16; }
 // LDS leading dimension (bf16 elements) for a logical width k (multiple of 8): (ld/8) odd
 __host__ __device__ constexpr int ldh(int k) { return ((k / 8) % 2 == 1) ? k : k + 8; }

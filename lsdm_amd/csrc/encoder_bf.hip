@@ -27,17 +27,6 @@ __device__ unsigned long long g_phase[64 * 64];   // 64 spread copies of 64 slot
 #define PHASE_MARK(slot) do {} while (0)
 #endif
 
-template <int NP> struct FeatT { typedef float type; };
-template <> struct FeatT<1> { typedef __bf16 type; };
-
-__device__ __forceinline__ f32x4 load4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 load4f(const __bf16* p) {
-    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
-    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-    return r;
-}
-__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
-__device__ __forceinline__ void store1(__bf16* p, float v) { *p = (__bf16)v; }
 
 // ---------------------------------------------------------------------------------------------
 template <int D, int C1, int C2, int C3, int TM, int NW, int NP, int WPS = 1>

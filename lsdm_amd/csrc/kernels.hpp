@@ -89,6 +89,9 @@ void launch_sa_h(int np, int level, int num_clouds, const float* src_xyz, const 
                  const DenseH* l, void* out, hipStream_t st);
 void launch_fp_h(int np, int which, int num_clouds, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
                  const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st);
+// encoder_reg.hip: register-chained SA kernel for levels 0 and 1 (weights resident in LDS)
+void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
+                 const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
 // cond.hip
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st);

@@ -189,6 +189,37 @@ def test_scene_encoder_vs_oracle_and_golden(model13, sd13, golden):
     assert maxabs(out, T(g["out"])) <= 5e-4   # the real reference's output
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 0.6)])
+def test_scene_encoder_split_bf16_levels_vs_oracle_and_golden(sd13, golden, precision, tol):
+    """Every level of the encoder on the split-bf16 core -- register-chained sa1/sa2 (weights resident in LDS), streamed
+    sa3, LDS-tiled sa4 / FP stages -- against the oracle's taps and the reference's recorded output (G3, incl. the
+    all-zero cloud)."""
+    g = golden("g3_pointnet")
+    clouds = T(g["clouds"])
+    starts = [s.long() for s in T(g["starts"])]
+    taps = {}
+    ref = cpu_ref.scene_encoder(sd13, clouds, starts, taps)
+    m, _ = create_model_and_diffusion("proxd", precision=precision)
+    m.load_state_dict(sd13)
+    m._context()
+    m._reserve(1)
+    nc = clouds.shape[0]
+    out = torch.empty(nc, 1024, 3, device=DEV)
+    d_clouds, d_starts = clouds.to(DEV).contiguous(), torch.stack(starts).to(DEV).contiguous()
+    m._ctx.call("lsdm_scene_encoder", d_clouds.data_ptr(), d_starts.data_ptr(), nc, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    bf = precision == "bf16"
+    C_, S = (64, 128, 256, 512), (1024, 256, 64, 16)
+    for l in range(4):
+        got = ws(m, ("feat_bf%d" if bf else "feat%d") % (l + 1), (nc, S[l], C_[l]), torch.bfloat16 if bf else torch.float32).float()
+        assert maxabs(got, taps["sa%d.new_points" % (l + 1)]) <= tol, "sa%d" % (l + 1)
+    for name, shape in (("fp4", (nc, 64, 256)), ("fp3", (nc, 256, 256)), ("fp2", (nc, 1024, 128))):
+        got = ws(m, name + ("_bf" if bf else ""), shape, torch.bfloat16 if bf else torch.float32).float()
+        assert maxabs(got, taps[name + ".out"]) <= tol, name
+    assert maxabs(out, ref) <= tol
+    assert maxabs(out, T(g["out"])) <= tol   # the real reference's output
+
+
 def test_human_backbone(model13, sd13):
     bt = make_synthetic_batch(3, seed=5)
     ref = cpu_ref.human_backbone(sd13, bt["given_objs"][:, 0])
