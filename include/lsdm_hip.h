@@ -95,8 +95,8 @@ int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* 
 
 /* K consecutive ancestral steps t = t_first, t_first-1, ... with device-resident RNG draws; `x` ping-pongs with
  * an internal buffer and holds the final sample on return.  The x-independent PointNet++ geometry (FPS, ball queries,
- * 3-NN) of up to 4 consecutive steps is evaluated in one launch per stage ahead of those steps; results are identical
- * to K single-step calls.  Replaces the loop body of
+ * 3-NN) and conditioning MLPs of up to 8 consecutive steps are evaluated in one launch per stage ahead of those steps;
+ * results are identical to K single-step calls.  Replaces the loop body of
  * p_sample_loop_progressive (gaussian_diffusion.py:736-759) for a fixed batch.
  *   fps_start_steps (K,4,B*9) int64 ; noise_steps (K,B,1024,3) */
 int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,

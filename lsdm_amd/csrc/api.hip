@@ -44,8 +44,8 @@ struct lsdm_ctx {
     Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
     int prec = LSDM_PREC_F32;           // arithmetic of the dense layers (lsdm_set_precision)
     DenseH sa_h[4][3], fp_h[4][3], head_h[1];  // split-bf16 operands of the same layers (prec != F32)
-    bool sa_reg = getenv("LSDM_SA_REG") ? atoi(getenv("LSDM_SA_REG")) != 0 : true;   // debug switch: sa1/sa2 kernel form
-    DenseH sa_r[3];                     // sa1 / sa2 as LDS-resident fragment blobs of the register-chained kernel (encoder_reg.hip)
+    int sa_reg = getenv("LSDM_SA_REG") ? atoi(getenv("LSDM_SA_REG")) : 3;   // SA levels 0..sa_reg-1 use the register-chained kernels (A/B switch)
+    DenseH sa_r[4];                     // sa1 / sa2 as LDS-resident fragment blobs of the register-chained kernel (encoder_reg.hip)
     void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
     void* fpo_b[3] = {};
     CondParams cond{};
@@ -64,7 +64,7 @@ struct lsdm_ctx {
     // Everything a step computes WITHOUT x (conditioning vectors + PointNet++ geometry) lives in a FrontSet.  There are
     // kGroup of them, carved out of contiguous allocations [kGroup][...], so that lsdm_sample_steps can evaluate the
     // geometry of up to kGroup consecutive steps in ONE launch per stage (the fronts do not depend on x or on each other).
-    static constexpr int kGroup = 4;
+    static constexpr int kGroup = 8;
     struct FrontSet {
         int* idx[4] = {};
         float* xyz[4] = {};
@@ -314,9 +314,10 @@ T* ws_alloc(lsdm_ctx* c, const char* name, size_t count) {
     return static_cast<T*>(d);
 }
 
-__global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
+// timesteps of g consecutive steps, step-major: p[j*B + b] = t0 - j
+__global__ void fill_steps_kernel(int64_t* p, int64_t t0, int B, int g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i < B * g) p[i] = t0 - i / B;
 }
 
 // geometry + dense stages of get_backbone.forward on `num_clouds` clouds
@@ -378,7 +379,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     for (int l = 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
-        if (l < 3 && c->sa_reg)
+        if (l < c->sa_reg)
             launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
         else
             launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
@@ -400,21 +401,27 @@ int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, i
     return check_launch(c, "scene encoder");
 }
 
-// FRONT of a step: everything that does not read x -- conditioning vectors, up-sampling layers 1-2, the human branch
-// (given_objs only: evaluated once per multi-step call) and, unless the caller batched it for a group of steps
-// (with_geometry = false), the PointNet++ geometry.
-void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_objs, const float* given_cats,
-               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st, bool with_geometry = true) {
+// x-independent conditioning of `g` consecutive steps into front sets f, f+1, ... (contiguous): timestep / text /
+// category MLPs + up-sampling layers 1-2, one launch each for the group; `t` holds g*B timesteps (step-major).
+// The human branch depends on given_objs only and is evaluated once per multi-step call.
+void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, const float* mask, const float* given_objs,
+                      const float* given_cats, const float* text, float* out_cat, bool reuse_hm, hipStream_t st) {
     prof_mark(c, K_COND, st);
-    launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
+    launch_cond(c->cond, t, text, given_cats, mask, B, g, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
     prof_mark(c, K_UP12, st);
-    launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B, f.h2p, st);
+    launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B * g, f.h2p, st);
     if (!reuse_hm) {
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->hm, st);
     }
     prof_mark(c, -1, st);
-    if (with_geometry) run_geometry(c, f, given_objs, starts, B * kO, 1, st);
+}
+
+// FRONT of a single step: conditioning + PointNet++ geometry (nothing here reads x)
+void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_objs, const float* given_cats,
+               const float* text, const int64_t* starts, float* out_cat, bool reuse_hm, hipStream_t st) {
+    run_conditioning(c, f, B, 1, t, mask, given_objs, given_cats, text, out_cat, reuse_hm, st);
+    run_geometry(c, f, given_objs, starts, B * kO, 1, st);
 }
 
 // conditioning that depends on the scene only: dense encoder stages + collapsed scene attention (needs f.w, f.tr)
@@ -442,17 +449,6 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
               const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
     run_scene_conditioning(c, f, B, given_objs, st);
     run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st);
-}
-
-// t-dependent conditioning only (timestep/text/category MLPs + up-sampling layers 1-2) -- the per-step front of the
-// hoisted-conditioning mode
-void run_light_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* mask, const float* given_cats, const float* text,
-                     float* out_cat, hipStream_t st) {
-    prof_mark(c, K_COND, st);
-    launch_cond(c->cond, t, text, given_cats, mask, B, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
-    prof_mark(c, K_UP12, st);
-    launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B, f.h2p, st);
-    prof_mark(c, -1, st);
 }
 
 int run_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
@@ -590,7 +586,8 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
         ok = ok && load_dense_h(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, np, {}, &c->head_h[0]);
         ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], np, &c->sa_r[0]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
-             build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]);
+             build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]) &&
+             build_sa_reg_blob(c, "pcd_backbone.sa4", 256, sa_mlp[3], np, &c->sa_r[3]);
     }
     if (ok) {
         Lin l{};
@@ -801,12 +798,12 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     // step produces) is evaluated first, one launch per stage over group x B x 9 clouds, then the steps run in order.
     for (int k0 = 0; k0 < K; k0 += lsdm_ctx::kGroup) {
         const int g = K - k0 < lsdm_ctx::kGroup ? K - k0 : lsdm_ctx::kGroup;
+        hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);
+        run_conditioning(c, c->fs[0], B, g, c->fs[0].tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
         run_geometry(c, c->fs[0], given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st);
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
             lsdm_ctx::FrontSet& f = c->fs[j];
-            hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f.tbuf, (int64_t)(t_first - k), B);
-            run_front(c, f, B, f.tbuf, mask, given_objs, given_cats, text, nullptr, out_cat, /*reuse_hm=*/k > 0, st, /*with_geometry=*/false);
             run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
             rc = check_launch(c, "sample step");
             if (rc) return rc;
@@ -831,21 +828,25 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
     float* cur = x;
     float* nxt = c->xs;
     const size_t xn = (size_t)B * kN * 3;
-    // once per call: everything that depends on (given_objs, text, cats, mask, FPS starts) only
-    hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)t_first, B);
-    run_front(c, c->fs[0], B, c->fs[0].tbuf, mask, given_objs, given_cats, text, starts, out_cat, /*reuse_hm=*/false, st);
-    run_scene_conditioning(c, c->fs[0], B, given_objs, st);
-    // per step: t-dependent conditioning (front) + the denoiser (back).  fs[0] already holds step 0's front.
-    for (int k = 0; k < K; ++k) {
-        lsdm_ctx::FrontSet& f = c->fs[k & 1];
-        if (k > 0) {
-            hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 63) / 64), dim3(64), 0, st, f.tbuf, (int64_t)(t_first - k), B);
-            run_light_front(c, f, B, f.tbuf, mask, given_cats, text, out_cat, st);
+    // once per call: everything that depends on (given_objs, text, cats, mask, FPS starts) only.  The scene attention needs
+    // w / tr of the conditioning, which do not depend on t: the first group's conditioning is evaluated first.
+    for (int k0 = 0; k0 < K; k0 += lsdm_ctx::kGroup) {
+        const int g = K - k0 < lsdm_ctx::kGroup ? K - k0 : lsdm_ctx::kGroup;
+        // per group: the t-dependent conditioning of its steps in one launch per stage
+        hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);
+        run_conditioning(c, c->fs[0], B, g, c->fs[0].tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
+        if (k0 == 0) {
+            run_geometry(c, c->fs[0], given_objs, starts, B * kO, 1, st);
+            run_scene_conditioning(c, c->fs[0], B, given_objs, st);
         }
-        run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
-        rc = check_launch(c, "hoisted sample step");
-        if (rc) return rc;
-        float* tmp = cur; cur = nxt; nxt = tmp;
+        // per step: the fused denoiser + sampler update (the only stage that reads x)
+        for (int j = 0; j < g; ++j) {
+            lsdm_ctx::FrontSet& f = c->fs[j];
+            run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)(k0 + j) * xn, out_x0, out_guiding, nxt, st);
+            rc = check_launch(c, "hoisted sample step");
+            if (rc) return rc;
+            float* tmp = cur; cur = nxt; nxt = tmp;
+        }
     }
     if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
     return LSDM_OK;

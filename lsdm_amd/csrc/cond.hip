@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
                                                    float* __restrict__ tr_out, float* __restrict__ w_out) {
     __shared__ float sa[512], sb[512], enc[128], ecat[kSlots * 32], trh[kSlots * 128];
     __shared__ float q[128], kk[kSlots * 128], logit[8 * kSlots];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // A launch may cover G consecutive steps of the same batch (grid = G*B): block r = step*B + b reads the conditioning
+    // of sample b and step `step`'s timestep, and writes row r of e0 / tr / w (the front sets are contiguous).
+    const int r = blockIdx.x, b = r % B, tid = threadIdx.x;
     // 1. timestep embedding: pe[t] -> Linear -> SiLU -> Linear  (diffusion_utils.py:14-21)
-    const float* pe = P.pe + (size_t)t[b] * 128;
+    const float* pe = P.pe + (size_t)t[r] * 128;
     if (tid < 128) sa[tid] = pe[tid];
     __syncthreads();
     for (int j = tid; j < 128; j += 256) {
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
         sb[j] = siluf(s + P.time0.b[j]);
     }
     __syncthreads();
-    dense_vec<ACT_NONE>(sb, 128, P.time2, e0 + (size_t)b * 256, 128);
+    dense_vec<ACT_NONE>(sb, 128, P.time2, e0 + (size_t)r * 256, 128);
     // 2. text embedding 512 -> 256 -> 256 -> 128, GELU after every layer (Q9)
     __syncthreads();
     for (int k = tid; k < 512; k += 256) sa[k] = text[(size_t)b * 512 + k];
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
     __syncthreads();
     dense_vec<ACT_GELU>(sa, 256, P.text4, enc, 128);
     __syncthreads();
-    if (tid < 128) e0[(size_t)b * 256 + 128 + tid] = enc[tid];
+    if (tid < 128) e0[(size_t)r * 256 + 128 + tid] = enc[tid];
     // 3. category head 128 -> 64 -> 32 -> C, GELU on the logits, softmax (Q10)
     dense_vec<ACT_GELU>(enc, 128, P.pcat0, sa, 64);
     __syncthreads();
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
         const float* w = P.tr2.w + (size_t)j * 128;
         float s = 0.0f;
         for (int k = 0; k < 128; ++k) s = fmaf(trh[o * 128 + k], w[k], s);
-        tr_out[((size_t)b * kSlots + o) * 12 + j] = gelu(s + P.tr2.b[j]);
+        tr_out[((size_t)r * kSlots + o) * 12 + j] = gelu(s + P.tr2.b[j]);
     }
     if (tid < 8 * kSlots) {
         const int h = tid / kSlots, o = tid - h * kSlots;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
             for (int o = 0; o < kSlots; ++o) s += expf(logit[h * kSlots + o] - m);
             acc += expf(logit[h * kSlots + tid] - m) / s;
         }
-        w_out[(size_t)b * kSlots + tid] = acc / 8.0f;
+        w_out[(size_t)r * kSlots + tid] = acc / 8.0f;
     }
 }
 
@@ -346,9 +348,9 @@ __global__ __launch_bounds__(256) void scene_attn_kernel(SceneAttnParams P, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int C,
+void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st) {
-    hipLaunchKernelGGL(cond_kernel, dim3(B), dim3(256), 0, st, P, t, text, given_cats, mask, B, C, out_cat, e0, tr, w);
+    hipLaunchKernelGGL(cond_kernel, dim3(B * G), dim3(256), 0, st, P, t, text, given_cats, mask, B, C, out_cat, e0, tr, w);
 }
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st) {
     hipLaunchKernelGGL(posa_kernel, dim3(B), dim3(1024), 0, st, P, given_objs, hm);

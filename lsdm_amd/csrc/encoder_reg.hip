@@ -346,6 +346,12 @@ void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* sr
                                         new_xyz, ball, 256, 64, tot, blob_w, blob_b, static_cast<float*>(out));
         else hipLaunchKernelGGL((sa_s_kernel<128, 128, 128, 256, 4, 1>), dim3(512), dim3(256), 0, st, src_xyz, static_cast<const __bf16*>(src_feat),
                                 new_xyz, ball, 256, 64, tot, blob_w, blob_b, static_cast<__bf16*>(out));
+    } else if (level == 3) {
+        const long long tot = (long long)nc * 16;
+        if (np == 2) hipLaunchKernelGGL((sa_s_kernel<256, 256, 256, 512, 4, 2>), dim3(256), dim3(256), 0, st, src_xyz, static_cast<const float*>(src_feat),
+                                        new_xyz, ball, 64, 16, tot, blob_w, blob_b, static_cast<float*>(out));
+        else hipLaunchKernelGGL((sa_s_kernel<256, 256, 256, 512, 4, 1>), dim3(256), dim3(256), 0, st, src_xyz, static_cast<const __bf16*>(src_feat),
+                                new_xyz, ball, 64, 16, tot, blob_w, blob_b, static_cast<__bf16*>(out));
     } else {
         const long long tot = (long long)nc * 256;
         if (np == 2) hipLaunchKernelGGL((sa_r_kernel<64, 64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, src_xyz, static_cast<const float*>(src_feat),

@@ -93,7 +93,8 @@ void launch_fp_h(int np, int which, int num_clouds, const void* points1, const v
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
 // cond.hip
-void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int C,
+// G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
+void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st);
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st);
 // np = 0: fp32 operand for denoise_kernel; 1 / 2: bf16 planes for denoise_h_kernel
