@@ -44,8 +44,10 @@ struct lsdm_ctx {
     Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
     int prec = LSDM_PREC_F32;           // arithmetic of the dense layers (lsdm_set_precision)
     DenseH sa_h[4][3], fp_h[4][3], head_h[1];  // split-bf16 operands of the same layers (prec != F32)
-    int sa_reg = getenv("LSDM_SA_REG") ? atoi(getenv("LSDM_SA_REG")) : 3;   // SA levels 0..sa_reg-1 use the register-chained kernels (A/B switch)
-    DenseH sa_r[4];                     // sa1 / sa2 as LDS-resident fragment blobs of the register-chained kernel (encoder_reg.hip)
+    // SA levels 0..sa_reg-1 use the register-chained kernels (encoder_reg.hip), the rest the LDS-tiled sa_h_kernel;
+    // LSDM_SA_REG=0..3 is an A/B switch for measurements (sa4 and the FP stages were measured slower in the chained form)
+    int sa_reg = getenv("LSDM_SA_REG") ? (atoi(getenv("LSDM_SA_REG")) < 3 ? atoi(getenv("LSDM_SA_REG")) : 3) : 3;
+    DenseH sa_r[3];                     // sa1..sa3 as fragment blobs of the register-chained kernels (encoder_reg.hip)
     void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
     void* fpo_b[3] = {};
     CondParams cond{};
@@ -225,23 +227,21 @@ bool fold_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname,
     return true;
 }
 
-// Fragment blob of the register-chained SA kernel (encoder_reg.hip) for one level: three layers, each as
+// Fragment blob of a register-chained layer stack (encoder_reg.hip): every layer as
 // [nb = n/32][k-step s][plane][lane = n%32 + 32*h][8] bf16 with k-slot (s, h, j) -> input channel
-//   layer 1 : 16*s + 8*h + j in the kernel's K order [features (D) || xyz - centroid (3) || 0]
-//   layer 2,3: 32*(s/2) + 8*(2*(s%2) + j/4) + 4*h + j%4  -- the channels a lane owns in accumulator registers
-//              8*(s%2) .. 8*(s%2)+7 of block s/2 of the previous layer's transposed product
-// followed (separately) by the fp32 biases [b1 | b2 | b3], BatchNorm folded.
-bool build_sa_reg_blob(lsdm_ctx* c, const std::string& prefix, int D, const int (&mlp)[3], int np, DenseH* out) {
+//   first layer : first_map[16*s + 8*h + j]  (column of W in the kernel's own K order; -1 / beyond the map = zero pad)
+//   later layers: 32*(s/2) + 8*(2*(s%2) + j/4) + 4*h + j%4  -- the channels a lane owns in accumulator registers
+//                 8*(s%2) .. 8*(s%2)+7 of block s/2 of the previous layer's transposed product
+// followed (separately) by the fp32 biases of the layers back to back, BatchNorm folded.
+struct ChainLayer { std::string w, b, bn; int N, K; };
+bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const std::vector<int>& first_map, int np, DenseH* out) {
     std::vector<uint16_t> blob;
     std::vector<float> biases;
-    int K = D + 3;
-    for (int li = 0; li < 3; ++li) {
-        const int N = mlp[li];
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const int N = layers[li].N, K = layers[li].K;
         std::vector<float> W, Bv;
-        if (!fold_dense(c, prefix + ".mlp_convs." + std::to_string(li) + ".weight", prefix + ".mlp_convs." + std::to_string(li) + ".bias",
-                        prefix + ".mlp_bns." + std::to_string(li), N, K, W, Bv))
-            return false;
-        const int KS = li == 0 ? (D == 3 ? 1 : (D + 16) / 16) : K / 16;
+        if (!fold_dense(c, layers[li].w, layers[li].b, layers[li].bn, N, K, W, Bv)) return false;
+        const int KS = li == 0 ? ((int)first_map.size() + 15) / 16 : K / 16;
         for (int nb = 0; nb < N / 32; ++nb)
             for (int s = 0; s < KS; ++s)
                 for (int pl = 0; pl < np; ++pl)
@@ -250,23 +250,36 @@ bool build_sa_reg_blob(lsdm_ctx* c, const std::string& prefix, int D, const int 
                             const int n = nb * 32 + (lane & 31), h = lane >> 5;
                             float v = 0.0f;
                             if (li == 0) {
-                                const int k = 16 * s + 8 * h + j;            // kernel order: features first, then dxyz
-                                if (k < D) v = W[(size_t)n * K + 3 + k];      // reference order: [xyz - centroid (3) || features (D)]
-                                else if (k < D + 3) v = W[(size_t)n * K + (k - D)];
+                                const int k = 16 * s + 8 * h + j;
+                                if (k < (int)first_map.size() && first_map[k] >= 0) v = W[(size_t)n * K + first_map[k]];
                             } else {
-                                const int ch = 32 * (s / 2) + 8 * (2 * (s % 2) + j / 4) + 4 * h + j % 4;
-                                v = W[(size_t)n * K + ch];
+                                v = W[(size_t)n * K + 32 * (s / 2) + 8 * (2 * (s % 2) + j / 4) + 4 * h + j % 4];
                             }
                             const uint16_t hi = f2bf(v);
                             blob.push_back(pl == 0 ? hi : f2bf(v - bf2f(hi)));
                         }
         biases.insert(biases.end(), Bv.begin(), Bv.end());
-        K = N;
     }
     if (blob.size() % 2) blob.push_back(0);
     out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
     out->b = upload(c, biases.data(), biases.size());
     return out->w && out->b;
+}
+
+// SA level: three layers; the kernels order the first layer's K as [features (D) || xyz - centroid (3) || 0], the
+// reference as [xyz - centroid (3) || features (D)]
+bool build_sa_reg_blob(lsdm_ctx* c, const std::string& prefix, int D, const int (&mlp)[3], int np, DenseH* out) {
+    std::vector<ChainLayer> layers;
+    int K = D + 3;
+    for (int li = 0; li < 3; ++li) {
+        layers.push_back({prefix + ".mlp_convs." + std::to_string(li) + ".weight", prefix + ".mlp_convs." + std::to_string(li) + ".bias",
+                          prefix + ".mlp_bns." + std::to_string(li), mlp[li], K});
+        K = mlp[li];
+    }
+    std::vector<int> map;
+    for (int k = 0; k < D; ++k) map.push_back(3 + k);
+    for (int k = 0; k < 3; ++k) map.push_back(k);
+    return build_chain_blob(c, layers, map, np, out);
 }
 
 bool load_dense_h(lsdm_ctx* c, const std::string& wname, const std::string& bname, const std::string& bn, int N, int K, int np,
@@ -586,8 +599,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
         ok = ok && load_dense_h(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, np, {}, &c->head_h[0]);
         ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], np, &c->sa_r[0]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
-             build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]) &&
-             build_sa_reg_blob(c, "pcd_backbone.sa4", 256, sa_mlp[3], np, &c->sa_r[3]);
+             build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]);
     }
     if (ok) {
         Lin l{};

@@ -296,14 +296,16 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
         }
         bf16x8 yh[KS2], yl[KS2], zh[KS3], zl[KS3];
         // one panel step: request the next panel, run this panel's MFMAs + epilogue, publish the next panel
-#define PANEL_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0];
+// lz: an opaque zero defined per panel -- the LDS reads of biases / conv2 weights are the same every round, and without
+// it the compiler hoists all of them to the top of the persistent loop and parks them in ~200 VGPRs
+#define PANEL_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz));
 #define PANEL_END(Q) commit(((Q) + 1) % NPANEL); __syncthreads(); }
 #pragma unroll
         for (int nb = 0; nb < NB1; ++nb) {
             PANEL_BEGIN(nb)
             f32x16 acc;
             mma_panel<KS1, NP, true>(acc, W, xh, xl, lane);
-            relu_split_pair<NP>(acc, b1 + 32 * nb, h, yh[2 * nb], yl[2 * nb], yh[2 * nb + 1], yl[2 * nb + 1]);
+            relu_split_pair<NP>(acc, b1 + lz + 32 * nb, h, yh[2 * nb], yl[2 * nb], yh[2 * nb + 1], yl[2 * nb + 1]);
             PANEL_END(nb)
         }
 #pragma unroll
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
             PANEL_BEGIN(NB1 + nb)
             f32x16 acc;
             mma_panel<KS2, NP, true>(acc, W, yh, yl, lane);
-            relu_split_pair<NP>(acc, b2 + 32 * nb, h, zh[2 * nb], zl[2 * nb], zh[2 * nb + 1], zl[2 * nb + 1]);
+            relu_split_pair<NP>(acc, b2 + lz + 32 * nb, h, zh[2 * nb], zl[2 * nb], zh[2 * nb + 1], zl[2 * nb + 1]);
             PANEL_END(NB1 + nb)
         }
 #pragma unroll
@@ -346,12 +348,6 @@ void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* sr
                                         new_xyz, ball, 256, 64, tot, blob_w, blob_b, static_cast<float*>(out));
         else hipLaunchKernelGGL((sa_s_kernel<128, 128, 128, 256, 4, 1>), dim3(512), dim3(256), 0, st, src_xyz, static_cast<const __bf16*>(src_feat),
                                 new_xyz, ball, 256, 64, tot, blob_w, blob_b, static_cast<__bf16*>(out));
-    } else if (level == 3) {
-        const long long tot = (long long)nc * 16;
-        if (np == 2) hipLaunchKernelGGL((sa_s_kernel<256, 256, 256, 512, 4, 2>), dim3(256), dim3(256), 0, st, src_xyz, static_cast<const float*>(src_feat),
-                                        new_xyz, ball, 64, 16, tot, blob_w, blob_b, static_cast<float*>(out));
-        else hipLaunchKernelGGL((sa_s_kernel<256, 256, 256, 512, 4, 1>), dim3(256), dim3(256), 0, st, src_xyz, static_cast<const __bf16*>(src_feat),
-                                new_xyz, ball, 64, 16, tot, blob_w, blob_b, static_cast<__bf16*>(out));
     } else {
         const long long tot = (long long)nc * 256;
         if (np == 2) hipLaunchKernelGGL((sa_r_kernel<64, 64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, src_xyz, static_cast<const float*>(src_feat),

@@ -16,7 +16,7 @@ FP = {("256", "512"): "fp_kernel<fp4>", ("128", "256"): "fp_kernel<fp3>", ("64",
 
 
 def bench_name(k):
-    m = re.search(r"sa_(?:h_)?kernel<(\d+),", k)
+    m = re.search(r"sa_(?:[hrs]_)?kernel<(\d+),", k)
     if m:
         return SA.get(m.group(1))
     m = re.search(r"fp_(?:h_)?kernel<(\d+), (\d+),", k)
