@@ -721,6 +721,7 @@ int lsdm_set_schedule(lsdm_ctx* c, int T, const float* coef1, const float* coef2
 
 int lsdm_reserve(lsdm_ctx* c, int B) {
     if (!c || B <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_reserve: bad batch");
+    if ((long long)B * kO > 65535) return fail(c, LSDM_ERR_ARG, "lsdm_reserve: batch %d exceeds 7281 chains per context (65535 clouds per launch)", B);
     HIP_TRY(c, hipSetDevice(c->device));
     if (B <= c->cap_B) return LSDM_OK;
     HIP_TRY(c, hipDeviceSynchronize());
@@ -808,8 +809,10 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     const int nc = B * kO;
     // Steps are processed in groups of up to kGroup: the geometry of the whole group (it reads neither x nor anything a
     // step produces) is evaluated first, one launch per stage over group x B x 9 clouds, then the steps run in order.
-    for (int k0 = 0; k0 < K; k0 += lsdm_ctx::kGroup) {
-        const int g = K - k0 < lsdm_ctx::kGroup ? K - k0 : lsdm_ctx::kGroup;
+    // (the cloud index of a batched geometry launch is gridDim.y: at most 65535 clouds per launch)
+    const int gmax = 65535 / nc < lsdm_ctx::kGroup ? (65535 / nc < 1 ? 1 : 65535 / nc) : lsdm_ctx::kGroup;
+    for (int k0 = 0; k0 < K; k0 += gmax) {
+        const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);
         run_conditioning(c, c->fs[0], B, g, c->fs[0].tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
         run_geometry(c, c->fs[0], given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st);
