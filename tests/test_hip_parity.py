@@ -500,8 +500,8 @@ def test_hoisted_conditioning_vs_pinned_reference_golden(golden, precision):
 
 
 def test_multi_step_call_is_deterministic(sd13):
-    """K steps in one library call (the bench path), repeated: bit-identical results (single stream; the experimental
-    two-stream overlap stays off, include/lsdm_hip.h)."""
+    """K steps in one library call (the bench path: geometry and conditioning batched per group of steps, one stream),
+    repeated: bit-identical results."""
     B, K = 2, 4
     m, diff = create_model_and_diffusion("proxd", precision="bf16x3")
     m.load_state_dict(sd13)
