@@ -4,19 +4,21 @@
 // posterior / DDIM update; model/sdm.py:196-217, gaussian_diffusion.py:258-280,545-561,790-811); the dense layers
 //   upsampling_layer.4 (transposed: rows = points, K = 512, per-POINT bias), combine_extraction, InputProcess and
 //   OutputProcess (model/diffusion_utils.py:51-78,98-122)
-// run as bf16x3 (NP = 2) or bf16 (NP = 1) products with fp32 accumulation.  One 512-thread workgroup per
-// (sample, 64-point tile); all activations stay in LDS as bf16 planes:
-//   R0 [64][264]  e tile (up-sampling output) -> later the 192-wide hidden state of combination_extraction
-//   R1 [64][136]  emb = combine_extraction(e)  (shared by both denoiser passes; read as the second K half of cex0)
-//   R2 [64][136]  W4 chunk staging -> pose embedding / 128-wide hidden states
-//   R3 [64][72]   64-wide hidden states
+// run as bf16x3 (NP = 2) or bf16 (NP = 1) products with fp32 accumulation.  One 256-thread workgroup per
+// (sample, 32-point tile); all activations stay in LDS as bf16 planes:
+//   R0 [32][264]  e tile (up-sampling output) -> later the 192-wide hidden state of combination_extraction
+//   R1 [32][136]  emb = combine_extraction(e)  (shared by both denoiser passes; read as the second K half of cex0)
+//   R2 [32][136]  W4 chunk staging -> pose embedding / 128-wide hidden states
+//   R3 [32][72]   64-wide hidden states
 #include "bf16_core.hpp"
 #include "kernels.hpp"
 
 namespace lsdm {
 
 namespace {
-constexpr int TM = 64, NW = 8, NT = NW * 64;
+// 32 points x 4 waves: 79 KB of LDS in bf16x3, i.e. two independent workgroups per CU whose phases interleave
+// (64 points x 8 waves, one workgroup per CU, measured 7 % slower)
+constexpr int TM = 32, NW = 4, NT = NW * 64;
 constexpr int LD0 = ldh(256), LD1 = ldh(128), LDC = ldh(192), LD3 = ldh(64);
 constexpr int P0 = TM * LD0, P1 = TM * LD1, P3 = TM * LD3;
 constexpr int KC = 128;  // K chunk of the up-sampling GEMM (K = 512)
@@ -49,7 +51,7 @@ __device__ __forceinline__ void denoiser_pass_h(const DenoiseHParams& P, const f
     layer_lds_h<NW, TM, 64, 128, ACT_SIGMOID, NP>(R3, LD3, P3, P.pose2, R2, LD1, P1);   // pose (128) -> R2
     __syncthreads();
     {   // combination_extraction.0: [pose (R2) || emb (R1)] 256 -> 192 sigmoid -> R0
-        using TS = SplitH<NW, TM, 192, 4>;   // 6 channel blocks over 4 column groups x 2 point groups
+        using TS = SplitH<NW, TM, 192, 4>;   // 6 channel blocks over 4 column groups (x point groups when NW > 4)
         const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
 #pragma unroll 1
         for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
@@ -65,7 +67,7 @@ __device__ __forceinline__ void denoiser_pass_h(const DenoiseHParams& P, const f
     __syncthreads();
     layer_lds_h<NW, TM, 192, 128, ACT_SIGMOID, NP>(R0, LDC, P0, P.cex2, R2, LD1, P1);
     __syncthreads();
-    layer_lds_h<4, TM, 128, 64, ACT_GELU, NP>(R2, LD1, P1, P.fin0, R3, LD3, P3);        // 4 block tasks: waves 0-3
+    layer_lds_h<(TM / 32) * 2, TM, 128, 64, ACT_GELU, NP>(R2, LD1, P1, P.fin0, R3, LD3, P3);   // 2 x TM/32 block tasks: first waves only
     __syncthreads();
     // pose_final.2: 64 -> 3 GELU (VALU)
     for (int e = tid; e < TM * 3; e += NT) {
@@ -132,14 +134,16 @@ __global__ __launch_bounds__(NT) void denoise_h_kernel(DenoiseHParams P, StepCoe
 
     // ---- third up-sampling layer, transposed: e[p, c] = GELU(W4[n0+p, :] . h2[b, c, :] + b4[n0+p]) ------------------
     {
-        using TS = SplitH<NW, TM, 256>;   // 8 channel blocks, one per wave, 2 point blocks each
-        static_assert(TS::CSTEP == 8 && TS::RB == 2, "split");
+        using TS = SplitH<NW, TM, 256>;   // 8 channel blocks over the waves (one or two per wave), all point blocks each
+        constexpr int NCB = TS::CB / TS::CSTEP;
+        static_assert(TS::WPC == 1, "split");
         const __bf16* h2b = h2p + (size_t)b * 32 * 256 * NP * 16;
-        f32x16 acc[TS::RB];
-        acc_zero_h(acc);
+        f32x16 acc[NCB][TS::RB];
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) acc_zero_h(acc[q]);
         for (int ch = 0; ch < 512 / KC; ++ch) {
             __syncthreads();
-            // stage the chunk of the pre-split W4 rows: 64 rows x 128 k per plane, 16-byte pieces
+            // stage the chunk of the pre-split W4 rows: TM rows x 128 k per plane, 16-byte pieces
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) {
                 const __bf16* src = (pl == 0 ? P.up4_h : P.up4_l) + (size_t)n0 * 512 + ch * KC;
@@ -151,20 +155,24 @@ __global__ __launch_bounds__(NT) void denoise_h_kernel(DenoiseHParams P, StepCoe
                 }
             }
             __syncthreads();
-            mma_kloop_h<TS::RB, NP, true, KC / 16>(acc, R2, LD1, P1, h2b, 256, wave, ch * (KC / 16), lane);
+#pragma unroll
+            for (int q = 0; q < NCB; ++q)
+                mma_kloop_h<TS::RB, NP, true, KC / 16>(acc[q], R2, LD1, P1, h2b, 256, wave + q * TS::CSTEP, ch * (KC / 16), lane);
         }
         // epilogue: per-POINT bias, GELU, split -> R0[p][c]
         const int p = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int rb = 0; rb < TS::RB; ++rb) {
-            const float bp = P.up4_b[n0 + rb * 32 + p];
+        for (int q = 0; q < NCB; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = wave * 32 + 8 * q + 4 * h;
-                store_split4<NP>(R0 + (rb * 32 + p) * LD0 + n, P0, gelu(acc[rb][4 * q + 0] + bp), gelu(acc[rb][4 * q + 1] + bp),
-                                 gelu(acc[rb][4 * q + 2] + bp), gelu(acc[rb][4 * q + 3] + bp));
+            for (int rb = 0; rb < TS::RB; ++rb) {
+                const float bp = P.up4_b[n0 + rb * 32 + p];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int n = (wave + q * TS::CSTEP) * 32 + 8 * qd + 4 * h;
+                    store_split4<NP>(R0 + (rb * 32 + p) * LD0 + n, P0, gelu(acc[q][rb][4 * qd + 0] + bp), gelu(acc[q][rb][4 * qd + 1] + bp),
+                                     gelu(acc[q][rb][4 * qd + 2] + bp), gelu(acc[q][rb][4 * qd + 3] + bp));
+                }
             }
-        }
     }
     __syncthreads();
     // ---- combine_extraction 256 -> 128 GELU -> emb (R1) -----------------------------------------------------------
