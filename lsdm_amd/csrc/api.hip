@@ -67,6 +67,7 @@ struct lsdm_ctx {
     // kGroup of them, carved out of contiguous allocations [kGroup][...], so that lsdm_sample_steps can evaluate the
     // geometry of up to kGroup consecutive steps in ONE launch per stage (the fronts do not depend on x or on each other).
     static constexpr int kGroup = 8;
+    int group_cap = getenv("LSDM_GROUP") ? atoi(getenv("LSDM_GROUP")) : 0;   // A/B switch: steps per batched geometry launch
     struct FrontSet {
         int* idx[4] = {};
         float* xyz[4] = {};
@@ -810,7 +811,8 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     // Steps are processed in groups of up to kGroup: the geometry of the whole group (it reads neither x nor anything a
     // step produces) is evaluated first, one launch per stage over group x B x 9 clouds, then the steps run in order.
     // (the cloud index of a batched geometry launch is gridDim.y: at most 65535 clouds per launch)
-    const int gmax = 65535 / nc < lsdm_ctx::kGroup ? (65535 / nc < 1 ? 1 : 65535 / nc) : lsdm_ctx::kGroup;
+    int gmax = 65535 / nc < lsdm_ctx::kGroup ? (65535 / nc < 1 ? 1 : 65535 / nc) : lsdm_ctx::kGroup;
+    if (c->group_cap > 0 && gmax > c->group_cap) gmax = c->group_cap;
     for (int k0 = 0; k0 < K; k0 += gmax) {
         const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);

@@ -8,6 +8,8 @@
 // discrete decisions (arg-max, d > r^2, nearest-3) are index-exact against the CPU oracle.
 // Built with -ffp-contract=off; explicit __f*_rn intrinsics are used where the order matters.
 #include "common.hpp"
+#include <cstdlib>
+#include <cstring>
 
 namespace lsdm {
 
@@ -179,22 +181,203 @@ __global__ __launch_bounds__(64) void fps_chain_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// FPS, one wave per cloud, points AND centroid fetch in registers (fps_chain_reg_kernel): the lanes hold N/64 points
+// each (point p = lane + 64*j) as register vectors.  Per iteration a lane keeps only the MAXIMUM of its running minima
+// (one v_max per point instead of compare + two selects); the wave maximum is a 32-bit DPP reduction; the winner is then
+// located with one v_cmp_eq per register (lowest j, then lowest lane = lowest point index, like torch.max on CPU) and
+// its coordinates are read straight out of the owning lane's registers (uniform dynamic register index + v_readlane) --
+// no LDS access and no memory latency inside the dependent chain.  The selections of 64 consecutive iterations are
+// collected one per lane and flushed as coalesced stores.  LDS is only the 12 KiB hand-over buffer between levels, so
+// 12 waves fit a CU and the VALU (not latency) bounds the kernel.  ~45 % fewer VALU instructions per iteration than
+// fps_level_wave.
+// ---------------------------------------------------------------------------------------------
+template <int PPT> struct FpsVec { typedef float type __attribute__((ext_vector_type(PPT))); };
+template <> struct FpsVec<1> { typedef float type; };
+template <int PPT> __device__ __forceinline__ float fv_get(const typename FpsVec<PPT>::type& v, int j) { return v[j]; }
+template <> __device__ __forceinline__ float fv_get<1>(const float& v, int) { return v; }
+template <int PPT> __device__ __forceinline__ void fv_set(typename FpsVec<PPT>::type& v, int j, float x) { v[j] = x; }
+template <> __device__ __forceinline__ void fv_set<1>(float& v, int, float x) { v = x; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// single-instruction min / max3 (the values on this path are never NaN, so the canonicalising v_max the compiler puts in
+// front of fminf / fmaxf under IEEE mode is dead weight)
+__device__ __forceinline__ float vmin_f32(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3_f32(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax_f32(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// wave64 max, one v_max_f32 with a DPP source per step (s_nop 1 = the two wait states a DPP read needs after a VALU
+// write of the same register); returned as a wave-uniform value
+__device__ __forceinline__ float wave_max_f32(float v) {
+    asm volatile(
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// lowest j with any lane holding run[j] == wmax (ascending search with early exit: ~PPT/2 compares on average), and the
+// lane mask of that j
+template <int PPT, int J>
+__device__ __forceinline__ void fps_find(const typename FpsVec<PPT>::type& run, float wmax, int& selj, unsigned long long& selm) {
+    const unsigned long long m = __ballot(fv_get<PPT>(run, J) == wmax);
+    if (J == PPT - 1 || m != 0ull) { selj = J; selm = m; return; }
+    if constexpr (J + 1 < PPT) fps_find<PPT, J + 1>(run, wmax, selj, selm);
+}
+
+// src: N points in registers (SoA LDS hand-over buffer `hx|hy|hz` is overwritten with the NP selected points)
+template <int N, int NP>
+__device__ __forceinline__ void fps_level_reg(const typename FpsVec<N / 64>::type& px, const typename FpsVec<N / 64>::type& py,
+                                              const typename FpsVec<N / 64>::type& pz, int start, float* __restrict__ hand,
+                                              int* __restrict__ out_idx, float* __restrict__ out_xyz) {
+    constexpr int PPT = N / 64;
+    static_assert(N % 64 == 0 && (NP <= 64 || NP % 64 == 0), "fps_level_reg tiling");
+    const int lane = threadIdx.x;
+    typename FpsVec<PPT>::type run;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) fv_set<PPT>(run, j, 1e10f);
+    int sj = __builtin_amdgcn_readfirstlane(start >> 6), sl = __builtin_amdgcn_readfirstlane(start & 63);
+    constexpr int BLK = NP < 64 ? NP : 64;
+    for (int ib = 0; ib < NP; ib += BLK) {
+        int sel_i = 0, sel_x = 0, sel_y = 0, sel_z = 0;   // lane ii of these holds the ii-th selection of the block
+#pragma unroll 1
+        for (int ii = 0; ii < BLK; ++ii) {
+            // centroid = point (sl + 64*sj): registers of lane sl (uniform dynamic register index + v_readlane)
+            const int icx = __builtin_amdgcn_readlane(__float_as_int(fv_get<PPT>(px, sj)), sl);
+            const int icy = __builtin_amdgcn_readlane(__float_as_int(fv_get<PPT>(py, sj)), sl);
+            const int icz = __builtin_amdgcn_readlane(__float_as_int(fv_get<PPT>(pz, sj)), sl);
+            asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
+                         "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0"
+                         : "+v"(sel_i), "+v"(sel_x), "+v"(sel_y), "+v"(sel_z)
+                         : "s"(ii), "s"(sl + 64 * sj), "s"(icx), "s"(icy), "s"(icz)
+                         : "m0");
+            const float cx = __int_as_float(icx), cy = __int_as_float(icy), cz = __int_as_float(icz);
+            float bv;
+            if constexpr (PPT == 1) {
+                const float dx = __fsub_rn(fv_get<PPT>(px, 0), cx), dy = __fsub_rn(fv_get<PPT>(py, 0), cy), dz = __fsub_rn(fv_get<PPT>(pz, 0), cz);
+                bv = vmin_f32(fv_get<PPT>(run, 0), sumsq3(dx, dy, dz));
+                fv_set<PPT>(run, 0, bv);
+            } else {
+                // two points per packed instruction (v_pk_add/mul_f32 round each half like the scalar forms)
+                const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+                float r[PPT];
+#pragma unroll
+                for (int j = 0; j < PPT; j += 2) {
+                    const f32x2 x2 = {fv_get<PPT>(px, j), fv_get<PPT>(px, j + 1)};
+                    const f32x2 y2 = {fv_get<PPT>(py, j), fv_get<PPT>(py, j + 1)};
+                    const f32x2 z2 = {fv_get<PPT>(pz, j), fv_get<PPT>(pz, j + 1)};
+                    const f32x2 dx = x2 - cx2, dy = y2 - cy2, dz = z2 - cz2;
+                    const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                    r[j] = vmin_f32(fv_get<PPT>(run, j), d[0]);       // dist < distance ? dist : distance
+                    r[j + 1] = vmin_f32(fv_get<PPT>(run, j + 1), d[1]);
+                    fv_set<PPT>(run, j, r[j]);
+                    fv_set<PPT>(run, j + 1, r[j + 1]);
+                }
+                bv = vmax_f32(r[0], r[1]);
+#pragma unroll
+                for (int j = 2; j < PPT; j += 2) bv = vmax3_f32(bv, r[j], r[j + 1]);
+            }
+            const float wmax = wave_max_f32(bv);
+            // lowest point index holding the maximum: lowest j first, then lowest lane (torch.max on CPU keeps the first)
+            unsigned long long selm;
+            int selj;
+            fps_find<PPT, 0>(run, wmax, selj, selm);
+            sl = __builtin_amdgcn_readfirstlane(__ffsll((long long)selm) - 1);
+            sj = __builtin_amdgcn_readfirstlane(selj);
+        }
+        if (lane < BLK) {
+            out_idx[ib + lane] = sel_i;
+            float* o = out_xyz + (size_t)(ib + lane) * 3;
+            o[0] = __int_as_float(sel_x); o[1] = __int_as_float(sel_y); o[2] = __int_as_float(sel_z);
+            hand[ib + lane] = __int_as_float(sel_x); hand[kPoints + ib + lane] = __int_as_float(sel_y);
+            hand[2 * kPoints + ib + lane] = __int_as_float(sel_z);
+        }
+    }
+}
+
+template <int PPT>
+__device__ __forceinline__ void fps_load_hand(const float* hand, typename FpsVec<PPT>::type& px, typename FpsVec<PPT>::type& py,
+                                              typename FpsVec<PPT>::type& pz) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        fv_set<PPT>(px, j, hand[lane + 64 * j]);
+        fv_set<PPT>(py, j, hand[kPoints + lane + 64 * j]);
+        fv_set<PPT>(pz, j, hand[2 * kPoints + lane + 64 * j]);
+    }
+}
+
+__global__ __launch_bounds__(64) void fps_chain_reg_kernel(
+    const float* __restrict__ clouds, const int64_t* __restrict__ starts, int nc_step,
+    int* __restrict__ idx1, int* __restrict__ idx2, int* __restrict__ idx3, int* __restrict__ idx4,
+    float* __restrict__ xyz1, float* __restrict__ xyz2, float* __restrict__ xyz3, float* __restrict__ xyz4) {
+    __shared__ float hand[3 * kPoints];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int step = c / nc_step, cl = c - step * nc_step;
+    const float* src = clouds + (size_t)cl * kPoints * 3;
+    const int64_t* st4 = starts + (size_t)step * 4 * nc_step + cl;
+    const int s1 = (int)st4[0 * (size_t)nc_step], s2 = (int)st4[1 * (size_t)nc_step];
+    const int s3 = (int)st4[2 * (size_t)nc_step], s4 = (int)st4[3 * (size_t)nc_step];
+    {
+        FpsVec<16>::type px, py, pz;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = lane + 64 * j;
+            px[j] = src[p * 3 + 0]; py[j] = src[p * 3 + 1]; pz[j] = src[p * 3 + 2];
+        }
+        fps_level_reg<1024, 1024>(px, py, pz, s1, hand, idx1 + (size_t)c * 1024, xyz1 + (size_t)c * 1024 * 3);
+        // one wave: its LDS operations complete in program order, no barrier between the levels
+        fps_load_hand<16>(hand, px, py, pz);
+        fps_level_reg<1024, 256>(px, py, pz, s2, hand, idx2 + (size_t)c * 256, xyz2 + (size_t)c * 256 * 3);
+    }
+    {
+        FpsVec<4>::type px, py, pz;
+        fps_load_hand<4>(hand, px, py, pz);
+        fps_level_reg<256, 64>(px, py, pz, s3, hand, idx3 + (size_t)c * 64, xyz3 + (size_t)c * 64 * 3);
+    }
+    {
+        float px, py, pz;
+        fps_load_hand<1>(hand, px, py, pz);
+        fps_level_reg<64, 16>(px, py, pz, s4, hand, idx4 + (size_t)c * 16, xyz4 + (size_t)c * 16 * 3);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ball query: one wave per centroid scans the N source points in index order, 64 at a time, and
 // keeps the first 32 with NOT(d > r^2); unfilled slots repeat the first hit.  No sort.
 // Workgroup = 4 waves x CPW centroids each; the source cloud is staged once in LDS as (x,y,z,|p|^2).
 // ---------------------------------------------------------------------------------------------
 // src_mod > 0: the source clouds repeat with period src_mod (level-0 clouds of a multi-step batch), else one per cloud
+//
+// N >= 128: a lane tests TWO points per step (p = 128k + lane and p + 64) with packed fp32 instructions -- v_pk_mul /
+// v_pk_fma / v_pk_add round each half exactly like the scalar forms, so the d > r^2 decisions are unchanged -- and the
+// slot bookkeeping (prefix count, LDS store) only runs when one of the 128 points is inside the ball, which is rare at
+// the small radii of the fine levels.  The cloud is staged as pairs {x_a x_b y_a y_b | z_a z_b n_a n_b} so that a
+// lane's two points are two conflict-free ds_read_b128.
 template <int N>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
                                                          int S, float r2, int* __restrict__ out, int src_mod) {
     constexpr int CPW = 4;
-    __shared__ float4 pts[N];
+    constexpr bool PAIRED = N >= 128;
+    constexpr int NPAIR = PAIRED ? N / 128 : 1;
+    __shared__ f32x4 pts[PAIRED ? NPAIR * 2 * 64 : N];
     __shared__ int slots[4][kNSample];
     const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = xyz + (size_t)(src_mod > 0 ? c % src_mod : c) * N * 3;
     for (int p = tid; p < N; p += 256) {
         const float x = src[p * 3 + 0], y = src[p * 3 + 1], z = src[p * 3 + 2];
-        pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
+        const float n2 = sumsq3(x, y, z);
+        if constexpr (PAIRED) {
+            float* q = reinterpret_cast<float*>(&pts[((p >> 7) * 2) * 64 + (p & 63)]);
+            const int hb = (p >> 6) & 1;
+            q[hb] = x; q[2 + hb] = y; q[64 * 4 + hb] = z; q[64 * 4 + 2 + hb] = n2;
+        } else {
+            pts[p] = f32x4{x, y, z, n2};
+        }
     }
     __syncthreads();
     for (int q = 0; q < CPW; ++q) {
@@ -204,18 +387,44 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
         const float ax = cp[0], ay = cp[1], az = cp[2];
         const float a2 = sumsq3(ax, ay, az);
         int cnt = 0;
-        for (int base = 0; base < N && cnt < kNSample; base += 64) {
-            const int p = base + lane;
-            bool in = false;
-            if (p < N) {
-                const float4 b = pts[p];
-                const float d = sqdist_ref(ax, ay, az, a2, b.x, b.y, b.z, b.w);
-                in = !(d > r2);
+        if constexpr (PAIRED) {
+            const f32x2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, a22 = {a2, a2}, m2 = {-2.0f, -2.0f};
+            for (int k = 0; k < NPAIR; ++k) {
+                if (cnt >= kNSample) break;
+                const f32x4 u = pts[(k * 2) * 64 + lane], v = pts[(k * 2 + 1) * 64 + lane];
+                const f32x2 bx = {u[0], u[1]}, by = {u[2], u[3]}, bz = {v[0], v[1]}, b2 = {v[2], v[3]};
+                // common.hpp::sqdist_ref on both halves
+                f32x2 dot = ax2 * bx;
+                dot = __builtin_elementwise_fma(ay2, by, dot);
+                dot = __builtin_elementwise_fma(az2, bz, dot);
+                f32x2 d = m2 * dot;
+                d = d + a22;
+                d = d + b2;
+                const bool in_a = !(d[0] > r2), in_b = !(d[1] > r2);
+                const unsigned long long ma = __ballot(in_a), mb = __ballot(in_b);
+                if ((ma | mb) == 0ull) continue;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int pos_a = cnt + __popcll(ma & below);
+                if (in_a && pos_a < kNSample) slots[wave][pos_a] = k * 128 + lane;
+                cnt += __popcll(ma);
+                const int pos_b = cnt + __popcll(mb & below);
+                if (in_b && pos_b < kNSample) slots[wave][pos_b] = k * 128 + 64 + lane;
+                cnt += __popcll(mb);
             }
-            const unsigned long long m = __ballot(in);
-            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-            if (in && pos < kNSample) slots[wave][pos] = p;
-            cnt += __popcll(m);
+        } else {
+            for (int base = 0; base < N && cnt < kNSample; base += 64) {
+                const int p = base + lane;
+                bool in = false;
+                if (p < N) {
+                    const f32x4 b = pts[p];
+                    const float d = sqdist_ref(ax, ay, az, a2, b[0], b[1], b[2], b[3]);
+                    in = !(d > r2);
+                }
+                const unsigned long long m = __ballot(in);
+                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && pos < kNSample) slots[wave][pos] = p;
+                cnt += __popcll(m);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < kNSample) {
@@ -276,8 +485,13 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],
                       hipStream_t st) {
-    // >= 1024 clouds (two or more steps of a B=64 batch): one wave per cloud; otherwise four waves per cloud
-    if (num_clouds >= 1024)
+    // default: one wave per cloud, everything in registers (fps_chain_reg_kernel).  LSDM_FPS=lds selects the older forms
+    // for A/B measurements (>= 1024 clouds: one wave per cloud with LDS centroid fetch; otherwise four waves per cloud).
+    static const bool legacy = getenv("LSDM_FPS") && !strcmp(getenv("LSDM_FPS"), "lds");
+    if (!legacy)
+        hipLaunchKernelGGL(fps_chain_reg_kernel, dim3(num_clouds), dim3(64), 0, st, clouds, starts, nc_step, idx[0], idx[1], idx[2], idx[3],
+                           xyz[0], xyz[1], xyz[2], xyz[3]);
+    else if (num_clouds >= 1024)
         hipLaunchKernelGGL(fps_chain_wave_kernel, dim3(num_clouds), dim3(64), 0, st, clouds, starts, nc_step, idx[0], idx[1], idx[2], idx[3],
                            xyz[0], xyz[1], xyz[2], xyz[3]);
     else
