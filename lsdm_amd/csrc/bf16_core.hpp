@@ -117,16 +117,30 @@ __device__ __forceinline__ void mma_kloop_pre_h(f32x16 (&acc)[RB], const __bf16*
     const __bf16* xp = X + i * ldx + 8 * h;
     const size_t ws = (size_t)N * NP * 16;
     const __bf16* wp = Wp + ((size_t)(cb * 32 + i) * NP) * 16 + 8 * h + (size_t)kb0 * ws;
-#pragma unroll 1
+    // Weight fragments are requested TWO k-groups ahead (the loaded L2 latency is a multiple of the ~0.8k cycles one group
+    // of MFMAs lasts): `w` (group 0, requested by the caller) and `w2` (group 1) are in flight on entry; the buffer a group
+    // is copied out of is refilled at once with the group after next.  The tail group is requested up front as well.
+    WFrag<NP, U> w2;
+    if constexpr (NG > 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w2.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(U + u) * ws);
+            if constexpr (NP == 2) w2.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(U + u) * ws + 16);
+        }
+    }
+    [[maybe_unused]] WFrag<NP, kgroup(TAIL > 0 ? TAIL : 1)> wt;
+    if constexpr (TAIL > 0) wfrag_load<NP, TAIL>(wt, Wp, N, cb, kb0 + NG * U, lane);
+#pragma unroll
     for (int g = 0; g < NG; ++g) {
+        WFrag<NP, U>& src = (g & 1) ? w2 : w;
         bf16x8 ch[U], cl[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { ch[u] = w.h[u]; if constexpr (NP == 2) cl[u] = w.l[u]; }
-        if (g + 1 < NG) {
+        for (int u = 0; u < U; ++u) { ch[u] = src.h[u]; if constexpr (NP == 2) cl[u] = src.l[u]; }
+        if (g + 2 < NG) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                w.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws);
-                if constexpr (NP == 2) w.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 1) * U + u) * ws + 16);
+                src.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 2) * U + u) * ws);
+                if constexpr (NP == 2) src.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 2) * U + u) * ws + 16);
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this group's MFMAs
@@ -157,11 +171,7 @@ __device__ __forceinline__ void mma_kloop_pre_h(f32x16 (&acc)[RB], const __bf16*
             }
         }
     }
-    if constexpr (TAIL > 0) {
-        WFrag<NP, kgroup(TAIL)> wt;
-        wfrag_load<NP, TAIL>(wt, Wp, N, cb, kb0 + NG * U, lane);
-        mma_kloop_pre_h<RB, NP, WA, TAIL>(acc, X + NG * U * 16, ldx, plane, Wp, N, cb, kb0 + NG * U, lane, wt);
-    }
+    if constexpr (TAIL > 0) mma_kloop_pre_h<RB, NP, WA, TAIL>(acc, X + NG * U * 16, ldx, plane, Wp, N, cb, kb0 + NG * U, lane, wt);
 }
 
 template <int RB, int NP, bool WA, int NKB>

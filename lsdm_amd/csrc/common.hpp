@@ -22,6 +22,21 @@ __device__ __forceinline__ float reluf(float v) { return v > 0.0f ? v : 0.0f; }
 // C/D map of the 32x32 MFMA shapes (dtype-independent on gfx950): col = lane & 31, row = acc_row(r, lane)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// XCD-aware work-group remap.  MI355X dispatches work-group b to XCD b % 8 and every XCD has its own 4 MiB L2, so work-groups
+// that share operands (the tiles of one cloud gather rows of the same level tensors) should sit on ONE XCD.  Returns a virtual
+// id such that each XCD owns one contiguous range of ids; bijective for any grid size.  A pure speed choice: results do not
+// depend on placement.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+// 1-D grid of tiles_per_cloud * num_clouds work-groups -> (cloud, tile)
+__device__ __forceinline__ void xcd_cloud_tile(int tiles_per_cloud, int& cloud, int& tile) {
+    const int v = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    cloud = v / tiles_per_cloud;
+    tile = v - cloud * tiles_per_cloud;
+}
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
 
 template <int ACT>

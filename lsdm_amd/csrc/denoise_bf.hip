@@ -100,7 +100,9 @@ __global__ __launch_bounds__(NT) void denoise_h_kernel(DenoiseHParams P, StepCoe
     float* gt = xt + TM * 3;          // guiding-point tile
     float* res = gt + TM * 3;         // denoiser output tile
     float* oterm = res + TM * 3;      // W15[c, 3:15] . o[b,o',:]   (27 values)
-    const int b = blockIdx.y, n0 = blockIdx.x * TM;
+    int b, tile;
+    xcd_cloud_tile(kPoints / TM, b, tile);   // the tiles of one chain share its h2p / pcd rows: keep them on one XCD
+    const int n0 = tile * TM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* pcd_b = pcd + (size_t)b * kSlots * kPoints * 3;
     const float* w_b = w + (size_t)b * kSlots;
@@ -214,10 +216,10 @@ void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int 
                       const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
     const __bf16* h2 = static_cast<const __bf16*>(h2p);
     if (np == 2)
-        hipLaunchKernelGGL(denoise_h_kernel<2>, dim3(kPoints / TM, B), dim3(NT), 0, st, P, sc, mode, eta, B, x, t, mask, pcd, w, o12, hm, h2,
+        hipLaunchKernelGGL(denoise_h_kernel<2>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, x, t, mask, pcd, w, o12, hm, h2,
                            noise, out_x0, out_guiding, out_sample);
     else
-        hipLaunchKernelGGL(denoise_h_kernel<1>, dim3(kPoints / TM, B), dim3(NT), 0, st, P, sc, mode, eta, B, x, t, mask, pcd, w, o12, hm, h2,
+        hipLaunchKernelGGL(denoise_h_kernel<1>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, x, t, mask, pcd, w, o12, hm, h2,
                            noise, out_x0, out_guiding, out_sample);
 }
 

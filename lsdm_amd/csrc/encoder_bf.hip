@@ -41,8 +41,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (PA + PB)];
     __bf16* bufA = smem;
     __bf16* bufB = smem + NP * PA;
-    const int c = blockIdx.y, tid = threadIdx.x;
-    const int s0 = blockIdx.x * (TM / 32);
+    int c, tile;
+    xcd_cloud_tile(S / (TM / 32), c, tile);
+    const int tid = threadIdx.x;
+    const int s0 = tile * (TM / 32);
     const float* xyz = src_xyz + (size_t)c * NSRC * 3;
     const int* bl = ball + ((size_t)c * S + s0) * kNSample;
     const float* cen = new_xyz + ((size_t)c * S + s0) * 3;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     PHASE_MARK(PS + 6);
 #ifdef LSDM_PHASE_TIMING
     if (threadIdx.x == 0) {
-        unsigned long long* g = g_phase + ((blockIdx.x + blockIdx.y * 7) & 63) * 64 + PS;
+        unsigned long long* g = g_phase + (blockIdx.x & 63) * 64 + PS;
         for (int i = 0; i < 7; ++i) atomicAdd(g + i, pd_[i]);
         atomicAdd(g + 7, 1ull);
     }
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
     __shared__ __attribute__((aligned(16))) __bf16 smem[SMEM];
     __bf16* bufX = smem;
     __bf16* bufB = HEAD ? smem + NP * PX : smem;
-    const int c = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n0 = blockIdx.x * TM;
+    int c, tile;
+    xcd_cloud_tile(N / TM, c, tile);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = tile * TM;
     const feat_t* p1 = D1 > 0 ? points1 + ((size_t)c * N + n0) * D1 : nullptr;
     const feat_t* p2 = points2 + (size_t)c * S * D2;
     const int* ni = nn_idx + ((size_t)c * N + n0) * 3;
@@ -332,13 +336,13 @@ static void launch_sa_h_t(int level, int nc, const float* src_xyz, const void* s
     const F* sf = static_cast<const F*>(src_feat);
     F* o = static_cast<F*>(out);
     switch (level) {
-        case 0: hipLaunchKernelGGL((sa_h_kernel<3, 32, 32, 64, 128, 4, NP>), dim3(1024 / 4, nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
+        case 0: hipLaunchKernelGGL((sa_h_kernel<3, 32, 32, 64, 128, 4, NP>), dim3(1024 / 4 * nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
                                    ball, 1024, 1024, l[0], l[1], l[2], o); break;
-        case 1: hipLaunchKernelGGL((sa_h_kernel<64, 64, 64, 128, 128, 4, NP>), dim3(256 / 4, nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
+        case 1: hipLaunchKernelGGL((sa_h_kernel<64, 64, 64, 128, 128, 4, NP>), dim3(256 / 4 * nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
                                    ball, 1024, 256, l[0], l[1], l[2], o); break;
-        case 2: hipLaunchKernelGGL((sa_h_kernel<128, 128, 128, 256, 64, 4, NP>), dim3(64 / 2, nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
+        case 2: hipLaunchKernelGGL((sa_h_kernel<128, 128, 128, 256, 64, 4, NP>), dim3(64 / 2 * nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
                                    ball, 256, 64, l[0], l[1], l[2], o); break;
-        case 3: hipLaunchKernelGGL((sa_h_kernel<256, 256, 256, 512, 64, 8, NP>), dim3(16 / 2, nc), dim3(512), 0, st, src_xyz, sf, new_xyz,
+        case 3: hipLaunchKernelGGL((sa_h_kernel<256, 256, 256, 512, 64, 8, NP>), dim3(16 / 2 * nc), dim3(512), 0, st, src_xyz, sf, new_xyz,
                                    ball, 64, 16, l[0], l[1], l[2], o); break;
     }
 }
@@ -352,13 +356,13 @@ static void launch_fp_h_t(int which, int nc, const void* points1, const void* po
     const DenseH none{nullptr, nullptr};
     const Lin nol{nullptr, nullptr};
     switch (which) {
-        case 4: hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, NP>), dim3(64 / 64, nc), dim3(256), 0, st, p1, p2,
+        case 4: hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, NP>), dim3(64 / 64 * nc), dim3(256), 0, st, p1, p2,
                                    nn_idx, nn_w, 64, 16, l[0], l[1], none, none, nol, out); break;
-        case 3: hipLaunchKernelGGL((fp_h_kernel<128, 256, 256, 256, 0, false, 64, 128, 4, NP>), dim3(256 / 64, nc), dim3(256), 0, st, p1, p2,
+        case 3: hipLaunchKernelGGL((fp_h_kernel<128, 256, 256, 256, 0, false, 64, 128, 4, NP>), dim3(256 / 64 * nc), dim3(256), 0, st, p1, p2,
                                    nn_idx, nn_w, 256, 64, l[0], l[1], none, none, nol, out); break;
-        case 2: hipLaunchKernelGGL((fp_h_kernel<64, 256, 256, 128, 0, false, 64, 64, 4, NP>), dim3(1024 / 64, nc), dim3(256), 0, st, p1, p2,
+        case 2: hipLaunchKernelGGL((fp_h_kernel<64, 256, 256, 128, 0, false, 64, 64, 4, NP>), dim3(1024 / 64 * nc), dim3(256), 0, st, p1, p2,
                                    nn_idx, nn_w, 1024, 256, l[0], l[1], none, none, nol, out); break;
-        case 1: hipLaunchKernelGGL((fp_h_kernel<0, 128, 128, 128, 128, true, 64, 128, 4, NP>), dim3(1024 / 64, nc), dim3(256), 0, st, p1, p2,
+        case 1: hipLaunchKernelGGL((fp_h_kernel<0, 128, 128, 128, 128, true, 64, 128, 4, NP>), dim3(1024 / 64 * nc), dim3(256), 0, st, p1, p2,
                                    nn_idx, nn_w, 1024, 1024, l[0], l[1], l[2], head1[0], head2, out); break;
     }
 }

@@ -144,7 +144,12 @@ __global__ __launch_bounds__(NW * 64) void sa_r_kernel(const float* __restrict__
     const float* b3 = bl + C1 + C2;
     const int p = lane & 31, h = lane >> 5;
 
-    for (long long cent = (long long)blockIdx.x * NW + wave; cent < total_centroids; cent += (long long)gridDim.x * NW) {
+    // each work-group owns one contiguous chunk of centroids, and the chunks of the work-groups of one XCD are adjacent
+    // (common.hpp::xcd_remap): the rows a chunk gathers stay in that XCD's L2
+    const long long chunk = ((total_centroids + gridDim.x - 1) / gridDim.x + NW - 1) / NW * NW;
+    const long long cbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk;
+    const long long cend = cbeg + chunk < total_centroids ? cbeg + chunk : total_centroids;
+    for (long long cent = cbeg + wave; cent < cend; cent += NW) {
         const long long c = cent / S;                                  // cloud
         const int idx = ball[cent * kNSample + p];
         const float* xyz = src_xyz + ((size_t)c * NSRC + idx) * 3;
@@ -267,7 +272,10 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
     __syncthreads();
 
     const long long rounds = (total_centroids + NW - 1) / NW;
-    for (long long rd = blockIdx.x; rd < rounds; rd += gridDim.x) {
+    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
+    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
+    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    for (long long rd = rbeg; rd < rend; ++rd) {
         long long cent = rd * NW + wave;
         const bool live = cent < total_centroids;
         if (!live) cent = total_centroids - 1;                              // keep the barriers convergent; results discarded

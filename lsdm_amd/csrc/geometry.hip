@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
     constexpr int NPAIR = PAIRED ? N / 128 : 1;
     __shared__ f32x4 pts[PAIRED ? NPAIR * 2 * 64 : N];
     __shared__ int slots[4][kNSample];
-    const int c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c, tile;
+    xcd_cloud_tile((S + 15) / 16, c, tile);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = xyz + (size_t)(src_mod > 0 ? c % src_mod : c) * N * 3;
     for (int p = tid; p < N; p += 256) {
         const float x = src[p * 3 + 0], y = src[p * 3 + 1], z = src[p * 3 + 2];
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
     }
     __syncthreads();
     for (int q = 0; q < CPW; ++q) {
-        const int s = (blockIdx.x * 4 + wave) * CPW + q;
+        const int s = (tile * 4 + wave) * CPW + q;
         if (s >= S) break;  // wave-uniform
         const float* cp = new_xyz + ((size_t)c * S + s) * 3;
         const float ax = cp[0], ay = cp[1], az = cp[2];
@@ -446,14 +448,16 @@ template <int S>
 __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__ fine, const float* __restrict__ coarse, int N,
                                                        int* __restrict__ out_idx, float* __restrict__ out_w, int fine_mod) {
     __shared__ float4 pts[S];
-    const int c = blockIdx.y, tid = threadIdx.x;
+    int c, tile;
+    xcd_cloud_tile((N + 255) / 256, c, tile);
+    const int tid = threadIdx.x;
     const float* src = coarse + (size_t)c * S * 3;
     for (int p = tid; p < S; p += 256) {
         const float x = src[p * 3 + 0], y = src[p * 3 + 1], z = src[p * 3 + 2];
         pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
     }
     __syncthreads();
-    const int n = blockIdx.x * 256 + tid;
+    const int n = tile * 256 + tid;
     if (n >= N) return;
     const float* fp = fine + ((size_t)(fine_mod > 0 ? c % fine_mod : c) * N + n) * 3;
     const float ax = fp[0], ay = fp[1], az = fp[2];
@@ -501,7 +505,7 @@ void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds
 
 void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod,
                        hipStream_t st) {
-    dim3 grid((S + 15) / 16, num_clouds), block(256);
+    dim3 grid((S + 15) / 16 * num_clouds), block(256);
     switch (N) {
         case 1024: hipLaunchKernelGGL(ball_query_kernel<1024>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
         case 256: hipLaunchKernelGGL(ball_query_kernel<256>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
@@ -511,7 +515,7 @@ void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, i
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,
                      hipStream_t st) {
-    dim3 grid((N + 255) / 256, num_clouds), block(256);
+    dim3 grid((N + 255) / 256 * num_clouds), block(256);
     switch (S) {
         case 1024: hipLaunchKernelGGL(three_nn_kernel<1024>, grid, block, 0, st, fine, coarse, N, out_idx, out_w, fine_mod); break;
         case 256: hipLaunchKernelGGL(three_nn_kernel<256>, grid, block, 0, st, fine, coarse, N, out_idx, out_w, fine_mod); break;
