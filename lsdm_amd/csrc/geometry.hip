@@ -8,188 +8,25 @@
 // discrete decisions (arg-max, d > r^2, nearest-3) are index-exact against the CPU oracle.
 // Built with -ffp-contract=off; explicit __f*_rn intrinsics are used where the order matters.
 #include "common.hpp"
-#include <cstdlib>
-#include <cstring>
 
 namespace lsdm {
 
 // ---------------------------------------------------------------------------------------------
-// wave64 max of a 64-bit key with DPP (no LDS traffic); result broadcast from lane 63.
-// ---------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
-    unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
-    unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    return o > v ? o : v;
-}
-
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-    v = dpp_max_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v = dpp_max_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v = dpp_max_step<0x141, 0xf>(v);  // row_half_mirror
-    v = dpp_max_step<0x140, 0xf>(v);  // row_mirror
-    v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-    v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
-    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// ---------------------------------------------------------------------------------------------
-// FPS: one 256-thread workgroup per cloud runs the four chained levels (1024->1024->256->64->16).
-// Points and running minima live in registers; the chosen centroid is re-read from LDS (broadcast).
-// Arg-max key = (bits(running_min) << 32) | (~index): distances are >= 0 so the bit pattern is
-// monotone, and ties resolve to the lowest index like torch.max on CPU (pointnet2_utils.py:80).
-// ---------------------------------------------------------------------------------------------
-template <int N, int NP>
-__device__ __forceinline__ int fps_level(const float* __restrict__ src, float* __restrict__ dst, int start,
-                                          int* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                          unsigned long long (*red)[4]) {
-    constexpr int PPT = (N + 255) / 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float px[PPT], py[PPT], pz[PPT], run[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int p = tid + 256 * j;
-        const bool valid = p < N;
-        px[j] = valid ? src[p * 3 + 0] : 0.0f;
-        py[j] = valid ? src[p * 3 + 1] : 0.0f;
-        pz[j] = valid ? src[p * 3 + 2] : 0.0f;
-        run[j] = 1e10f;
-    }
-    int far = start;
-    for (int i = 0; i < NP; ++i) {
-        const float cx = src[far * 3 + 0], cy = src[far * 3 + 1], cz = src[far * 3 + 2];
-        if (tid == 0) {
-            out_idx[i] = far;
-            dst[i * 3 + 0] = cx; dst[i * 3 + 1] = cy; dst[i * 3 + 2] = cz;
-            out_xyz[i * 3 + 0] = cx; out_xyz[i * 3 + 1] = cy; out_xyz[i * 3 + 2] = cz;
-        }
-        unsigned long long best = 0ull;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int p = tid + 256 * j;
-            const float dx = __fsub_rn(px[j], cx), dy = __fsub_rn(py[j], cy), dz = __fsub_rn(pz[j], cz);
-            const float d = sumsq3(dx, dy, dz);
-            run[j] = d < run[j] ? d : run[j];
-            unsigned long long key = ((unsigned long long)__float_as_uint(run[j]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
-            if (p >= N) key = 0ull;
-            best = key > best ? key : best;
-        }
-        best = wave_max_u64(best);
-        if (lane == 0) red[i & 1][wave] = best;
-        __syncthreads();
-        unsigned long long b0 = red[i & 1][0], b1 = red[i & 1][1], b2 = red[i & 1][2], b3 = red[i & 1][3];
-        b0 = b1 > b0 ? b1 : b0;
-        b2 = b3 > b2 ? b3 : b2;
-        b0 = b2 > b0 ? b2 : b0;
-        far = (int)(0xFFFFFFFFu - (unsigned)b0);
-    }
-    __syncthreads();
-    return far;
-}
-
+// FPS (fps_chain_reg_kernel): one WAVE per cloud runs the four chained levels (1024->1024->256->64->16) entirely in
+// registers.  The lanes hold N/64 points each (point p = lane + 64*j) as register vectors with their running minima.
+// Per iteration
+//   * a lane keeps only the MAXIMUM of its running minima (v_min + half a v_max3 per point; no index bookkeeping);
+//   * the wave maximum is a 32-bit DPP reduction (six v_max_f32 with a DPP source);
+//   * the winner is located by comparing the registers against that maximum in increasing j with early exit: lowest j,
+//     then lowest lane = lowest point index -- ties resolve like torch.max on CPU (pointnet2_utils.py:80);
+//   * its coordinates are read straight out of the owning lane's registers (uniform dynamic register index + v_readlane):
+//     no LDS access and no memory latency inside the dependent chain.
+// The selections of 64 consecutive iterations are collected one per lane (v_writelane) and flushed as coalesced stores.
+// LDS is only the 12 KiB hand-over buffer between levels, so 13 waves fit a CU; the batched launches of the multi-step
+// entry point (>= 4 clouds per SIMD) are bound by VALU issue, not by the length of the dependent chain.
 // Batched launches cover G consecutive steps of one chain batch: cloud c of the launch is cloud (c % nc_step) of step
 // (c / nc_step) -- the same input cloud every step, with that step's start draws starts[(step*4 + level)*nc_step + cloud]
 // (the (K,4,B*9) layout of lsdm_sample_steps).  A single-step launch has nc_step == number of clouds.
-__global__ __launch_bounds__(256) void fps_chain_kernel(
-    const float* __restrict__ clouds, const int64_t* __restrict__ starts, int nc_step,
-    int* __restrict__ idx1, int* __restrict__ idx2, int* __restrict__ idx3, int* __restrict__ idx4,
-    float* __restrict__ xyz1, float* __restrict__ xyz2, float* __restrict__ xyz3, float* __restrict__ xyz4) {
-    __shared__ float bufA[kPoints * 3];
-    __shared__ float bufB[kPoints * 3];
-    __shared__ unsigned long long red[2][4];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const int step = c / nc_step, cl = c - step * nc_step;
-    const float* src = clouds + (size_t)cl * kPoints * 3;
-    for (int i = tid; i < kPoints * 3; i += 256) bufA[i] = src[i];
-    __syncthreads();
-    const int64_t* st4 = starts + (size_t)step * 4 * nc_step + cl;
-    const int s1 = (int)st4[0 * (size_t)nc_step], s2 = (int)st4[1 * (size_t)nc_step];
-    const int s3 = (int)st4[2 * (size_t)nc_step], s4 = (int)st4[3 * (size_t)nc_step];
-    fps_level<1024, 1024>(bufA, bufB, s1, idx1 + (size_t)c * 1024, xyz1 + (size_t)c * 1024 * 3, red);
-    fps_level<1024, 256>(bufB, bufA, s2, idx2 + (size_t)c * 256, xyz2 + (size_t)c * 256 * 3, red);
-    fps_level<256, 64>(bufA, bufB, s3, idx3 + (size_t)c * 64, xyz3 + (size_t)c * 64 * 3, red);
-    fps_level<64, 16>(bufB, bufA, s4, idx4 + (size_t)c * 16, xyz4 + (size_t)c * 16 * 3, red);
-}
-
-// ---------------------------------------------------------------------------------------------
-// FPS, one WAVE per cloud (used for batched launches of >= 1024 clouds): the lanes hold N/64 points each in registers
-// (point p = lane + 64*j) with their running minima; no workgroup barrier, no cross-wave exchange -- 40 % fewer VALU
-// instructions per cloud-iteration than the 4-wave form, but a longer dependent chain per iteration, so it only pays
-// once every SIMD has several independent clouds to interleave (geometry of G steps in one launch).
-// ---------------------------------------------------------------------------------------------
-template <int N, int NP>
-__device__ __forceinline__ void fps_level_wave(const float4* __restrict__ src, float4* __restrict__ dst, int start,
-                                               int* __restrict__ out_idx, float* __restrict__ out_xyz) {
-    constexpr int PPT = (N + 63) / 64;
-    const int lane = threadIdx.x;
-    float px[PPT], py[PPT], pz[PPT], run[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int p = lane + 64 * j;
-        const float4 v = p < N ? src[p] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        px[j] = v.x; py[j] = v.y; pz[j] = v.z;
-        run[j] = 1e10f;
-    }
-    int far = start;
-    for (int i = 0; i < NP; ++i) {
-        const float4 cen = src[far];
-        if (lane == 0) {
-            out_idx[i] = far;
-            dst[i] = cen;
-            out_xyz[i * 3 + 0] = cen.x; out_xyz[i * 3 + 1] = cen.y; out_xyz[i * 3 + 2] = cen.z;
-        }
-        float bv = -1.0f;
-        int bi = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float dx = __fsub_rn(px[j], cen.x), dy = __fsub_rn(py[j], cen.y), dz = __fsub_rn(pz[j], cen.z);
-            const float d = sumsq3(dx, dy, dz);
-            run[j] = d < run[j] ? d : run[j];
-            const int p = lane + 64 * j;
-            // strictly greater: the lane's points are visited in increasing index order, so ties keep the lowest index
-            if (p < N && run[j] > bv) { bv = run[j]; bi = p; }
-        }
-        unsigned long long key = 0ull;
-        if (bv >= 0.0f) key = ((unsigned long long)__float_as_uint(bv) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)bi);
-        key = wave_max_u64(key);
-        far = (int)(0xFFFFFFFFu - (unsigned)key);
-    }
-}
-
-__global__ __launch_bounds__(64) void fps_chain_wave_kernel(
-    const float* __restrict__ clouds, const int64_t* __restrict__ starts, int nc_step,
-    int* __restrict__ idx1, int* __restrict__ idx2, int* __restrict__ idx3, int* __restrict__ idx4,
-    float* __restrict__ xyz1, float* __restrict__ xyz2, float* __restrict__ xyz3, float* __restrict__ xyz4) {
-    __shared__ float4 bufA[kPoints];
-    __shared__ float4 bufB[kPoints];
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int step = c / nc_step, cl = c - step * nc_step;
-    const float* src = clouds + (size_t)cl * kPoints * 3;
-    for (int p = lane; p < kPoints; p += 64) bufA[p] = make_float4(src[p * 3 + 0], src[p * 3 + 1], src[p * 3 + 2], 0.0f);
-    const int64_t* st4 = starts + (size_t)step * 4 * nc_step + cl;
-    const int s1 = (int)st4[0 * (size_t)nc_step], s2 = (int)st4[1 * (size_t)nc_step];
-    const int s3 = (int)st4[2 * (size_t)nc_step], s4 = (int)st4[3 * (size_t)nc_step];
-    // one wave: its LDS operations complete in program order, no barriers between the levels
-    fps_level_wave<1024, 1024>(bufA, bufB, s1, idx1 + (size_t)c * 1024, xyz1 + (size_t)c * 1024 * 3);
-    fps_level_wave<1024, 256>(bufB, bufA, s2, idx2 + (size_t)c * 256, xyz2 + (size_t)c * 256 * 3);
-    fps_level_wave<256, 64>(bufA, bufB, s3, idx3 + (size_t)c * 64, xyz3 + (size_t)c * 64 * 3);
-    fps_level_wave<64, 16>(bufB, bufA, s4, idx4 + (size_t)c * 16, xyz4 + (size_t)c * 16 * 3);
-}
-
-// ---------------------------------------------------------------------------------------------
-// FPS, one wave per cloud, points AND centroid fetch in registers (fps_chain_reg_kernel): the lanes hold N/64 points
-// each (point p = lane + 64*j) as register vectors.  Per iteration a lane keeps only the MAXIMUM of its running minima
-// (one v_max per point instead of compare + two selects); the wave maximum is a 32-bit DPP reduction; the winner is then
-// located with one v_cmp_eq per register (lowest j, then lowest lane = lowest point index, like torch.max on CPU) and
-// its coordinates are read straight out of the owning lane's registers (uniform dynamic register index + v_readlane) --
-// no LDS access and no memory latency inside the dependent chain.  The selections of 64 consecutive iterations are
-// collected one per lane and flushed as coalesced stores.  LDS is only the 12 KiB hand-over buffer between levels, so
-// 12 waves fit a CU and the VALU (not latency) bounds the kernel.  ~45 % fewer VALU instructions per iteration than
-// fps_level_wave.
 // ---------------------------------------------------------------------------------------------
 template <int PPT> struct FpsVec { typedef float type __attribute__((ext_vector_type(PPT))); };
 template <> struct FpsVec<1> { typedef float type; };
@@ -489,18 +326,8 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],
                       hipStream_t st) {
-    // default: one wave per cloud, everything in registers (fps_chain_reg_kernel).  LSDM_FPS=lds selects the older forms
-    // for A/B measurements (>= 1024 clouds: one wave per cloud with LDS centroid fetch; otherwise four waves per cloud).
-    static const bool legacy = getenv("LSDM_FPS") && !strcmp(getenv("LSDM_FPS"), "lds");
-    if (!legacy)
-        hipLaunchKernelGGL(fps_chain_reg_kernel, dim3(num_clouds), dim3(64), 0, st, clouds, starts, nc_step, idx[0], idx[1], idx[2], idx[3],
-                           xyz[0], xyz[1], xyz[2], xyz[3]);
-    else if (num_clouds >= 1024)
-        hipLaunchKernelGGL(fps_chain_wave_kernel, dim3(num_clouds), dim3(64), 0, st, clouds, starts, nc_step, idx[0], idx[1], idx[2], idx[3],
-                           xyz[0], xyz[1], xyz[2], xyz[3]);
-    else
-        hipLaunchKernelGGL(fps_chain_kernel, dim3(num_clouds), dim3(256), 0, st, clouds, starts, nc_step, idx[0], idx[1], idx[2], idx[3],
-                           xyz[0], xyz[1], xyz[2], xyz[3]);
+    hipLaunchKernelGGL(fps_chain_reg_kernel, dim3(num_clouds), dim3(64), 0, st, clouds, starts, nc_step, idx[0], idx[1], idx[2], idx[3],
+                       xyz[0], xyz[1], xyz[2], xyz[3]);
 }
 
 void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod,

@@ -121,9 +121,9 @@ def test_fps_ball_threenn_index_exact(model13, sd13, golden):
         assert maxabs(ow[keep], taps[name + ".nn_w"][keep]) <= 1e-6, name
 
 
-def test_fps_one_wave_per_cloud_form_index_exact(model13, sd13):
-    """Launches of >= 1024 clouds (the geometry of several steps batched into one launch) run FPS with one wave per cloud;
-    same selections as the oracle, including the degenerate all-zero cloud."""
+def test_fps_large_batched_launch_index_exact(model13, sd13):
+    """A launch of > 1024 clouds (the geometry of several steps batched into one launch, several waves per SIMD): same
+    selections as the oracle for every replica, including the degenerate all-zero cloud."""
     ctx = model13._ctx
     base = _clouds()
     reps = 231                                   # 5 x 231 = 1155 clouds
