@@ -146,6 +146,36 @@ def test_fps_large_batched_launch_index_exact(model13, sd13):
         assert maxabs(xyz[l], taps["sa%d.new_xyz" % (l + 1)].repeat(reps, 1, 1)) == 0.0
 
 
+def test_ball_query_grid_edge_cases_index_exact(model13):
+    """The finest-level ball query prunes candidates through a 16^3 grid (geometry.hip::ball_query_grid_kernel).  Shapes
+    that stress it: a cloud much smaller than a cell (every point in one cell: the crowded path / ordered scan), a thin
+    slab (anisotropic extents, cells larger than r on two axes), a cloud with duplicated points, points exactly on the
+    bounding box, and a wide sparse cloud (most balls hold only the centroid).  Index-exact against the oracle's
+    query_ball_point with the centroids in a random (FPS-like) order."""
+    ctx = model13._ctx
+    g = torch.Generator().manual_seed(77)
+    N = 1024
+    clouds = [
+        torch.rand(N, 3, generator=g) * 0.05 + 1.0,                                   # one cell, non-degenerate
+        torch.rand(N, 3, generator=g) * torch.tensor([0.04, 1.5, 1.5]),                # thin slab
+        torch.rand(N, 3, generator=g).mul(0.8)[torch.randint(0, 700, (N,), generator=g)],   # ~300 duplicated points
+        torch.cat([torch.tensor([[0.0, 0.0, 0.0], [1.6, 1.6, 1.6]]), torch.rand(N - 2, 3, generator=g) * 1.6]),
+        torch.randn(N, 3, generator=g) * 3.0,                                          # wide and sparse
+        torch.randn(N, 3, generator=g) * torch.tensor([0.25, 0.25, 0.45]),             # the human-branch shape
+    ]
+    xyz = torch.stack(clouds).contiguous()
+    nc = xyz.shape[0]
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(nc)])
+    new_xyz = torch.gather(xyz, 1, perm[:, :, None].expand(-1, -1, 3)).contiguous()
+    want = cpu_ref.query_ball_point(0.1, 32, xyz, new_xyz)
+    d_xyz, d_new = xyz.to(DEV), new_xyz.to(DEV)
+    out = torch.empty(nc, N, 32, dtype=torch.int32, device=DEV)
+    ctx.call("lsdm_ball_query", d_xyz.data_ptr(), d_new.data_ptr(), nc, N, N, 0.1, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    for c in range(nc):
+        assert torch.equal(out[c].cpu().long(), want[c]), "cloud %d" % c
+
+
 def test_geometry_matches_reference_goldens(model13, golden):
     """G3: indices recorded from the real reference's farthest_point_sample / query_ball_point."""
     g = golden("g3_pointnet")
