@@ -218,9 +218,9 @@ __device__ __forceinline__ void store_lds_h(const f32x16 (&acc)[RB], int rb0, in
         const int n = cb * 32 + 8 * q + 4 * h;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            store_split4<NP>(out + ((rb0 + rb) * 32 + p) * ldo + n, plane, apply_act<ACT>(acc[rb][4 * q + 0] + bv[q][0]),
-                             apply_act<ACT>(acc[rb][4 * q + 1] + bv[q][1]), apply_act<ACT>(acc[rb][4 * q + 2] + bv[q][2]),
-                             apply_act<ACT>(acc[rb][4 * q + 3] + bv[q][3]));
+            store_split4<NP>(out + ((rb0 + rb) * 32 + p) * ldo + n, plane, apply_act_fast<ACT>(acc[rb][4 * q + 0] + bv[q][0]),
+                             apply_act_fast<ACT>(acc[rb][4 * q + 1] + bv[q][1]), apply_act_fast<ACT>(acc[rb][4 * q + 2] + bv[q][2]),
+                             apply_act_fast<ACT>(acc[rb][4 * q + 3] + bv[q][3]));
         }
     }
 }

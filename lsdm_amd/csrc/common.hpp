@@ -19,6 +19,24 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 __device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
 __device__ __forceinline__ float reluf(float v) { return v > 0.0f ? v : 0.0f; }
 
+// Activations of the split-bf16 dense stacks (bf16x3 / bf16 modes): the same functions evaluated with the hardware
+// exp2 / reciprocal (1 ulp each) instead of libm's erff / expf / IEEE division -- the denoiser applies ~640 GELU / sigmoid
+// evaluations per point and VALU time adds to MFMA time on gfx950 (DESIGN.md "What a SIMD does ...").
+//   GELU: Phi(v) through Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), written so that the negative branch has no
+//   cancellation: Phi(-|v|) = P(t) e^{-x^2} / 2,  Phi(|v|) = 1 - P(t) e^{-x^2} / 2,  x = |v| / sqrt(2), t = 1 / (1 + p x).
+// Absolute error of gelu_fast <= |v| * 1.1e-7, of sigmoid_fast <= 3e-7; the exact-f32 mode keeps gelu / sigmoidf above.
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float pl = fmaf(t, 1.061405429f, -1.453152027f);
+    pl = fmaf(t, pl, 1.421413741f);
+    pl = fmaf(t, pl, -0.284496736f);
+    pl = fmaf(t, pl, 0.254829592f);
+    const float q = 0.5f * (pl * t) * __expf(-x * x);
+    return v * (v < 0.0f ? q : 1.0f - q);
+}
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 // C/D map of the 32x32 MFMA shapes (dtype-independent on gfx950): col = lane & 31, row = acc_row(r, lane)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -38,6 +56,14 @@ __device__ __forceinline__ void xcd_cloud_tile(int tiles_per_cloud, int& cloud, 
 }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SIGMOID = 3 };
+
+template <int ACT>
+__device__ __forceinline__ float apply_act_fast(float v) {
+    if constexpr (ACT == ACT_RELU) return reluf(v);
+    else if constexpr (ACT == ACT_GELU) return gelu_fast(v);
+    else if constexpr (ACT == ACT_SIGMOID) return sigmoid_fast(v);
+    else return v;
+}
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {

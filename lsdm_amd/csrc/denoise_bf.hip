@@ -43,7 +43,7 @@ __device__ __forceinline__ void denoiser_pass_h(const DenoiseHParams& P, const f
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float* w = P.pose0.w + (j0 + j) * 3;
-            v[j] = sigmoidf(fmaf(z2, w[2], fmaf(z1, w[1], z0 * w[0])) + P.pose0.b[j0 + j]);
+            v[j] = sigmoid_fast(fmaf(z2, w[2], fmaf(z1, w[1], z0 * w[0])) + P.pose0.b[j0 + j]);
         }
         store_split4<NP>(R3 + row * LD3 + j0, P3, v[0], v[1], v[2], v[3]);
     }
@@ -77,7 +77,7 @@ __device__ __forceinline__ void denoiser_pass_h(const DenoiseHParams& P, const f
         float s = 0.0f;
 #pragma unroll 8
         for (int k = 0; k < 64; ++k) s = fmaf(lds_val<NP>(a + k, P3), w[k], s);
-        res[e] = gelu(s + P.fin2.b[c]);
+        res[e] = gelu_fast(s + P.fin2.b[c]);
     }
     __syncthreads();
 }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT) void denoise_h_kernel(DenoiseHParams P, StepCoe
         for (int op = 0; op < kSlots; ++op) {
             const float p0 = scrambled_h(pcd_b, w_b, op, n, 0), p1 = scrambled_h(pcd_b, w_b, op, n, 1), p2 = scrambled_h(pcd_b, w_b, op, n, 2);
             float s = fmaf(p2, P.pwt.w[c * 15 + 2], fmaf(p1, P.pwt.w[c * 15 + 1], p0 * P.pwt.w[c * 15]));
-            s = gelu(s + oterm[op * 3 + c] + P.pwt.b[c]);
+            s = gelu_fast(s + oterm[op * 3 + c] + P.pwt.b[c]);
             // (N,-1,B,O) view: the multiplier of flat element f is mask.flatten()[f % (B*O)]  (Q2)
             const long long f = (((long long)b * kSlots + op) * kPoints + n) * 3 + c;
             acc += s * mask[f % ((long long)B * kSlots)];
@@ -171,8 +171,8 @@ __global__ __launch_bounds__(NT) void denoise_h_kernel(DenoiseHParams P, StepCoe
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const int n = (wave + q * TS::CSTEP) * 32 + 8 * qd + 4 * h;
-                    store_split4<NP>(R0 + (rb * 32 + p) * LD0 + n, P0, gelu(acc[q][rb][4 * qd + 0] + bp), gelu(acc[q][rb][4 * qd + 1] + bp),
-                                     gelu(acc[q][rb][4 * qd + 2] + bp), gelu(acc[q][rb][4 * qd + 3] + bp));
+                    store_split4<NP>(R0 + (rb * 32 + p) * LD0 + n, P0, gelu_fast(acc[q][rb][4 * qd + 0] + bp), gelu_fast(acc[q][rb][4 * qd + 1] + bp),
+                                     gelu_fast(acc[q][rb][4 * qd + 2] + bp), gelu_fast(acc[q][rb][4 * qd + 3] + bp));
                 }
             }
     }
