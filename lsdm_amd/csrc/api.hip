@@ -48,6 +48,13 @@ struct lsdm_ctx {
     // LSDM_SA_REG=0..3 is an A/B switch for measurements (sa4 and the FP stages were measured slower in the chained form)
     int sa_reg = getenv("LSDM_SA_REG") ? (atoi(getenv("LSDM_SA_REG")) < 3 ? atoi(getenv("LSDM_SA_REG")) : 3) : 3;
     DenseH sa_r[3];                     // sa1..sa3 as fragment blobs of the register-chained kernels (encoder_reg.hip)
+    // First SA layer split across the grouping (encoder_u.hip, bf16x3): per level i (0: sa3, 1: sa4) the feature columns of
+    // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
+    // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
+    DenseH sa_uw[2], sa_ub[2];
+    const float* sa_wx[2] = {};
+    float *sa_U[2] = {}, *sa_V[2] = {};
+    int sa_split = getenv("LSDM_SA_SPLIT") ? atoi(getenv("LSDM_SA_SPLIT")) : 2;   // A/B switch: number of levels (from sa3) using it
     void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
     void* fpo_b[3] = {};
     CondParams cond{};
@@ -393,7 +400,14 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     for (int l = 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
-        if (l < c->sa_reg)
+        if (np == 2 && l == 2 && c->sa_split >= 1) {
+            // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
+            launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
+            launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+        } else if (np == 2 && l == 3 && c->sa_split >= 2) {
+            launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
+            launch_sa_h_pre(nc, c->sa_U[1], c->sa_V[1], f.idx[3], lvl_xyz[4], f.ball[3], c->sa_h[3], c->feat[3], st);
+        } else if (l < c->sa_reg)
             launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
         else
             launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
@@ -601,6 +615,43 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
         ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], np, &c->sa_r[0]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]);
+        if (np == 2 && ok) {
+            // sa3: first layer (128 x 131, reference column order [xyz (3) || features (128)]) split into Wx | Wf
+            const std::string pre = "pcd_backbone.sa3";
+            std::vector<float> W, Bv;
+            ok = fold_dense(c, pre + ".mlp_convs.0.weight", pre + ".mlp_convs.0.bias", pre + ".mlp_bns.0", 128, 131, W, Bv);
+            if (ok) {
+                std::vector<float> wf((size_t)128 * 128), wx((size_t)128 * 3);
+                for (int n = 0; n < 128; ++n) {
+                    for (int k = 0; k < 3; ++k) wx[(size_t)n * 3 + k] = W[(size_t)n * 131 + k];
+                    for (int k = 0; k < 128; ++k) wf[(size_t)n * 128 + k] = W[(size_t)n * 131 + 3 + k];
+                }
+                std::vector<uint16_t> pk = pack_weight_h(wf, 128, 128, np, {});
+                c->sa_uw[0].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pk.data()), pk.size() / 2));
+                c->sa_uw[0].b = upload(c, Bv.data(), Bv.size());
+                c->sa_wx[0] = upload(c, wx.data(), wx.size());
+                std::vector<ChainLayer> layers = {{pre + ".mlp_convs.1.weight", pre + ".mlp_convs.1.bias", pre + ".mlp_bns.1", 128, 128},
+                                                  {pre + ".mlp_convs.2.weight", pre + ".mlp_convs.2.bias", pre + ".mlp_bns.2", 256, 128}};
+                std::vector<int> ident(128);
+                for (int k = 0; k < 128; ++k) ident[k] = k;
+                ok = c->sa_uw[0].w && c->sa_uw[0].b && c->sa_wx[0] && build_chain_blob(c, layers, ident, np, &c->sa_ub[0]);
+            }
+            // sa4: first layer (256 x 259) split the same way; layers 2-3 are the LDS-tiled operands sa_h[3][1..2]
+            std::vector<float> W4, B4;
+            ok = ok && fold_dense(c, "pcd_backbone.sa4.mlp_convs.0.weight", "pcd_backbone.sa4.mlp_convs.0.bias", "pcd_backbone.sa4.mlp_bns.0", 256, 259, W4, B4);
+            if (ok) {
+                std::vector<float> wf((size_t)256 * 256), wx((size_t)256 * 3);
+                for (int n = 0; n < 256; ++n) {
+                    for (int k = 0; k < 3; ++k) wx[(size_t)n * 3 + k] = W4[(size_t)n * 259 + k];
+                    for (int k = 0; k < 256; ++k) wf[(size_t)n * 256 + k] = W4[(size_t)n * 259 + 3 + k];
+                }
+                std::vector<uint16_t> pk = pack_weight_h(wf, 256, 256, np, {});
+                c->sa_uw[1].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pk.data()), pk.size() / 2));
+                c->sa_uw[1].b = upload(c, B4.data(), B4.size());
+                c->sa_wx[1] = upload(c, wx.data(), wx.size());
+                ok = c->sa_uw[1].w && c->sa_uw[1].b && c->sa_wx[1];
+            }
+        }
     }
     if (ok) {
         Lin l{};
@@ -766,7 +817,9 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
     ok = ok && (c->fpo4 = ws_alloc<float>(c, "fp4", nc * 64 * 256)) && (c->fpo3 = ws_alloc<float>(c, "fp3", nc * 256 * 256)) &&
          (c->fpo2 = ws_alloc<float>(c, "fp2", nc * 1024 * 128)) && (c->pcd = ws_alloc<float>(c, "pcd", nc * kN * 3)) &&
          (c->hm = ws_alloc<float>(c, "hm", (size_t)B * kN * 3)) && (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) &&
-         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3));
+         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->sa_U[0] = ws_alloc<float>(c, "sa3_u", nc * 256 * 128)) &&
+         (c->sa_V[0] = ws_alloc<float>(c, "sa3_v", nc * 256 * 128)) && (c->sa_U[1] = ws_alloc<float>(c, "sa4_u", nc * 64 * 256)) &&
+         (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256));
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)

@@ -29,11 +29,15 @@ __device__ unsigned long long g_phase[64 * 64];   // 64 spread copies of 64 slot
 
 
 // ---------------------------------------------------------------------------------------------
-template <int D, int C1, int C2, int C3, int TM, int NW, int NP, int WPS = 1>
+// PRE: the first layer has been split across the grouping (encoder_u.hip): src_feat = U (NSRC x C1 per cloud), pre_v = V,
+// pre_cent = index of every centroid among the source points; the gather writes ReLU(U_j - V_i) straight into the layer-2
+// operand buffer and layer 1 is skipped.
+template <int D, int C1, int C2, int C3, int TM, int NW, int NP, int WPS = 1, bool PRE = false>
 __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restrict__ src_xyz, const typename FeatT<NP>::type* __restrict__ src_feat,
                                                         const float* __restrict__ new_xyz, const int* __restrict__ ball, int NSRC,
                                                         int S, DenseH l1, DenseH l2, DenseH l3,
-                                                        typename FeatT<NP>::type* __restrict__ out) {
+                                                        typename FeatT<NP>::type* __restrict__ out,
+                                                        const float* __restrict__ pre_v = nullptr, const int* __restrict__ pre_cent = nullptr) {
     constexpr int NT = NW * 64;
     constexpr int K0P = (D == 3) ? 16 : round16(D + 3);
     constexpr int LDA = ldh(imax(K0P, C2)), LDB = ldh(C1);
@@ -56,11 +60,47 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     const int wave_ = tid >> 6, lane_ = tid & 63;
     WFrag<NP, kgroup(K0P / 16)> w1;
     f32x4 b1[4];
-    wfrag_load<NP, K0P / 16>(w1, l1.w, C1, wave_ % T1::CSTEP, 0, lane_);
-    load_bias_h(b1, l1.b, wave_ % T1::CSTEP, lane_);
+    WFrag<NP, kgroup(C1 / 16)> w2;
+    f32x4 b2[4];
+    if constexpr (!PRE) {
+        wfrag_load<NP, K0P / 16>(w1, l1.w, C1, wave_ % T1::CSTEP, 0, lane_);
+        load_bias_h(b1, l1.b, wave_ % T1::CSTEP, lane_);
+    } else {
+        wfrag_load<NP, C1 / 16>(w2, l2.w, C2, wave_ % T2::CSTEP, 0, lane_);
+        load_bias_h(b2, l2.b, wave_ % T2::CSTEP, lane_);
+    }
     [[maybe_unused]] constexpr int PS = (D == 3 ? 0 : D == 64 ? 8 : D == 128 ? 16 : 24);   // phase-timing slot base of this level
     PHASE_T0();
-    if constexpr (D == 3) {
+    if constexpr (PRE) {
+        static_assert(NP == 2 && D == C1, "split first layer: fp32 U / V of width C1");
+        const float* Ub = src_feat + (size_t)c * NSRC * C1;
+        const float* Vb = pre_v + (size_t)c * NSRC * C1;
+        const int* ci = pre_cent + (size_t)c * S + s0;
+        constexpr int CH = C1 / 4;
+        static_assert((TM * CH) % NT == 0, "gather tiling");
+        constexpr int ITER = TM * CH / NT;
+        int gidx[ITER], vidx[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int row = (tid + it * NT) / CH;
+            gidx[it] = bl[row];
+            vidx[it] = ci[row >> 5];
+        }
+        f32x4 gu[ITER], gw[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + it * NT;
+            gu[it] = load4f(Ub + (size_t)gidx[it] * C1 + 4 * (e % CH));
+            gw[it] = load4f(Vb + (size_t)vidx[it] * C1 + 4 * (e % CH));
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + it * NT;
+            const int row = e / CH, ch = e - row * CH;
+            store_split4<NP>(bufB + row * LDB + 4 * ch, PB, reluf(gu[it][0] - gw[it][0]), reluf(gu[it][1] - gw[it][1]),
+                             reluf(gu[it][2] - gw[it][2]), reluf(gu[it][3] - gw[it][3]));
+        }
+    } else if constexpr (D == 3) {
         // sa1: the point features are the raw coordinates.  Row = [x y z | dx dy dz | 0 x 10]
         for (int row = tid; row < TM; row += NT) {
             const int idx = bl[row];
@@ -111,15 +151,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void sa_h_kernel(const float* __restr
     PHASE_MARK(PS + 0);   // gather issued + written (this wave)
     __syncthreads();
     PHASE_MARK(PS + 1);   // barrier wait
-    WFrag<NP, kgroup(C1 / 16)> w2;
-    f32x4 b2[4];
-    layer_lds_pre_h<NW, TM, K0P, C1, ACT_RELU, NP>(bufA, LDA, PA, l1, bufB, LDB, PB, w1, b1, [&]() {
-        wfrag_load<NP, C1 / 16>(w2, l2.w, C2, wave_ % T2::CSTEP, 0, lane_);
-        load_bias_h(b2, l2.b, wave_ % T2::CSTEP, lane_);
-    });
-    PHASE_MARK(PS + 2);
-    __syncthreads();
-    PHASE_MARK(PS + 3);
+    if constexpr (!PRE) {
+        layer_lds_pre_h<NW, TM, K0P, C1, ACT_RELU, NP>(bufA, LDA, PA, l1, bufB, LDB, PB, w1, b1, [&]() {
+            wfrag_load<NP, C1 / 16>(w2, l2.w, C2, wave_ % T2::CSTEP, 0, lane_);
+            load_bias_h(b2, l2.b, wave_ % T2::CSTEP, lane_);
+        });
+        PHASE_MARK(PS + 2);
+        __syncthreads();
+        PHASE_MARK(PS + 3);
+    }
     WFrag<NP, kgroup(C2 / 16)> w3;
     layer_lds_pre_h<NW, TM, C1, C2, ACT_RELU, NP>(bufB, LDB, PB, l2, bufA, LDA, PA, w2, b2,
                                                    [&]() { wfrag_load<NP, C2 / 16>(w3, l3.w, C3, wave_ % T3::CSTEP, 0, lane_); });
@@ -365,6 +405,13 @@ static void launch_fp_h_t(int which, int nc, const void* points1, const void* po
         case 1: hipLaunchKernelGGL((fp_h_kernel<0, 128, 128, 128, 128, true, 64, 128, 4, NP>), dim3(1024 / 64 * nc), dim3(256), 0, st, p1, p2,
                                    nn_idx, nn_w, 1024, 1024, l[0], l[1], l[2], head1[0], head2, out); break;
     }
+}
+
+// sa4 with the first layer split across the grouping (encoder_u.hip): U, V of the level-3 points, cent = FPS indices of level 4
+void launch_sa_h_pre(int nc, const float* U, const float* V, const int* cent, const float* new_xyz, const int* ball, const DenseH* l,
+                     float* out, hipStream_t st) {
+    hipLaunchKernelGGL((sa_h_kernel<256, 256, 256, 512, 64, 8, 2, 1, true>), dim3(16 / 2 * nc), dim3(512), 0, st, nullptr, U, new_xyz, ball, 64, 16,
+                       l[0], l[1], l[2], out, V, cent);
 }
 
 void launch_sa_h(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,

@@ -89,9 +89,16 @@ void launch_sa_h(int np, int level, int num_clouds, const float* src_xyz, const 
                  const DenseH* l, void* out, hipStream_t st);
 void launch_fp_h(int np, int which, int num_clouds, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
                  const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st);
+void launch_sa_h_pre(int num_clouds, const float* U, const float* V, const int* cent, const float* new_xyz, const int* ball, const DenseH* l,
+                     float* out, hipStream_t st);
 // encoder_reg.hip: register-chained SA kernel for levels 0 and 1 (weights resident in LDS)
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
+// encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
+// point (level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on ReLU(U_j - V_i)
+void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
+void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const __bf16* blob_w,
+                 const float* blob_b, float* out, hipStream_t st);
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
