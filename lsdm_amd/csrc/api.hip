@@ -74,6 +74,7 @@ struct lsdm_ctx {
     // kGroup of them, carved out of contiguous allocations [kGroup][...], so that lsdm_sample_steps can evaluate the
     // geometry of up to kGroup consecutive steps in ONE launch per stage (the fronts do not depend on x or on each other).
     static constexpr int kGroup = 8;
+    int fps_slots = 4096;               // resident FPS waves on the device (lsdm_create: 16 x CUs)
     int group_cap = getenv("LSDM_GROUP") ? atoi(getenv("LSDM_GROUP")) : 0;   // A/B switch: steps per batched geometry launch
     struct FrontSet {
         int* idx[4] = {};
@@ -507,6 +508,8 @@ int lsdm_create(lsdm_ctx** out, int device) {
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, LSDM_ERR_HIP, "hipSetDevice(%d) failed", device);
     lsdm_ctx* c = new lsdm_ctx();
     c->device = device;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->fps_slots = 16 * cus;
     *out = c;
     return LSDM_OK;
 }
@@ -865,6 +868,9 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     // step produces) is evaluated first, one launch per stage over group x B x 9 clouds, then the steps run in order.
     // (the cloud index of a batched geometry launch is gridDim.y: at most 65535 clouds per launch)
     int gmax = 65535 / nc < lsdm_ctx::kGroup ? (65535 / nc < 1 ? 1 : 65535 / nc) : lsdm_ctx::kGroup;
+    // FPS runs one wave per cloud at 16 waves per CU (register-bound): a group whose clouds fit the chip in ONE round of waves
+    // avoids a second, nearly empty round (B = 64: 7 steps = 4032 clouds on 4096 slots rather than 8 = 4608)
+    if (c->fps_slots / nc >= 4 && c->fps_slots / nc < gmax) gmax = c->fps_slots / nc;
     if (c->group_cap > 0 && gmax > c->group_cap) gmax = c->group_cap;
     for (int k0 = 0; k0 < K; k0 += gmax) {
         const int g = K - k0 < gmax ? K - k0 : gmax;

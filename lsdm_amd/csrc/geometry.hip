@@ -23,8 +23,9 @@ namespace lsdm {
 //   * its coordinates are read straight out of the owning lane's registers (uniform dynamic register index + v_readlane):
 //     no LDS access and no memory latency inside the dependent chain.
 // The selections of 64 consecutive iterations are collected one per lane (v_writelane) and flushed as coalesced stores.
-// LDS is only the 12 KiB hand-over buffer between levels, so 13 waves fit a CU; the batched launches of the multi-step
-// entry point (>= 4 clouds per SIMD) are bound by VALU issue, not by the length of the dependent chain.
+// No LDS: a level hands its selection to the next through its own global output (fps_load_prev), so 16 waves fit a CU
+// (register-bound) and a batched launch of the multi-step entry point (~4 clouds per SIMD) is bound by VALU issue, not by
+// the length of the dependent chain.
 // Batched launches cover G consecutive steps of one chain batch: cloud c of the launch is cloud (c % nc_step) of step
 // (c / nc_step) -- the same input cloud every step, with that step's start draws starts[(step*4 + level)*nc_step + cloud]
 // (the (K,4,B*9) layout of lsdm_sample_steps).  A single-step launch has nc_step == number of clouds.
@@ -67,10 +68,10 @@ __device__ __forceinline__ void fps_find(const typename FpsVec<PPT>::type& run, 
     if constexpr (J + 1 < PPT) fps_find<PPT, J + 1>(run, wmax, selj, selm);
 }
 
-// src: N points in registers (SoA LDS hand-over buffer `hx|hy|hz` is overwritten with the NP selected points)
+// src: N points in registers; the NP selected points go to out_xyz (global), from where the next level reads them back
 template <int N, int NP>
 __device__ __forceinline__ void fps_level_reg(const typename FpsVec<N / 64>::type& px, const typename FpsVec<N / 64>::type& py,
-                                              const typename FpsVec<N / 64>::type& pz, int start, float* __restrict__ hand,
+                                              const typename FpsVec<N / 64>::type& pz, int start,
                                               int* __restrict__ out_idx, float* __restrict__ out_xyz) {
     constexpr int PPT = N / 64;
     static_assert(N % 64 == 0 && (NP <= 64 || NP % 64 == 0), "fps_level_reg tiling");
@@ -131,21 +132,24 @@ __device__ __forceinline__ void fps_level_reg(const typename FpsVec<N / 64>::typ
             out_idx[ib + lane] = sel_i;
             float* o = out_xyz + (size_t)(ib + lane) * 3;
             o[0] = __int_as_float(sel_x); o[1] = __int_as_float(sel_y); o[2] = __int_as_float(sel_z);
-            hand[ib + lane] = __int_as_float(sel_x); hand[kPoints + ib + lane] = __int_as_float(sel_y);
-            hand[2 * kPoints + ib + lane] = __int_as_float(sel_z);
         }
     }
 }
 
+// Hand-over between levels through the level's own output in global memory: the wave waits for its stores (s_waitcnt vmcnt(0):
+// they are complete in L2, the vector L1 is write-through) and reads the points back with agent-scope loads, which bypass
+// the vector L1 -- no LDS at all, so the number of resident waves is bounded by registers only (4 per SIMD).
 template <int PPT>
-__device__ __forceinline__ void fps_load_hand(const float* hand, typename FpsVec<PPT>::type& px, typename FpsVec<PPT>::type& py,
+__device__ __forceinline__ void fps_load_prev(const float* prev_xyz, typename FpsVec<PPT>::type& px, typename FpsVec<PPT>::type& py,
                                               typename FpsVec<PPT>::type& pz) {
     const int lane = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        fv_set<PPT>(px, j, hand[lane + 64 * j]);
-        fv_set<PPT>(py, j, hand[kPoints + lane + 64 * j]);
-        fv_set<PPT>(pz, j, hand[2 * kPoints + lane + 64 * j]);
+        const float* q = prev_xyz + (size_t)(lane + 64 * j) * 3;
+        fv_set<PPT>(px, j, __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        fv_set<PPT>(py, j, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        fv_set<PPT>(pz, j, __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
 
@@ -153,7 +157,6 @@ __global__ __launch_bounds__(64) void fps_chain_reg_kernel(
     const float* __restrict__ clouds, const int64_t* __restrict__ starts, int nc_step,
     int* __restrict__ idx1, int* __restrict__ idx2, int* __restrict__ idx3, int* __restrict__ idx4,
     float* __restrict__ xyz1, float* __restrict__ xyz2, float* __restrict__ xyz3, float* __restrict__ xyz4) {
-    __shared__ float hand[3 * kPoints];
     const int c = blockIdx.x, lane = threadIdx.x;
     const int step = c / nc_step, cl = c - step * nc_step;
     const float* src = clouds + (size_t)cl * kPoints * 3;
@@ -167,20 +170,19 @@ __global__ __launch_bounds__(64) void fps_chain_reg_kernel(
             const int p = lane + 64 * j;
             px[j] = src[p * 3 + 0]; py[j] = src[p * 3 + 1]; pz[j] = src[p * 3 + 2];
         }
-        fps_level_reg<1024, 1024>(px, py, pz, s1, hand, idx1 + (size_t)c * 1024, xyz1 + (size_t)c * 1024 * 3);
-        // one wave: its LDS operations complete in program order, no barrier between the levels
-        fps_load_hand<16>(hand, px, py, pz);
-        fps_level_reg<1024, 256>(px, py, pz, s2, hand, idx2 + (size_t)c * 256, xyz2 + (size_t)c * 256 * 3);
+        fps_level_reg<1024, 1024>(px, py, pz, s1, idx1 + (size_t)c * 1024, xyz1 + (size_t)c * 1024 * 3);
+        fps_load_prev<16>(xyz1 + (size_t)c * 1024 * 3, px, py, pz);
+        fps_level_reg<1024, 256>(px, py, pz, s2, idx2 + (size_t)c * 256, xyz2 + (size_t)c * 256 * 3);
     }
     {
         FpsVec<4>::type px, py, pz;
-        fps_load_hand<4>(hand, px, py, pz);
-        fps_level_reg<256, 64>(px, py, pz, s3, hand, idx3 + (size_t)c * 64, xyz3 + (size_t)c * 64 * 3);
+        fps_load_prev<4>(xyz2 + (size_t)c * 256 * 3, px, py, pz);
+        fps_level_reg<256, 64>(px, py, pz, s3, idx3 + (size_t)c * 64, xyz3 + (size_t)c * 64 * 3);
     }
     {
         float px, py, pz;
-        fps_load_hand<1>(hand, px, py, pz);
-        fps_level_reg<64, 16>(px, py, pz, s4, hand, idx4 + (size_t)c * 16, xyz4 + (size_t)c * 16 * 3);
+        fps_load_prev<1>(xyz3 + (size_t)c * 64 * 3, px, py, pz);
+        fps_level_reg<64, 16>(px, py, pz, s4, idx4 + (size_t)c * 16, xyz4 + (size_t)c * 16 * 3);
     }
 }
 
