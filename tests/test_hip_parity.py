@@ -296,6 +296,31 @@ def test_forward_vs_oracle_and_reference_golden(C_, golden):
     assert maxabs(m.saved_guiding_points, T(g["guiding"])) <= 5e-4
 
 
+@pytest.mark.parametrize("precision,B", [("bf16x3", 1), ("bf16x3", 5), ("f32", 5)])
+def test_forward_odd_batch_sizes_vs_oracle(sd13, precision, B):
+    """Batch sizes whose work-group counts are not multiples of 8 (the XCD-aware remap must stay a bijection), whose row
+    counts are not multiples of the 64-row tiles of the row-wise U/V kernel, and whose centroid counts leave partial chunks
+    in the persistent set-abstraction kernels."""
+    m, _ = create_model_and_diffusion("proxd", precision=precision)
+    m.load_state_dict(sd13)
+    bt = make_synthetic_batch(B, seed=41)
+    torch.manual_seed(43)
+    starts = cpu_ref.draw_fps_starts(B * 9)
+    x0 = torch.randn(B, 1024, 3)
+    t = torch.tensor([(777 * (b + 1)) % 1000 for b in range(B)])
+    x_ref = x0.clone()
+    cat_o, out_o, guid_o = cpu_ref.forward(sd13, x_ref, bt["mask"], t, bt["given_objs"], bt["given_cats"], bt["text_features"],
+                                           fps_starts=starts)
+    x = x0.clone().to(DEV)
+    d = {k: v.to(DEV) for k, v in bt.items()}
+    out_cat, out = m(x, d["mask"], t.to(DEV), d["given_objs"], d["given_cats"], y=d["text_features"], fps_starts=starts)
+    torch.cuda.synchronize()
+    assert maxabs(out_cat, cat_o) <= 1e-6
+    assert maxabs(x, x_ref) <= 1e-3
+    assert maxabs(out, out_o) <= 1e-3
+    assert maxabs(m.saved_guiding_points, guid_o) <= 1e-3
+
+
 def test_forward_all_ones_mask_and_batch_position_quirks(sd13):
     """Q2/Q3 make the result depend on B and the sample's position; compare B=4 all-ones-mask against the oracle."""
     m, _ = create_model_and_diffusion("proxd")
