@@ -43,7 +43,7 @@ struct lsdm_ctx {
     // device parameter blocks
     Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
     int prec = LSDM_PREC_F32;           // arithmetic of the dense layers (lsdm_set_precision)
-    DenseH sa_h[4][3], fp_h[4][3], head_h[1];  // split-bf16 operands of the same layers (prec != F32)
+    DenseH sa_h[4][3], fp_h[4][3], head_h[2];   // head_h[1]: conv2 (3 x 128) zero-padded to one 32-channel block  // split-bf16 operands of the same layers (prec != F32)
     // SA levels 0..sa_reg-1 use the register-chained kernels (encoder_reg.hip), the rest the LDS-tiled sa_h_kernel;
     // LSDM_SA_REG=0..3 is an A/B switch for measurements (sa4 and the FP stages were measured slower in the chained form)
     int sa_reg = getenv("LSDM_SA_REG") ? (atoi(getenv("LSDM_SA_REG")) < 3 ? atoi(getenv("LSDM_SA_REG")) : 3) : 3;
@@ -615,6 +615,18 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
             }
         }
         ok = ok && load_dense_h(c, "pcd_backbone.conv1.weight", "pcd_backbone.conv1.bias", "pcd_backbone.bn1", 128, 128, np, {}, &c->head_h[0]);
+        if (ok) {
+            const HostTensor* w2 = find(c, "pcd_backbone.conv2.weight", {3, 128});
+            ok = w2 != nullptr;
+            if (ok) {
+                std::vector<float> wpad((size_t)32 * 128, 0.0f);
+                std::copy(w2->data.begin(), w2->data.end(), wpad.begin());
+                std::vector<uint16_t> pk = pack_weight_h(wpad, 32, 128, np, {});
+                c->head_h[1].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pk.data()), pk.size() / 2));
+                c->head_h[1].b = nullptr;
+                ok = c->head_h[1].w != nullptr;
+            }
+        }
         ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], np, &c->sa_r[0]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]);
@@ -751,6 +763,18 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
              load_dense_h(c, "input_process.combination_extraction.0.weight", "input_process.combination_extraction.0.bias", "", 192, 256, np, {}, &c->den_h.cex0) &&
              load_dense_h(c, "input_process.combination_extraction.2.weight", "input_process.combination_extraction.2.bias", "", 128, 192, np, {}, &c->den_h.cex2) &&
              load_dense_h(c, "output_process.pose_final.0.weight", "output_process.pose_final.0.bias", "", 64, 128, np, {}, &c->den_h.fin0);
+        if (ok) {
+            const HostTensor* wf = find(c, "output_process.pose_final.2.weight", {3, 64});
+            ok = wf != nullptr;
+            if (ok) {
+                std::vector<float> wpad((size_t)32 * 64, 0.0f);
+                std::copy(wf->data.begin(), wf->data.end(), wpad.begin());
+                std::vector<uint16_t> pk = pack_weight_h(wpad, 32, 64, np, {});
+                c->den_h.fin2m.w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pk.data()), pk.size() / 2));
+                c->den_h.fin2m.b = nullptr;
+                ok = c->den_h.fin2m.w != nullptr;
+            }
+        }
     }
     if (!ok) return c->err.empty() ? fail(c, LSDM_ERR_PARAM, "parameter upload failed") : LSDM_ERR_PARAM;
     c->finalized = true;

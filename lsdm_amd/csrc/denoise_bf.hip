@@ -69,15 +69,18 @@ __device__ __forceinline__ void denoiser_pass_h(const DenoiseHParams& P, const f
     __syncthreads();
     layer_lds_h<(TM / 32) * 2, TM, 128, 64, ACT_GELU, NP>(R2, LD1, P1, P.fin0, R3, LD3, P3);   // 2 x TM/32 block tasks: first waves only
     __syncthreads();
-    // pose_final.2: 64 -> 3 GELU (VALU)
-    for (int e = tid; e < TM * 3; e += NT) {
-        const int row = e / 3, c = e - row * 3;
-        const __bf16* a = R3 + row * LD3;
-        const float* w = P.fin2.w + c * 64;
-        float s = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k) s = fmaf(lds_val<NP>(a + k, P3), w[k], s);
-        res[e] = gelu_fast(s + P.fin2.b[c]);
+    // pose_final.2: 64 -> 3 GELU on the matrix pipe (fin2m = the three rows zero-padded to one 32-channel block), one wave per
+    // 32-point block
+    if (wave < TM / 32) {
+        f32x16 a3[1];
+        acc_zero_h(a3);
+        mma_kloop_h<1, NP, false, 64 / 16>(a3, R3 + wave * 32 * LD3, LD3, P3, P.fin2m.w, 32, 0, 0, lane);
+        const int c = lane & 31;
+        if (c < 3) {
+            const float bv = P.fin2.b[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[(wave * 32 + acc_row(r, lane)) * 3 + c] = gelu_fast(a3[0][r] + bv);
+        }
     }
     __syncthreads();
 }

@@ -230,7 +230,7 @@ template <int D1, int D2, int C1, int C2, int C3, bool HEAD, int TM, int KC, int
 __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT<NP>::type* __restrict__ points1,
                                                         const typename FeatT<NP>::type* __restrict__ points2,
                                                         const int* __restrict__ nn_idx, const float* __restrict__ nn_w, int N, int S,
-                                                        DenseH l1, DenseH l2, DenseH l3, DenseH h1, Lin h2, void* __restrict__ out_v) {
+                                                        DenseH l1, DenseH l2, DenseH l3, DenseH h1, Lin h2, DenseH h2m, void* __restrict__ out_v) {
     typedef typename FeatT<NP>::type feat_t;
     constexpr int NT = NW * 64;
     constexpr int K0 = D1 + D2;
@@ -352,15 +352,18 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
         __syncthreads();
         layer_lds_h<NW, TM, 128, 128, ACT_RELU, NP>(bufB, LDB, PB, h1, bufX, LDX, PX);  // conv1 + bn1 + ReLU (dropout = identity in eval)
         __syncthreads();
-        // conv2: 128 -> 3, plain fp32 weights (3,128), VALU
-        for (int e = tid; e < TM * 3; e += NT) {
-            const int row = e / 3, ch3 = e - row * 3;
-            const __bf16* a = bufX + row * LDX;
-            const float* w = h2.w + ch3 * 128;
-            float s = 0.0f;
-#pragma unroll 8
-            for (int k = 0; k < 128; ++k) s = fmaf(lds_val<NP>(a + k, PX), w[k], s);
-            out[((size_t)c * N + n0 + row) * 3 + ch3] = s + h2.b[ch3];
+        // conv2: 128 -> 3 on the matrix pipe (h2m = the three rows zero-padded to one 32-channel block): two waves, one
+        // 32-point block each -- as VALU work the 64 x 3 x 128 FMAs with their hi + lo LDS reads cost every wave ~480 instructions
+        if (wave < TM / 32) {
+            f32x16 a3[1];
+            acc_zero_h(a3);
+            mma_kloop_h<1, NP, false, 128 / 16>(a3, bufX + wave * 32 * LDX, LDX, PX, h2m.w, 32, 0, 0, lane);
+            const int col = lane & 31;
+            if (col < 3) {
+                const float bv = h2.b[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[((size_t)c * N + n0 + wave * 32 + acc_row(r, lane)) * 3 + col] = a3[0][r] + bv;
+            }
         }
     }
 }
@@ -397,13 +400,13 @@ static void launch_fp_h_t(int which, int nc, const void* points1, const void* po
     const Lin nol{nullptr, nullptr};
     switch (which) {
         case 4: hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, NP>), dim3(64 / 64 * nc), dim3(256), 0, st, p1, p2,
-                                   nn_idx, nn_w, 64, 16, l[0], l[1], none, none, nol, out); break;
+                                   nn_idx, nn_w, 64, 16, l[0], l[1], none, none, nol, none, out); break;
         case 3: hipLaunchKernelGGL((fp_h_kernel<128, 256, 256, 256, 0, false, 64, 128, 4, NP>), dim3(256 / 64 * nc), dim3(256), 0, st, p1, p2,
-                                   nn_idx, nn_w, 256, 64, l[0], l[1], none, none, nol, out); break;
+                                   nn_idx, nn_w, 256, 64, l[0], l[1], none, none, nol, none, out); break;
         case 2: hipLaunchKernelGGL((fp_h_kernel<64, 256, 256, 128, 0, false, 64, 64, 4, NP>), dim3(1024 / 64 * nc), dim3(256), 0, st, p1, p2,
-                                   nn_idx, nn_w, 1024, 256, l[0], l[1], none, none, nol, out); break;
+                                   nn_idx, nn_w, 1024, 256, l[0], l[1], none, none, nol, none, out); break;
         case 1: hipLaunchKernelGGL((fp_h_kernel<0, 128, 128, 128, 128, true, 64, 128, 4, NP>), dim3(1024 / 64 * nc), dim3(256), 0, st, p1, p2,
-                                   nn_idx, nn_w, 1024, 1024, l[0], l[1], l[2], head1[0], head2, out); break;
+                                   nn_idx, nn_w, 1024, 1024, l[0], l[1], l[2], head1[0], head2, head1[1], out); break;
     }
 }
 

@@ -56,6 +56,7 @@ struct DenoiseHParams {  // split-bf16 operands of the same layers (denoise_bf.h
     const __bf16* up4_l;
     const float* up4_b;
     DenseH comb, pose2, cex0, cex2, fin0;
+    DenseH fin2m;         // output_process.pose_final.2 (3 x 64) zero-padded to one 32-channel block (bias: fin2.b)
     Lin pose0, fin2, pwt;
 };
 
