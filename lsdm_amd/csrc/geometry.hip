@@ -530,15 +530,30 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
     const float a2 = sumsq3(ax, ay, az);
     float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
     int i0 = 0, i1 = 0, i2 = 0;
-    for (int p = 0; p < S; ++p) {
-        const float4 b = pts[p];
-        const float d = sqdist_ref(ax, ay, az, a2, b.x, b.y, b.z, b.w);
-        if (d < d2) {
-            if (d < d1) {
-                d2 = d1; i2 = i1;
-                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = p; }
-                else { d1 = d; i1 = p; }
-            } else { d2 = d; i2 = p; }
+    // UN coarse points per trip: independent (broadcast) LDS reads and distance evaluations, ONE test against the current
+    // third-best; the insert (in index order, strict <: ties keep the lower index) only runs when one of them qualifies
+    constexpr int UN = S >= 16 ? 16 : 4;
+    for (int p = 0; p < S; p += UN) {
+        float d[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const float4 b = pts[p + j];
+            d[j] = sqdist_ref(ax, ay, az, a2, b.x, b.y, b.z, b.w);
+        }
+        float m = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+#pragma unroll
+        for (int j = 4; j < UN; j += 4) m = fminf(m, fminf(fminf(d[j], d[j + 1]), fminf(d[j + 2], d[j + 3])));
+        if (m < d2) {
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                if (d[j] < d2) {
+                    if (d[j] < d1) {
+                        d2 = d1; i2 = i1;
+                        if (d[j] < d0) { d1 = d0; i1 = i0; d0 = d[j]; i0 = p + j; }
+                        else { d1 = d[j]; i1 = p + j; }
+                    } else { d2 = d[j]; i2 = p + j; }
+                }
+            }
         }
     }
     const float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
