@@ -133,8 +133,8 @@ class Runner:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=28)
+    ap.add_argument("--warmup", type=int, default=7)
     ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
