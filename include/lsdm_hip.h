@@ -104,6 +104,20 @@ int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, in
                       const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,
                       float* out_guiding, void* stream);
 
+/* Same K steps, same results, with the LOOP-INVARIANT part of the scene encoder's finest level evaluated once per call.
+ * farthest_point_sample at the finest level draws all 1024 points of a cloud (pointnet2.py:46: npoint = 1024 of 1024), so the
+ * level-1 centroids are the cloud itself in a step-dependent order: the ball of a centroid (query_ball_point,
+ * pointnet2_utils.py:84-104: first 32 source indices within r, in SOURCE order), its sa1 feature, and the three nearest
+ * level-1 points of every source point (:283-298) depend on which point it is, not on its position in the FPS order.  They
+ * are computed once; each step only re-orders them (feature rows, 3-NN positions with the per-step tie rule re-applied).
+ * The arithmetic and its operands are those of lsdm_sample_steps -- results are bit-identical (tests) -- unlike the hoisted
+ * variant below, which changes the random stream.  Clouds whose finest FPS is not a permutation (duplicated points) fall
+ * back to the per-step 3-NN inside the kernel. */
+int lsdm_sample_steps_invariant(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+                                const float* given_objs, const float* given_cats, const float* text_feat,
+                                const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,
+                                float* out_guiding, void* stream);
+
 /* Hoisted-conditioning variant: the scene/text/category conditioning -- human branch, PointNet++
  * geometry AND dense stages, collapsed scene attention -- is evaluated ONCE with the pinned FPS starts `fps_start`
  * (4,B*9); each of the K steps then runs only the t-dependent embedding MLPs, the up-sampling layers and the fused

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "lsdm_step": (_i, [_vp, _i, _f, _i] + [_vp] * 12 + [_vp]),
     "lsdm_sample_steps": (_i, [_vp, _i, _f, _i, _i, _i] + [_vp] * 10 + [_vp]),
     "lsdm_sample_steps_hoisted": (_i, [_vp, _i, _f, _i, _i, _i] + [_vp] * 10 + [_vp]),
+    "lsdm_sample_steps_invariant": (_i, [_vp, _i, _f, _i, _i, _i] + [_vp] * 10 + [_vp]),
     "lsdm_fps": (_i, [_vp, _vp, _vp, _i] + [_vp] * 8 + [_vp]),
     "lsdm_ball_query": (_i, [_vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     "lsdm_three_nn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

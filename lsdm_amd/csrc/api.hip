@@ -74,6 +74,12 @@ struct lsdm_ctx {
     // kGroup of them, carved out of contiguous allocations [kGroup][...], so that lsdm_sample_steps can evaluate the
     // geometry of up to kGroup consecutive steps in ONE launch per stage (the fronts do not depend on x or on each other).
     static constexpr int kGroup = 8;
+    // loop-invariant level-1 work of lsdm_sample_steps_invariant: ball query + sa1 feature of every point as a centroid, the
+    // 8 nearest points of every point (geometry.hip::l1_remap_kernel turns them into the step's level-1 order)
+    int* inv_ball = nullptr;
+    void* inv_F1 = nullptr;
+    float* inv_nn8_d = nullptr;
+    int* inv_nn8_i = nullptr;
     int fps_slots = 4096;               // resident FPS waves on the device (lsdm_create: 16 x CUs)
     int group_cap = getenv("LSDM_GROUP") ? atoi(getenv("LSDM_GROUP")) : 0;   // A/B switch: steps per batched geometry launch
     struct FrontSet {
@@ -348,7 +354,7 @@ typedef lsdm_ctx::FrontSet FrontSet;
 // PointNet++ geometry of `g` consecutive steps x `nc` clouds into front sets f, f+1, ..., f+g-1 (contiguous memory):
 // FPS chain, 4 ball queries, 4 three-NN searches -- one launch each for the whole group (x-independent work).
 // `starts` is the (g,4,nc) slice of the per-step start draws.
-void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, int g, hipStream_t st) {
+void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, int g, hipStream_t st, bool skip_l1 = false) {
     const int tot = nc * g;
     prof_mark(c, K_FPS, st);
     launch_fps_chain(clouds, starts, tot, nc, f.idx, f.xyz, st);
@@ -356,6 +362,7 @@ void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* 
     for (int l = 0; l < 4; ++l) {
         // radius ** 2 is a double in the reference and is compared against fp32 distances (Q13)
         const float r2 = (float)(kRadius[l] * kRadius[l]);
+        if (l == 0 && skip_l1) continue;   // level-1 balls are step-invariant (lsdm_sample_steps_invariant)
         prof_mark(c, K_BALL1 + l, st);
         launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], tot, kSrcN[l], kS[l], r2, f.ball[l], l == 0 ? nc : 0, st);
     }
@@ -366,17 +373,19 @@ void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* 
     launch_three_nn(f.xyz[1], f.xyz[2], tot, 256, 64, f.nn_idx[1], f.nn_w[1], 0, st);
     prof_mark(c, K_NN2, st);
     launch_three_nn(f.xyz[0], f.xyz[1], tot, 1024, 256, f.nn_idx[2], f.nn_w[2], 0, st);
-    prof_mark(c, K_NN1, st);
-    launch_three_nn(clouds, f.xyz[0], tot, 1024, 1024, f.nn_idx[3], f.nn_w[3], nc, st);
+    if (!skip_l1) {
+        prof_mark(c, K_NN1, st);
+        launch_three_nn(clouds, f.xyz[0], tot, 1024, 1024, f.nn_idx[3], f.nn_w[3], nc, st);
+    }
     prof_mark(c, -1, st);
 }
 
 // dense stages of get_backbone.forward (4 x SA, 4 x FP + head) on the geometry of a front set
-void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int nc, float* out, hipStream_t st) {
+void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int nc, float* out, hipStream_t st, bool skip_sa1 = false) {
     const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
     if (c->prec == LSDM_PREC_F32) {
         const float* lvl_feat[5] = {clouds, c->feat[0], c->feat[1], c->feat[2], c->feat[3]};
-        for (int l = 0; l < 4; ++l) {
+        for (int l = skip_sa1 ? 1 : 0; l < 4; ++l) {
             prof_mark(c, K_SA1 + l, st);
             launch_sa(l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa[l], c->feat[l], st);
         }
@@ -399,7 +408,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
     fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
-    for (int l = 0; l < 4; ++l) {
+    for (int l = skip_sa1 ? 1 : 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
         if (np == 2 && l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
@@ -454,8 +463,8 @@ void run_front(lsdm_ctx* c, FrontSet& f, int B, const int64_t* t, const float* m
 }
 
 // conditioning that depends on the scene only: dense encoder stages + collapsed scene attention (needs f.w, f.tr)
-void run_scene_conditioning(lsdm_ctx* c, const FrontSet& f, int B, const float* given_objs, hipStream_t st) {
-    run_encoder_dense(c, f, given_objs, B * kO, c->pcd, st);
+void run_scene_conditioning(lsdm_ctx* c, const FrontSet& f, int B, const float* given_objs, hipStream_t st, bool skip_sa1 = false) {
+    run_encoder_dense(c, f, given_objs, B * kO, c->pcd, st, skip_sa1);
     prof_mark(c, K_SATTN, st);
     launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
 }
@@ -475,8 +484,16 @@ void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, flo
 
 // BACK of a step: dense encoder stages, collapsed scene attention, the fused per-point denoiser + sampler update
 void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
-              const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
-    run_scene_conditioning(c, f, B, given_objs, st);
+              const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st,
+              bool inv = false) {
+    if (inv) {
+        // level 1 of the encoder from the call's invariants: feature rows and 3-NN positions in this step's FPS order
+        prof_mark(c, K_SA1, st);
+        const int np = c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1);
+        launch_l1_remap(B * kO, c->inv_F1, np == 1 ? 128 : 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], given_objs,
+                        np == 1 ? c->feat_b[0] : (void*)c->feat[0], f.nn_idx[3], f.nn_w[3], st);
+    }
+    run_scene_conditioning(c, f, B, given_objs, st, inv);
     run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st);
 }
 
@@ -844,7 +861,9 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
     ok = ok && (c->fpo4 = ws_alloc<float>(c, "fp4", nc * 64 * 256)) && (c->fpo3 = ws_alloc<float>(c, "fp3", nc * 256 * 256)) &&
          (c->fpo2 = ws_alloc<float>(c, "fp2", nc * 1024 * 128)) && (c->pcd = ws_alloc<float>(c, "pcd", nc * kN * 3)) &&
          (c->hm = ws_alloc<float>(c, "hm", (size_t)B * kN * 3)) && (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) &&
-         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->sa_U[0] = ws_alloc<float>(c, "sa3_u", nc * 256 * 128)) &&
+         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->inv_ball = ws_alloc<int>(c, "inv_ball", nc * kN * 32)) &&
+         (c->inv_F1 = ws_alloc<float>(c, "inv_f1", nc * kN * 64)) && (c->inv_nn8_d = ws_alloc<float>(c, "inv_nn8_d", nc * kN * 8)) &&
+         (c->inv_nn8_i = ws_alloc<int>(c, "inv_nn8_i", nc * kN * 8)) && (c->sa_U[0] = ws_alloc<float>(c, "sa3_u", nc * 256 * 128)) &&
          (c->sa_V[0] = ws_alloc<float>(c, "sa3_v", nc * 256 * 128)) && (c->sa_U[1] = ws_alloc<float>(c, "sa4_u", nc * 64 * 256)) &&
          (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256));
     if (ok && c->prec == LSDM_PREC_BF16) {
@@ -873,9 +892,9 @@ int lsdm_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* ma
                     static_cast<hipStream_t>(stream));
 }
 
-int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int K, float* x, const float* mask, const float* given_objs,
-                      const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat,
-                      float* out_x0, float* out_guiding, void* stream) {
+static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+                             const float* given_objs, const float* given_cats, const float* text, const int64_t* starts,
+                             const float* noise, float* out_cat, float* out_x0, float* out_guiding, void* stream) {
     int rc = check_ready(c, B, true);
     if (rc) return rc;
     if (mode != LSDM_MODE_P_SAMPLE && mode != LSDM_MODE_DDIM) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: bad mode %d", mode);
@@ -896,15 +915,32 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     // avoids a second, nearly empty round (B = 64: 7 steps = 4032 clouds on 4096 slots rather than 8 = 4608)
     if (c->fps_slots / nc >= 4 && c->fps_slots / nc < gmax) gmax = c->fps_slots / nc;
     if (c->group_cap > 0 && gmax > c->group_cap) gmax = c->group_cap;
+    if (inv) {
+        // once per call: everything of encoder level 1 that does not depend on the FPS order (geometry.hip::l1_remap_kernel)
+        const float r2 = (float)(kRadius[0] * kRadius[0]);
+        prof_mark(c, K_BALL1, st);
+        launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2, c->inv_ball, 0, st);
+        prof_mark(c, K_SA1, st);
+        if (c->prec == LSDM_PREC_F32) {
+            launch_sa(0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), st);
+        } else {
+            const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
+            if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, st);
+            else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, st);
+        }
+        prof_mark(c, K_NN1, st);
+        launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, st);
+        prof_mark(c, -1, st);
+    }
     for (int k0 = 0; k0 < K; k0 += gmax) {
         const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);
         run_conditioning(c, c->fs[0], B, g, c->fs[0].tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
-        run_geometry(c, c->fs[0], given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st);
+        run_geometry(c, c->fs[0], given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
             lsdm_ctx::FrontSet& f = c->fs[j];
-            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st);
+            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st, inv);
             rc = check_launch(c, "sample step");
             if (rc) return rc;
             float* tmp = cur; cur = nxt; nxt = tmp;
@@ -912,6 +948,20 @@ int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int 
     }
     if (cur != x) HIP_TRY(c, hipMemcpyAsync(x, cur, xn * sizeof(float), hipMemcpyDeviceToDevice, st));
     return LSDM_OK;
+}
+
+int lsdm_sample_steps(lsdm_ctx* c, int mode, float eta, int B, int t_first, int K, float* x, const float* mask, const float* given_objs,
+                      const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat,
+                      float* out_x0, float* out_guiding, void* stream) {
+    return sample_steps_impl(c, false, mode, eta, B, t_first, K, x, mask, given_objs, given_cats, text, starts, noise, out_cat, out_x0,
+                             out_guiding, stream);
+}
+
+int lsdm_sample_steps_invariant(lsdm_ctx* c, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+                                const float* given_objs, const float* given_cats, const float* text, const int64_t* starts,
+                                const float* noise, float* out_cat, float* out_x0, float* out_guiding, void* stream) {
+    return sample_steps_impl(c, true, mode, eta, B, t_first, K, x, mask, given_objs, given_cats, text, starts, noise, out_cat, out_x0,
+                             out_guiding, stream);
 }
 
 int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,

@@ -566,6 +566,159 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Loop-invariant level-1 work (lsdm_sample_steps_invariant).  The finest FPS level draws all 1024 points of a cloud, so
+// the level-1 centroids are the cloud itself in a step-dependent ORDER; the ball of a centroid (first 32 source indices
+// within r, in source order) and therefore its sa1 feature depend on WHICH point it is, not on where FPS put it, and the
+// three nearest level-1 points of a source point are the same points every step, at step-dependent positions.  So once per
+// call: F1[p] = sa1 feature of point p as a centroid, NN8[n] = the eight nearest points of n (distance, source index).
+// Per step this kernel (one work-group per cloud) only
+//   * copies rows:          feat1[i]   = F1[idx1[i]]
+//   * translates positions: pos[idx1[i]] = i; the three smallest (distance, pos) pairs among the eight candidates -- the tie
+//     rule of the per-step scan (lowest level-1 position among equal distances) -- and their inverse-distance weights
+// Exact: the same arithmetic on the same operands, only evaluated once.  If idx1 is NOT a permutation (duplicated points
+// make FPS re-draw an index: degenerate clouds) the multiset of level-1 points differs from the cloud and the 3-NN of that
+// cloud is redone exhaustively here against the actual level-1 points, exactly as three_nn_kernel does.
+// ---------------------------------------------------------------------------------------------
+// once per call: the 8 nearest points of every point of a cloud, (distance, source index) ascending -- enough candidates
+// to re-apply the reference's tie rule (lowest LEVEL-1 POSITION among equal distances) once the step's order is known
+__global__ __launch_bounds__(256) void nn8_kernel(const float* __restrict__ clouds, float* __restrict__ out_d, int* __restrict__ out_i) {
+    constexpr int N = kPoints;
+    __shared__ float4 pts[N];
+    const int c = blockIdx.y, tid = threadIdx.x;
+    const float* src = clouds + (size_t)c * N * 3;
+    for (int p = tid; p < N; p += 256) {
+        const float x = src[p * 3 + 0], y = src[p * 3 + 1], z = src[p * 3 + 2];
+        pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    const float4 a = pts[n];
+    float d[8];
+    int id[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { d[j] = INFINITY; id[j] = 0; }
+    for (int p = 0; p < N; ++p) {
+        const float4 b = pts[p];
+        const float v = sqdist_ref(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);   // fine point = a, coarse point = b, as in three_nn_kernel
+        if (v < d[7]) {
+            // insert, keeping ascending order; strict < : equal distances stay in increasing source index
+            d[7] = v; id[7] = p;
+#pragma unroll
+            for (int j = 7; j > 0; --j) {
+                if (d[j] < d[j - 1]) {
+                    const float td = d[j]; d[j] = d[j - 1]; d[j - 1] = td;
+                    const int ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
+                }
+            }
+        }
+    }
+    const size_t o = ((size_t)c * N + n) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { out_d[o + j] = d[j]; out_i[o + j] = id[j]; }
+}
+
+__global__ __launch_bounds__(256) void l1_remap_kernel(const unsigned char* __restrict__ F1, int row_bytes, const int* __restrict__ idx1,
+                                                       const float* __restrict__ nn8_d, const int* __restrict__ nn8_i,
+                                                       const float* __restrict__ l1_xyz, const float* __restrict__ clouds,
+                                                       unsigned char* __restrict__ feat1, int* __restrict__ nn_idx, float* __restrict__ nn_w) {
+    constexpr int N = kPoints, NT = 256;
+    __shared__ unsigned short pos[N];
+    __shared__ float4 pts[N];
+    __shared__ int missing;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int* id = idx1 + (size_t)c * N;
+    for (int e = tid; e < N; e += NT) pos[e] = 0xFFFFu;
+    if (tid == 0) missing = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += NT) pos[id[i]] = (unsigned short)i;   // duplicates: any of the positions (identical points)
+    __syncthreads();
+    for (int e = tid; e < N; e += NT)
+        if (pos[e] == 0xFFFFu) missing = 1;
+    // feature rows (16-byte pieces; row_bytes = 256 fp32 / 128 bf16)
+    const int ppr = row_bytes / 16;
+    const unsigned char* fsrc = F1 + (size_t)c * N * row_bytes;
+    unsigned char* fdst = feat1 + (size_t)c * N * row_bytes;
+    for (int e = tid; e < N * ppr; e += NT) {
+        const int i = e / ppr, q = e - i * ppr;
+        *reinterpret_cast<f32x4*>(fdst + (size_t)i * row_bytes + q * 16) = *reinterpret_cast<const f32x4*>(fsrc + (size_t)id[i] * row_bytes + q * 16);
+    }
+    // 3-NN of the fine points from their 8 candidates: smallest (distance, level-1 position); certified when the 8th
+    // candidate is strictly farther than the chosen third (otherwise more ties than candidates: exhaustive path below)
+    if (!missing) {
+        for (int n = tid; n < N; n += NT) {
+            const size_t o8 = ((size_t)c * N + n) * 8;
+            float d[8];
+            int ps[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { d[j] = nn8_d[o8 + j]; ps[j] = (int)pos[nn8_i[o8 + j]]; }
+            float rd[3];
+            int ri[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                int best = 0;
+#pragma unroll
+                for (int j = 1; j < 8; ++j)
+                    if (d[j] < d[best] || (d[j] == d[best] && ps[j] < ps[best])) best = j;
+                rd[r] = d[best]; ri[r] = ps[best];
+                d[best] = INFINITY;
+            }
+            if (!(nn8_d[o8 + 7] > rd[2])) missing = 1;
+            const float r0 = __fdiv_rn(1.0f, __fadd_rn(rd[0], 1e-8f));
+            const float r1 = __fdiv_rn(1.0f, __fadd_rn(rd[1], 1e-8f));
+            const float r2 = __fdiv_rn(1.0f, __fadd_rn(rd[2], 1e-8f));
+            const float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+            const size_t o = ((size_t)c * N + n) * 3;
+            nn_idx[o + 0] = ri[0]; nn_idx[o + 1] = ri[1]; nn_idx[o + 2] = ri[2];
+            nn_w[o + 0] = __fdiv_rn(r0, norm); nn_w[o + 1] = __fdiv_rn(r1, norm); nn_w[o + 2] = __fdiv_rn(r2, norm);
+        }
+    }
+    __syncthreads();
+    if (!missing) return;
+    // degenerate cloud: exhaustive 3-NN against the actual level-1 points (three_nn_kernel's scan and tie rule)
+    const float* l1 = l1_xyz + (size_t)c * N * 3;
+    for (int p = tid; p < N; p += NT) {
+        const float x = l1[p * 3 + 0], y = l1[p * 3 + 1], z = l1[p * 3 + 2];
+        pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
+    }
+    __syncthreads();
+    const float* cl = clouds + (size_t)c * N * 3;
+    for (int n = tid; n < N; n += NT) {
+        const float ax = cl[n * 3 + 0], ay = cl[n * 3 + 1], az = cl[n * 3 + 2];
+        const float a2 = sumsq3(ax, ay, az);
+        float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+        int i0 = 0, i1 = 0, i2 = 0;
+        for (int p = 0; p < N; ++p) {
+            const float4 b = pts[p];
+            const float d = sqdist_ref(ax, ay, az, a2, b.x, b.y, b.z, b.w);
+            if (d < d2) {
+                if (d < d1) {
+                    d2 = d1; i2 = i1;
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = p; }
+                    else { d1 = d; i1 = p; }
+                } else { d2 = d; i2 = p; }
+            }
+        }
+        const float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
+        const float r1 = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f));
+        const float r2 = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+        const float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+        const size_t o = ((size_t)c * N + n) * 3;
+        nn_idx[o + 0] = i0; nn_idx[o + 1] = i1; nn_idx[o + 2] = i2;
+        nn_w[o + 0] = __fdiv_rn(r0, norm); nn_w[o + 1] = __fdiv_rn(r1, norm); nn_w[o + 2] = __fdiv_rn(r2, norm);
+    }
+}
+
+void launch_nn8(int nc, const float* clouds, float* out_d, int* out_i, hipStream_t st) {
+    hipLaunchKernelGGL(nn8_kernel, dim3(kPoints / 256, nc), dim3(256), 0, st, clouds, out_d, out_i);
+}
+
+void launch_l1_remap(int nc, const void* F1, int row_bytes, const int* idx1, const float* nn8_d, const int* nn8_i, const float* l1_xyz,
+                     const float* clouds, void* feat1, int* nn_idx, float* nn_w, hipStream_t st) {
+    hipLaunchKernelGGL(l1_remap_kernel, dim3(nc), dim3(256), 0, st, static_cast<const unsigned char*>(F1), row_bytes, idx1, nn8_d, nn8_i,
+                       l1_xyz, clouds, static_cast<unsigned char*>(feat1), nn_idx, nn_w);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],

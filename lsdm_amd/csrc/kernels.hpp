@@ -80,6 +80,10 @@ void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds
 void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod, hipStream_t st);
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,
                      hipStream_t st);
+// level-1 loop-invariant work translated into the step's FPS order (lsdm_sample_steps_invariant): feature rows + 3-NN positions
+void launch_nn8(int num_clouds, const float* clouds, float* out_d, int* out_i, hipStream_t st);
+void launch_l1_remap(int num_clouds, const void* F1, int row_bytes, const int* idx1, const float* nn8_d, const int* nn8_i,
+                     const float* l1_xyz, const float* clouds, void* feat1, int* nn_idx, float* nn_w, hipStream_t st);
 // encoder.hip
 void launch_sa(int level, int num_clouds, const float* src_xyz, const float* src_feat, const float* new_xyz, const int* ball,
                const Dense* l, float* out, hipStream_t st);

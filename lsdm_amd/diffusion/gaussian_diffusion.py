@@ -190,7 +190,7 @@ class GaussianDiffusion:
         return {"sample": sample, "pred_xstart": x0}
 
     def _bulk_loop(self, mode, eta, model, shape, mask, given_objs, given_cats, y, noise, device, skip_timesteps, init_image,
-                   const_noise, hoist_conditioning, chunk_steps):
+                   const_noise, hoist_conditioning, chunk_steps, hoist_invariants=False):
         """Whole sampling loop with ``chunk_steps`` steps per library call.  The random numbers are drawn in the
         reference's order (x_T; then per step the 4 FPS randints of pointnet2_utils.py:72 and randn_like of
         gaussian_diffusion.py:545), only ahead of time for a chunk.  With ``hoist_conditioning`` the FPS starts are the
@@ -226,21 +226,23 @@ class GaussianDiffusion:
                     starts.append(draw_starts())
                 noises.append(self._noise_like(x, const_noise))
             inner._run_steps(mode, eta, x, mask, t_first - done, k, given_objs, given_cats, text,
-                             pinned if hoist_conditioning else th.stack(starts), th.stack(noises), hoisted=hoist_conditioning)
+                             pinned if hoist_conditioning else th.stack(starts), th.stack(noises), hoisted=hoist_conditioning,
+                             invariant=hoist_invariants and not hoist_conditioning)
             done += k
         return x
 
     def p_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                       denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
                       init_image=None, randomize_class=False, cond_fn_with_grad=False, dump_steps=None,
-                      const_noise=False, *, hoist_conditioning=False, chunk_steps=50):
-        """Reference signature (gaussian_diffusion.py:611-632) + two keyword-only extensions: ``chunk_steps`` (steps per
+                      const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=False):
+        """Reference signature (gaussian_diffusion.py:611-632) + keyword-only extensions: ``hoist_invariants`` (evaluate the
+        loop-invariant level-1 encoder work once per library call -- bit-identical results, lsdm_sample_steps_invariant), ``chunk_steps`` (steps per
         library call on the fused path; results do not depend on it) and ``hoist_conditioning`` (pin the FPS starts to
         the first step's draws and evaluate the scene conditioning once -- not the stock reference's behaviour)."""
         if (dump_steps is None and not progress and not randomize_class and not cond_fn_with_grad
                 and self._fusable(model, clip_denoised, denoised_fn, cond_fn)):
             return self._bulk_loop(_lib.MODE_P_SAMPLE, 0.0, model, shape, mask, given_objs, given_cats, y, noise, device,
-                                   skip_timesteps, init_image, const_noise, hoist_conditioning, chunk_steps)
+                                   skip_timesteps, init_image, const_noise, hoist_conditioning, chunk_steps, hoist_invariants)
         if hoist_conditioning:
             raise NotImplementedError("hoist_conditioning needs the fused path (clip_denoised=False, no denoised_fn/cond_fn/dump_steps)")
         final, dump = None, []

@@ -197,8 +197,9 @@ class SceneDiffusionModel(nn.Module):
         self.saved_guiding_points = out_guid
         return out_cat, out_x0, out_sample
 
-    def _run_steps(self, mode, eta, x, mask, t_first, K, given_objs, given_cats, text, starts, noise, hoisted=False):
-        """K consecutive sampler steps t = t_first .. t_first-K+1 in ONE library call (lsdm_sample_steps, or
+    def _run_steps(self, mode, eta, x, mask, t_first, K, given_objs, given_cats, text, starts, noise, hoisted=False, invariant=False):
+        """K consecutive sampler steps t = t_first .. t_first-K+1 in ONE library call (lsdm_sample_steps; lsdm_sample_steps_invariant:
+        same results with the loop-invariant level-1 encoder work evaluated once per call; or
         lsdm_sample_steps_hoisted with one pinned (4,B*9) start tensor).  ``x`` (device, contiguous) holds the result;
         ``starts`` (K,4,B*9) int64 and ``noise`` (K,B,1024,3) are the pre-drawn RNG streams of the K steps."""
         B = x.shape[0]
@@ -217,7 +218,8 @@ class SceneDiffusionModel(nn.Module):
         out_x0, out_guid = torch.empty_like(x), torch.empty_like(x)
         p = lambda v: v.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ctx.call("lsdm_sample_steps_hoisted" if hoisted else "lsdm_sample_steps", mode, float(eta), B, int(t_first), int(K), p(x),
+        entry = "lsdm_sample_steps_hoisted" if hoisted else ("lsdm_sample_steps_invariant" if invariant else "lsdm_sample_steps")
+        ctx.call(entry, mode, float(eta), B, int(t_first), int(K), p(x),
                  p(mask), p(given_objs), p(given_cats), p(text), p(starts), p(noise), p(out_cat), p(out_x0), p(out_guid), stream)
         self.saved_cat, self.saved_guiding_points = out_cat, out_guid
         return out_x0

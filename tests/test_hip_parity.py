@@ -588,6 +588,29 @@ def test_hoisted_conditioning_vs_pinned_reference_golden(golden, precision):
     assert maxabs(out2, out) == 0.0
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
+def test_invariant_motion_is_bit_identical_to_strict(sd13, precision):
+    """lsdm_sample_steps_invariant evaluates the FPS-order-independent part of encoder level 1 (level-1 balls, sa1 features,
+    3-NN candidates) once per call and only re-orders it per step: the same arithmetic on the same operands, so samples,
+    categories and guiding points must equal the strict per-step recompute BIT FOR BIT -- including clouds whose finest FPS
+    is not a permutation (the all-zero padding slots of make_synthetic_batch and a cloud with duplicated points), which take
+    the per-step 3-NN inside the remap kernel."""
+    m, diff = create_model_and_diffusion("proxd", precision=precision)
+    m.load_state_dict(sd13)
+    B, K = 3, 5
+    bt = make_synthetic_batch(B, seed=61)           # 1..8 objects per sample: the remaining slots are all-zero clouds
+    bt["given_objs"][1, 1, 512:] = bt["given_objs"][1, 1, :512]   # a cloud made of 512 points, each twice
+    d = {k: v.to(DEV) for k, v in bt.items()}
+    outs = []
+    for inv in (False, True):
+        torch.manual_seed(62)
+        x = diff.p_sample_loop(m, [B, 1024, 3], d["mask"], d["given_objs"], d["given_cats"], d["text_features"], clip_denoised=False,
+                               skip_timesteps=1000 - K, chunk_steps=K, hoist_invariants=inv)
+        outs.append((x.clone(), m.saved_cat.clone(), m.saved_guiding_points.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_multi_step_call_is_deterministic(sd13):
     """K steps in one library call (the bench path: geometry and conditioning batched per group of steps, one stream),
     repeated: bit-identical results."""
