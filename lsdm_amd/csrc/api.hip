@@ -52,6 +52,11 @@ struct lsdm_ctx {
     // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
     // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
     DenseH sa_uw[2], sa_ub[2];
+    // first FP layer split at the concat boundary (encoder_u.hip): columns of points1 (+ bias) / of the interpolated points2;
+    // index 0: fp3, 1: fp2
+    DenseH fp_a[2], fp_y[2];
+    float* fp_ybuf[2] = {};
+    int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
     const float* sa_wx[2] = {};
     float *sa_U[2] = {}, *sa_V[2] = {};
     int sa_split = getenv("LSDM_SA_SPLIT") ? atoi(getenv("LSDM_SA_SPLIT")) : 2;   // A/B switch: number of levels (from sa3) using it
@@ -426,9 +431,15 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     prof_mark(c, K_FP4, st);
     launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
     prof_mark(c, K_FP3, st);
-    launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
+    if (np == 2 && c->fp_pre >= 2)
+        launch_fp_pre(3, nc, c->feat[1], c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, st);
+    else
+        launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
     prof_mark(c, K_FP2, st);
-    launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
+    if (np == 2 && c->fp_pre >= 1)
+        launch_fp_pre(2, nc, c->feat[0], c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, st);
+    else
+        launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_mark(c, K_FP1, st);
     launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
 }
@@ -668,6 +679,29 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                 for (int k = 0; k < 128; ++k) ident[k] = k;
                 ok = c->sa_uw[0].w && c->sa_uw[0].b && c->sa_wx[0] && build_chain_blob(c, layers, ident, np, &c->sa_ub[0]);
             }
+            // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
+            {
+                const char* pre[2] = {"pcd_backbone.fp3", "pcd_backbone.fp2"};
+                const int d1[2] = {128, 64};
+                for (int i = 0; i < 2 && ok; ++i) {
+                    const int K = d1[i] + 256;
+                    std::vector<float> Wf, Bf;
+                    ok = fold_dense(c, std::string(pre[i]) + ".mlp_convs.0.weight", std::string(pre[i]) + ".mlp_convs.0.bias",
+                                    std::string(pre[i]) + ".mlp_bns.0", 256, K, Wf, Bf);
+                    if (!ok) break;
+                    std::vector<float> wa((size_t)256 * d1[i]), wb((size_t)256 * 256);
+                    for (int n = 0; n < 256; ++n) {
+                        for (int k = 0; k < d1[i]; ++k) wa[(size_t)n * d1[i] + k] = Wf[(size_t)n * K + k];
+                        for (int k = 0; k < 256; ++k) wb[(size_t)n * 256 + k] = Wf[(size_t)n * K + d1[i] + k];
+                    }
+                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], np, {}), pb = pack_weight_h(wb, 256, 256, np, {});
+                    c->fp_a[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pa.data()), pa.size() / 2));
+                    c->fp_a[i].b = upload(c, Bf.data(), Bf.size());
+                    c->fp_y[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pb.data()), pb.size() / 2));
+                    c->fp_y[i].b = nullptr;
+                    ok = c->fp_a[i].w && c->fp_a[i].b && c->fp_y[i].w;
+                }
+            }
             // sa4: first layer (256 x 259) split the same way; layers 2-3 are the LDS-tiled operands sa_h[3][1..2]
             std::vector<float> W4, B4;
             ok = ok && fold_dense(c, "pcd_backbone.sa4.mlp_convs.0.weight", "pcd_backbone.sa4.mlp_convs.0.bias", "pcd_backbone.sa4.mlp_bns.0", 256, 259, W4, B4);
@@ -865,7 +899,8 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->inv_F1 = ws_alloc<float>(c, "inv_f1", nc * kN * 64)) && (c->inv_nn8_d = ws_alloc<float>(c, "inv_nn8_d", nc * kN * 8)) &&
          (c->inv_nn8_i = ws_alloc<int>(c, "inv_nn8_i", nc * kN * 8)) && (c->sa_U[0] = ws_alloc<float>(c, "sa3_u", nc * 256 * 128)) &&
          (c->sa_V[0] = ws_alloc<float>(c, "sa3_v", nc * 256 * 128)) && (c->sa_U[1] = ws_alloc<float>(c, "sa4_u", nc * 64 * 256)) &&
-         (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256));
+         (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256)) && (c->fp_ybuf[1] = ws_alloc<float>(c, "fp2_y", nc * 256 * 256)) &&
+         (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256));
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)

@@ -68,7 +68,7 @@ __device__ __forceinline__ void relu_split_pair_u(const f32x16& acc, const float
 
 // ---------------------------------------------------------------------------------------------
 // rows are independent (the source points of all clouds, flattened): X (R,K) fp32, xyz (R,3) -> U (R,N), V (R,N) fp32
-template <int K, int N>
+template <int K, int N, bool XYZ = true>
 __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__ X, const float* __restrict__ xyz, int R, DenseH W,
                                                        const float* __restrict__ wx, float* __restrict__ U, float* __restrict__ V) {
     constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__
             const int row = e / (K / 4), c4 = e - row * (K / 4);
             store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gv[it][0], gv[it][1], gv[it][2], gv[it][3]);
         }
-        for (int e = tid; e < TM * 3; e += NT) {
-            const int row = e / 3;
-            const int rr = r0 + row < R ? r0 + row : R - 1;
-            sxyz[e] = xyz[(size_t)rr * 3 + (e - row * 3)];
+        if constexpr (XYZ) {
+            for (int e = tid; e < TM * 3; e += NT) {
+                const int row = e / 3;
+                const int rr = r0 + row < R ? r0 + row : R - 1;
+                sxyz[e] = xyz[(size_t)rr * 3 + (e - row * 3)];
+            }
         }
     }
     __syncthreads();
@@ -109,8 +111,9 @@ __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__
         f32x16 acc[TS::RB];
         acc_zero_h(acc);
         const int col = cb * 32 + (lane & 31);
-        const float bias = W.b[col];
-        const float wx0 = wx[col * 3 + 0], wx1 = wx[col * 3 + 1], wx2 = wx[col * 3 + 2];
+        const float bias = W.b ? W.b[col] : 0.0f;
+        float wx0 = 0.0f, wx1 = 0.0f, wx2 = 0.0f;
+        if constexpr (XYZ) { wx0 = wx[col * 3 + 0]; wx1 = wx[col * 3 + 1]; wx2 = wx[col * 3 + 2]; }
         mma_kloop_h<TS::RB, NP, false, K / 16>(acc, bufX + rg * TS::RB * 32 * LDX, LDX, PX, W.w, N, cb, 0, lane);
 #pragma unroll
         for (int rb = 0; rb < TS::RB; ++rb)
@@ -118,9 +121,13 @@ __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) {
                 const int row = (rg * TS::RB + rb) * 32 + acc_row(r, lane);
                 if (r0 + row < R) {
-                    const float v = fmaf(wx2, sxyz[row * 3 + 2], fmaf(wx1, sxyz[row * 3 + 1], wx0 * sxyz[row * 3 + 0]));
-                    V[(size_t)(r0 + row) * N + col] = v;
-                    U[(size_t)(r0 + row) * N + col] = (acc[rb][r] + bias) + v;
+                    if constexpr (XYZ) {
+                        const float v = fmaf(wx2, sxyz[row * 3 + 2], fmaf(wx1, sxyz[row * 3 + 1], wx0 * sxyz[row * 3 + 0]));
+                        V[(size_t)(r0 + row) * N + col] = v;
+                        U[(size_t)(r0 + row) * N + col] = (acc[rb][r] + bias) + v;
+                    } else {
+                        U[(size_t)(r0 + row) * N + col] = acc[rb][r] + bias;
+                    }
                 }
             }
     }
@@ -231,6 +238,131 @@ __global__ __launch_bounds__(NW * 64) void sa_u_kernel(const float* __restrict__
 #undef PANEL_BEGIN
 #undef PANEL_END
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FP stage with the interpolated operand PRE-MULTIPLIED at the coarse level (fp2, fp3).  The first FP layer is linear in
+// [p1 || sum_j w_j p2_j] (pointnet2_utils.py:299-312), so with W = [Wa | Wb]:  W x [...] + b = Wa x p1 + sum_j w_j (Wb x p2_j) + b.
+// Y = p2 x Wb^T is evaluated once per COARSE point (lin_u_kernel<.., XYZ = false>, S = N/4 rows); here the three Y rows of a
+// fine point are gathered and interpolated cooperatively (coalesced 16-byte pieces, fp32, no bf16 split) into an LDS tile
+// from which every wave initialises its accumulators; the matrix pipe then only contracts over the D1 columns of p1.
+// One LDS region is reused in sequence: interpolated tile (fp32) -> p1 operand tile -> layer-1 activations.
+template <int D1, int C1, int C2>
+__global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict__ points1, const float* __restrict__ y,
+                                                        const int* __restrict__ nn_idx, const float* __restrict__ nn_w, int N, int S,
+                                                        DenseH l1, DenseH l2, float* __restrict__ out) {
+    constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
+    constexpr int LDT = C1 + 4;                              // fp32 tile row (floats): 16-byte aligned, rows 4 banks apart
+    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
+    constexpr int BYTES = imax(imax(TM * LDT * 4, NP * PX * 2), NP * PB * 2);
+    __shared__ __attribute__((aligned(16))) unsigned char region[BYTES];
+    float* tile = reinterpret_cast<float*>(region);
+    __bf16* bufX = reinterpret_cast<__bf16*>(region);
+    __bf16* bufB = reinterpret_cast<__bf16*>(region);
+    int c, tl;
+    xcd_cloud_tile(N / TM, c, tl);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int p = lane & 31, h = lane >> 5;
+    const int n0 = tl * TM;
+    const float* p1 = points1 + ((size_t)c * N + n0) * D1;
+    const float* yb = y + (size_t)c * S * C1;
+    // the p1 tile is requested first (consumed in phase C)
+    constexpr int XIT = TM * (D1 / 4) / NT;
+    f32x4 gx[XIT];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4);
+    // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
+    {
+        const int row = tid >> 2, sub = tid & 3;
+        const size_t o = ((size_t)c * N + n0 + row) * 3;
+        const float* r0 = yb + (size_t)nn_idx[o + 0] * C1;
+        const float* r1 = yb + (size_t)nn_idx[o + 1] * C1;
+        const float* r2 = yb + (size_t)nn_idx[o + 2] * C1;
+        const float w0 = nn_w[o + 0], w1 = nn_w[o + 1], w2 = nn_w[o + 2];
+        constexpr int PIECES = C1 / 16;                      // per thread
+#pragma unroll 1
+        for (int k0 = 0; k0 < PIECES; k0 += 4) {
+            f32x4 a[4], b[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = 4 * (sub + 4 * (k0 + k));
+                a[k] = load4f(r0 + ch); b[k] = load4f(r1 + ch); d[k] = load4f(r2 + ch);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = 4 * (sub + 4 * (k0 + k));
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(a[k][j], w0), __fmul_rn(b[k][j], w1)), __fmul_rn(d[k][j], w2));
+                *reinterpret_cast<f32x4*>(tile + row * LDT + ch) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: accumulators start from the interpolated rows (transposed product: lane owns channels 8q + 4h + j of point p)
+    using TS = SplitH<NW, TM, C1>;
+    constexpr int NCB = TS::CB / TS::CSTEP;
+    static_assert(TS::RB == 2 && TS::WPC == 1, "split");
+    const int cb0 = wave % TS::CSTEP;
+    f32x16 acc[NCB][2];
+#pragma unroll
+    for (int q = 0; q < NCB; ++q)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = t[j];
+            }
+    f32x4 bv1[NCB][4];
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane);
+    __syncthreads();
+    // ---- phase C: p1 operand tile, K = D1 -----------------------------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int e = tid + it * NT;
+        const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
+        store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) mma_kloop_h<2, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
+    __syncthreads();
+    // ---- phase D: layer-1 epilogue -> bufB, layer 2 (direct orientation) -> global -----------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, 2, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
+    __syncthreads();
+    using T2 = SplitH<NW, TM, C2>;
+    const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
+#pragma unroll 1
+    for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
+        f32x16 a2[T2::RB];
+        acc_zero_h(a2);
+        const int col = cb * 32 + (lane & 31);
+        const float bv = l2.b[col];
+        mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
+#pragma unroll
+        for (int rb = 0; rb < T2::RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lane);
+                out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv);
+            }
+    }
+}
+
+// which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
+void launch_fp_pre(int which, int nc, const float* points1, const float* fpo_coarse, DenseH wb, float* ybuf, const int* nn_idx,
+                   const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st) {
+    const int S = which == 2 ? 256 : 64;
+    const int R = nc * S;   // Y = coarse-level FP output x Wb^T
+    hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
+    if (which == 2)
+        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out);
+    else
+        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out);
 }
 
 // ---------------------------------------------------------------------------------------------

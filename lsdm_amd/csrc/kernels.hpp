@@ -104,6 +104,9 @@ void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const 
 void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
 void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const __bf16* blob_w,
                  const float* blob_b, float* out, hipStream_t st);
+// fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
+void launch_fp_pre(int which, int num_clouds, const float* points1, const float* fpo_coarse, DenseH wb, float* ybuf, const int* nn_idx,
+                   const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st);
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
