@@ -16,12 +16,17 @@ FP = {("256", "512"): "fp_kernel<fp4>", ("128", "256"): "fp_kernel<fp3>", ("64",
 
 
 def bench_name(k):
-    m = re.search(r"sa_(?:[hrs]_)?kernel<(\d+),", k)
+    m = re.search(r"sa_(?:[hrsu]_)?kernel<(\d+),", k)
     if m:
         return SA.get(m.group(1))
     m = re.search(r"fp_(?:h_)?kernel<(\d+), (\d+),", k)
     if m:
         return FP.get((m.group(1), m.group(2)))
+    m = re.search(r"fp_pre_kernel<(\d+),", k)
+    if m:
+        return {"64": "fp_kernel<fp2>", "128": "fp_kernel<fp3>"}.get(m.group(1))
+    if "fps_chain" in k:
+        return "fps_chain_kernel"
     for n in ("fps_chain_kernel", "posa_kernel", "cond_kernel", "scene_attn_kernel"):
         if n in k:
             return n
