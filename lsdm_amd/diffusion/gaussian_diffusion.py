@@ -215,20 +215,49 @@ class GaussianDiffusion:
         from ..model.sdm import FPS_RANGES, NUM_SLOTS
         draw_starts = lambda: th.stack([th.randint(0, n, (B * NUM_SLOTS,), dtype=th.long) for n in FPS_RANGES])
         pinned, done, total = None, 0, t_first + 1
+        # Host-RNG (parity) mode: the draws of a chunk go straight into one of two page-locked staging buffers and are
+        # uploaded with ONE asynchronous copy per chunk, so the host draws chunk k+1 while the GPU runs chunk k (a blocking
+        # per-step upload would wait behind the whole previous chunk and leave the GPU idle while the host draws).
+        kmax = min(int(chunk_steps), total)
+        stage = None
+        if self.host_rng and x.is_cuda:
+            stage = [dict(noise=th.empty(kmax, *x.shape, dtype=th.float32).pin_memory(),
+                          starts=th.empty(kmax, len(FPS_RANGES), B * NUM_SLOTS, dtype=th.long).pin_memory(), ev=None) for _ in range(2)]
+        chunk_i = 0
         while done < total:
             k = min(int(chunk_steps), total - done)
-            starts, noises = [], []
-            for _ in range(k):
-                if hoist_conditioning:
-                    if pinned is None:
-                        pinned = draw_starts()
-                else:
-                    starts.append(draw_starts())
-                noises.append(self._noise_like(x, const_noise))
-            inner._run_steps(mode, eta, x, mask, t_first - done, k, given_objs, given_cats, text,
-                             pinned if hoist_conditioning else th.stack(starts), th.stack(noises), hoisted=hoist_conditioning,
-                             invariant=hoist_invariants and not hoist_conditioning)
+            if stage is not None:
+                st = stage[chunk_i & 1]
+                if st["ev"] is not None:
+                    st["ev"].synchronize()       # the upload that last read this staging buffer has finished
+                for j in range(k):
+                    if hoist_conditioning:
+                        if pinned is None:
+                            pinned = draw_starts()
+                    else:
+                        for l, n in enumerate(FPS_RANGES):
+                            th.randint(0, n, (B * NUM_SLOTS,), dtype=th.long, out=st["starts"][j, l])
+                    th.randn(x.shape, out=st["noise"][j])
+                    if const_noise:
+                        st["noise"][j] = st["noise"][j][[0]].repeat(B, 1, 1)
+                noises_d = st["noise"][:k].to(x.device, non_blocking=True)
+                starts_d = (pinned if hoist_conditioning else st["starts"][:k]).to(x.device, non_blocking=True)
+                st["ev"] = th.cuda.Event()
+                st["ev"].record(th.cuda.current_stream(x.device))
+            else:
+                starts, noises = [], []
+                for _ in range(k):
+                    if hoist_conditioning:
+                        if pinned is None:
+                            pinned = draw_starts()
+                    else:
+                        starts.append(draw_starts())
+                    noises.append(self._noise_like(x, const_noise))
+                noises_d, starts_d = th.stack(noises), (pinned if hoist_conditioning else th.stack(starts))
+            inner._run_steps(mode, eta, x, mask, t_first - done, k, given_objs, given_cats, text, starts_d, noises_d,
+                             hoisted=hoist_conditioning, invariant=hoist_invariants and not hoist_conditioning)
             done += k
+            chunk_i += 1
         return x
 
     def p_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
