@@ -324,12 +324,12 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
                          skip_timesteps=0, init_image=None, randomize_class=False, cond_fn_with_grad=False,
-                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=50):
+                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=False):
         if dump_steps is not None or const_noise:
             raise NotImplementedError()
         if not progress and not randomize_class and not cond_fn_with_grad and self._fusable(model, clip_denoised, denoised_fn, cond_fn):
             return self._bulk_loop(_lib.MODE_DDIM, eta, model, shape, mask, given_objs, given_cats, y, noise, device,
-                                   skip_timesteps, init_image, False, hoist_conditioning, chunk_steps)
+                                   skip_timesteps, init_image, False, hoist_conditioning, chunk_steps, hoist_invariants)
         final = None
         for sample in self.ddim_sample_loop_progressive(
                 model, shape, mask, given_objs, given_cats, y, noise=noise, clip_denoised=clip_denoised,

@@ -609,6 +609,15 @@ def test_invariant_motion_is_bit_identical_to_strict(sd13, precision):
         outs.append((x.clone(), m.saved_cat.clone(), m.saved_guiding_points.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    if precision == "bf16x3":
+        # the DDIM loop takes the same path (respaced schedule, eta = 0)
+        ddim = create_gaussian_diffusion(get_default_diffusion(), timestep_respacing="ddim50")
+        outs = []
+        for inv in (False, True):
+            torch.manual_seed(63)
+            outs.append(ddim.ddim_sample_loop(m, [B, 1024, 3], d["mask"], d["given_objs"], d["given_cats"], d["text_features"],
+                                              clip_denoised=False, skip_timesteps=50 - K, chunk_steps=K, hoist_invariants=inv).clone())
+        assert torch.equal(outs[0], outs[1])
 
 
 def test_multi_step_call_is_deterministic(sd13):
