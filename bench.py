@@ -299,7 +299,7 @@ def main():
         res["invariant_motion"] = invariant
     del r
     torch.cuda.empty_cache()
-    if not a.no_others:
+    if not a.no_others and world == 1:
         others = {}
         for prec in ("f32", "bf16x3", "bf16"):
             if prec == a.precision:
@@ -321,7 +321,7 @@ def main():
     if not a.no_parity:
         log("parity check vs the CPU oracle")
         res["parity"] = parity_check(a.precision, dev)
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:      # the CPU leg is reported at N = 1 only
         log("cpu baseline (oracle) ...")
         res["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps, C)
     print(json.dumps(res), flush=True)
