@@ -117,7 +117,7 @@ class Runner:
         self.model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
         self.ctx = self.model._context()
         self.model._reserve(B)
-        self.model._set_schedule((id(self.diffusion), self.diffusion.num_timesteps), self.diffusion._device_tables())
+        self.model._set_schedule(self.diffusion._schedule_key(), self.diffusion._device_tables())
         self.bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=seed, max_cats=C, num_objects=8).items()}
         # RNG stream of the reference: x_T, then per step 4 FPS randints + randn, host generator
         torch.manual_seed(seed)
@@ -144,11 +144,30 @@ class Runner:
                       p(self.noise[k0] if noise is None else noise), p(self.out_cat), p(self.out_x0), p(self.out_g), self.stream)
 
 
+def respawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-executes itself under torch.distributed.run with one rank per GPU
+    (the same command line the driver uses) and returns that job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=28)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=7)
+    ap.add_argument("--mode", default="invariant", choices=["strict", "invariant"],
+                    help="headline entry point: lsdm_sample_steps_invariant (default; what p_sample_loop calls -- bit-identical to "
+                         "strict, the FPS-order-independent level-1 encoder work evaluated once per call inside the timed call) or "
+                         "lsdm_sample_steps (every stage recomputed every step); the other one is reported beside it")
     ap.add_argument("--batch", type=int, default=64, help="chains per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--precision", default=os.environ.get("LSDM_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
@@ -158,12 +177,17 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed oracle steps after 1 warm-up (BASELINE.md §3)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (python -m torch.distributed.run "
+                 "--nproc-per-node %d bench.py --gpus %d ...) or run `python bench.py --gpus %d` directly" % (a.gpus, world, a.gpus, a.gpus, a.gpus))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -181,32 +205,43 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    r = Runner(a.precision, B, C, W + K, a.seed + rank, local_rank, dev)
+    from lsdm_amd.parallel import shard_seed
+    inv = a.mode == "invariant"
+    r = Runner(a.precision, B, C, W + K, shard_seed(a.seed, rank), local_rank, dev)
     T = r.T
     log("inputs resident; warm-up %d steps" % W)
     if W:
-        r.run(T - 1, 0, W)
+        r.run(T - 1, 0, W, invariant=inv)
+    if dist:
+        gather_samples(r.x, dist)                 # untimed: RCCL communicator set-up belongs to the warm-up
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    log("timing %d steps (%s)" % (K, a.precision))
+    log("timing %d steps (%s, %s)" % (K, a.precision, a.mode))
+    x_start = r.x.clone()
     r.ctx.profile_begin()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
-    r.run(T - 1 - W, W, K)
+    r.run(T - 1 - W, W, K, invariant=inv)
+    ev[0].record()
     gathered = gather_samples(r.x, dist)          # the path's only collective (RCCL all-gather over xGMI)
+    ev[1].record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = r.ctx.profile_end()
+    allgather_us = ev[0].elapsed_time(ev[1]) * 1e3 if dist else 0.0
     log("timed region %.3f s" % dt)
     if dist:
+        assert dist.get_world_size() == a.gpus
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
+    x_final = r.x.clone()
 
     if rank != 0:
         dist.barrier()                 # rank 0 finishes its untimed reporting legs, then everyone tears down together
@@ -233,23 +268,26 @@ def main():
                            "evaluated once per call with pinned FPS starts, included in the timed call; equals the reference only with "
                            "its per-step FPS re-draw pinned (tests: g6_hoisted golden)"}
 
-    # Second separate figure (never `value`): loop-invariant motion -- the FPS-order-independent part of encoder level 1
-    # evaluated once per call (inside the timed call), results bit-identical to the strict path (tests).
-    invariant = None
-    if not a.no_hoisted:
-        xi = r.x.clone()
-        r.run(T - 1 - W, W, K, x=xi, invariant=True)
+    # The same K steps again (same inputs, same RNG draws, from the same x): once through the headline entry point WITHOUT the
+    # HIP-event instrumentation of the timed region, once through the OTHER entry point; the three final samples must be
+    # bit-identical (the invariant mode only moves FPS-order-independent work out of the loop).
+    def rerun(invariant):
+        xi = x_start.clone()
+        r.run(T - 1 - W, W, K, x=xi, invariant=invariant)      # warm
+        xi.copy_(x_start)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        r.run(T - 1 - W, W, K, x=xi, invariant=True)
+        r.run(T - 1 - W, W, K, x=xi, invariant=invariant)
         torch.cuda.synchronize()
-        dti = time.perf_counter() - t1
-        invariant = {"value": K / dti, "unit": "denoising-steps/sec per GPU (B=%d)" % B, "steps": K, "ms_per_step": dti / K * 1e3,
-                     "dtype": a.precision,
-                     "note": "NOT the headline metric: lsdm_sample_steps_invariant -- level-1 ball query, sa1 features and 3-NN candidates "
-                             "(FPS-order independent: the finest FPS level draws every point) evaluated once per call, inside the timed "
-                             "call, then re-ordered per step; outputs bit-identical to the strict per-step recompute "
-                             "(test_invariant_motion_is_bit_identical_to_strict)"}
+        d = time.perf_counter() - t1
+        return {"value": K / d, "ms_per_step": d / K * 1e3, "steps": K, "dtype": a.precision,
+                "final_sample_bit_identical_to_timed_region": bool(torch.equal(xi, x_final))}
+    uninstrumented = rerun(inv)
+    uninstrumented["note"] = "the timed region repeated without lsdm_profile_begin (no HIP events between the launches)"
+    other = rerun(not inv)
+    other["entry_point"] = "lsdm_sample_steps" if inv else "lsdm_sample_steps_invariant"
+    other["note"] = ("every stage recomputed every step (the reference's literal schedule of work)" if inv else
+                     "level-1 ball query, sa1 features and 3-NN candidates evaluated once per call, re-ordered per step")
 
     per_launch_units = lambda name: B * 9 if name[:4] in ("ball", "sa_k", "thre", "fp_k", "fps_") else B
     rows = []
@@ -277,9 +315,17 @@ def main():
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "sample_steps_per_s": world * B * K / dt,
         "config": {"workload": "BASELINE configs[2]: B=%d chains/GPU, 8 objects + human x 1024 pts (8192-pt scene cloud), C=13, random CLIP-text "
-                               "features, cosine T=1000, p_sample steps t=%d..%d; strict per-step recompute incl. PointNet++ with "
-                               "host-replayed RNG; one stream" % (B, T - 1 - W, T - W - K),
-                   "global_batch": B * world, "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
+                               "features, cosine T=1000, p_sample steps t=%d..%d in ONE %s call, host-replayed RNG, one stream; %s"
+                               % (B, T - 1 - W, T - W - K, "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
+                                  "per-step recompute of the conditioning MLPs and of PointNet++ (FPS with fresh starts, levels 2-4, all FP "
+                                  "stages); the FPS-order-independent level-1 work (balls, sa1 features, 3-NN candidates) is evaluated once "
+                                  "per call INSIDE the timed call and re-ordered per step -- results bit-identical to the strict schedule, "
+                                  "whose figure is under strict_recompute" if inv else
+                                  "strict per-step recompute of everything the reference recomputes"),
+                   "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
+                   "global_batch": B * world, "chains_per_gpu": B,
+                   "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
+        "rccl_ranks": world, "per_rank_seeds": [shard_seed(a.seed, q) for q in range(world)], "allgather_us": allgather_us,
         "roofline": {"bound": "mfma", "kernel": dom["name"],
                      "launches_of_the_stage": STAGE_KERNELS_BF16X3.get(dom["name"], dom["name"]) if a.precision == "bf16x3" else dom["name"],
                      "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
@@ -295,8 +341,8 @@ def main():
     }
     if hoisted:
         res["hoisted_conditioning"] = hoisted
-    if invariant:
-        res["invariant_motion"] = invariant
+    res["uninstrumented"] = uninstrumented
+    res["strict_recompute" if inv else "invariant_motion"] = other
     del r
     torch.cuda.empty_cache()
     if not a.no_others and world == 1:
@@ -307,10 +353,10 @@ def main():
             log("short run in %s" % prec)
             ko = 6 if prec == "f32" else 10
             ro = Runner(prec, B, C, 2 + ko, a.seed, local_rank, dev)
-            ro.run(ro.T - 1, 0, 2)
+            ro.run(ro.T - 1, 0, 2, invariant=inv)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            ro.run(ro.T - 3, 2, ko)
+            ro.run(ro.T - 3, 2, ko, invariant=inv)
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
             others[prec] = {"value": ko / d1, "ms_per_step": d1 / ko * 1e3, "steps": ko, "n_gpus": 1,

@@ -147,11 +147,19 @@ int lsdm_human_backbone(lsdm_ctx* ctx, const float* given_objs, int B, float* hm
  * ("feat1".."feat4","fp4","fp3","fp2","pcd","hm","w","tr","o12","e0","ball1".."ball4","nn_idx1".."nn_idx4") */
 int lsdm_workspace_tensor(lsdm_ctx* ctx, const char* name, void** ptr, int64_t* numel);
 
+/* ---- evaluation metrics of the CLI (run/test_sdm.py:185-196) -------------------------------------------------------- */
+/* For every point of a (batch,na,3) the squared Euclidean distance to its nearest point of b (batch,nb,3), fp32
+ * (ax-bx)^2+(ay-by)^2+(az-bz)^2, and optionally its index (lowest on ties; out_idx may be NULL).  One direction per
+ * call.  The K = 1 search underneath pytorch3d.loss.chamfer_distance (run/test_sdm.py:186: mean over points of both
+ * directions, summed) and open3d compute_point_cloud_distance (util/evaluation.py:37-38: sqrt(d2) < th for the F-score). */
+int lsdm_nn_distance(lsdm_ctx* ctx, const float* a, int na, const float* b, int nb, int batch, float* out_d2,
+                     int32_t* out_idx, void* stream);
+
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream ----------------------------- */
 /* After lsdm_profile_begin every launch of the hot path is bracketed by events until lsdm_profile_end, which
  * synchronises and returns (number of kernels, or < 0): total_ms[k] = summed duration, launches[k] = launch count,
  * macs_per_unit[k] = algorithmic multiply-accumulates of one launch per cloud (PointNet++ kernels) or per sample
- * (the others) -- the figures of DESIGN.md / SURVEY.md 8(d).  Arrays must hold `capacity` >= 22 entries. */
+ * (the others) -- the figures of DESIGN.md / SURVEY.md 8(d).  Arrays must hold `capacity` >= 23 entries. */
 int lsdm_profile_begin(lsdm_ctx* ctx);
 int lsdm_profile_end(lsdm_ctx* ctx, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit);
 const char* lsdm_profile_kernel_name(int k);

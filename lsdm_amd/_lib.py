@@ -39,6 +39,7 @@ _SIGNATURES = {
     "lsdm_three_nn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "lsdm_scene_encoder": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "lsdm_human_backbone": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "lsdm_nn_distance": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "lsdm_workspace_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "lsdm_profile_begin": (_i, [_vp]),
     "lsdm_profile_end": (_i, [_vp, _i, _vp, _vp, _vp]),

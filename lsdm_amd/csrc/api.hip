@@ -71,6 +71,7 @@ struct lsdm_ctx {
     Dense up2{};
     StepCoefs sched{};
     int sched_T = 0;
+    std::vector<void*> sched_allocs;    // the seven tables: owned apart from the parameter arena (lsdm_finalize_params frees that one)
     // workspace
     int cap_B = 0;
     std::vector<void*> ws_allocs;
@@ -95,10 +96,33 @@ struct lsdm_ctx {
         float* nn_w[4] = {};
         float *e0 = nullptr, *tr = nullptr, *w = nullptr, *h2p = nullptr;
         int64_t* tbuf = nullptr;
-    } fs[kGroup];
+    } fs0;                              // set 0 = base of every [kGroup][...] allocation
+    // Set j of a group of steps at batch B.  The batched launches of a group (fill_steps, cond, upsample12, FPS chain, ball
+    // queries, 3-NN) write step j right behind step j-1 at the CURRENT batch size (row = step*B + b, cloud = step*B*9 + c),
+    // so the per-step views are derived from B at call time -- not from the reserved capacity.
+    FrontSet fset(int j, int B) const {
+        FrontSet f = fs0;
+        if (j == 0) return f;
+        static const int S[4] = {1024, 256, 64, 16}, NN[4] = {64, 256, 1024, 1024};
+        const size_t nc = (size_t)B * 9, o = (size_t)j;
+        for (int l = 0; l < 4; ++l) {
+            f.idx[l] += o * nc * S[l];
+            f.xyz[l] += o * nc * S[l] * 3;
+            f.ball[l] += o * nc * S[l] * 32;
+            f.nn_idx[l] += o * nc * NN[l] * 3;
+            f.nn_w[l] += o * nc * NN[l] * 3;
+        }
+        f.e0 += o * B * 256;
+        f.tr += o * nc * 12;
+        f.w += o * nc;
+        // upsample12_kernel packs one chain as 256 x 512 fp32 (f32), bf16 hi + lo (bf16x3: the same bytes) or bf16 hi only
+        f.h2p += o * B * (prec == LSDM_PREC_BF16 ? 256 * 256 : 256 * 512);
+        f.tbuf += o * B;
+        return f;
+    }
     float* feat[4] = {};
     float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
-    float *hm = nullptr, *o12 = nullptr, *xs = nullptr;
+    float *hm = nullptr, *o12 = nullptr, *xs = nullptr, *posa_ws = nullptr;
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -118,6 +142,23 @@ int fail(lsdm_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
+// Every entry point runs on the context's device and leaves the calling thread's current device as it found it
+// (the host framework tracks its own current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(lsdm_ctx* c) : DeviceGuard(c, c->device) {}
+    DeviceGuard(lsdm_ctx* c, int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == device) { ok = true; prev = -1; return; }
+        ok = hipSetDevice(device) == hipSuccess;
+        if (!ok) fail(c, LSDM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 #define HIP_TRY(c, expr)                                                                         \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
@@ -125,18 +166,18 @@ int fail(lsdm_ctx* c, int code, const char* fmt, ...) {
     } while (0)
 
 enum KernelId { K_COND = 0, K_UP12, K_POSA, K_FPS, K_BALL1, K_BALL2, K_BALL3, K_BALL4, K_SA1, K_SA2, K_SA3, K_SA4, K_NN4, K_NN3, K_NN2,
-                K_NN1, K_FP4, K_FP3, K_FP2, K_FP1, K_SATTN, K_DENOISE, K_COUNT };
+                K_NN1, K_FP4, K_FP3, K_FP2, K_FP1, K_SATTN, K_DENOISE, K_REMAP, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"cond_kernel", "upsample12_kernel", "posa_kernel", "fps_chain_kernel", "ball_query<1024>/sa1",
     "ball_query<1024>/sa2", "ball_query<256>/sa3", "ball_query<64>/sa4", "sa_kernel<3,32,32,64>", "sa_kernel<64,64,64,128>",
     "sa_kernel<128,128,128,256>", "sa_kernel<256,256,256,512>", "three_nn<16>/fp4", "three_nn<64>/fp3", "three_nn<256>/fp2",
     "three_nn<1024>/fp1", "fp_kernel<fp4>", "fp_kernel<fp3>", "fp_kernel<fp2>", "fp_kernel<fp1+head>", "scene_attn_kernel",
-    "denoise_kernel"};
+    "denoise_kernel", "l1_remap_kernel"};
 // algorithmic MACs of one launch per cloud (encoder kernels) or per sample (others); SURVEY.md §8(d), DESIGN.md
 const double kKernelMacs[K_COUNT] = {0.24e6, 16.8e6, 7.2e6, 0, 0, 0, 0, 0,
     32768.0 * (6 * 32 + 32 * 32 + 32 * 64), 8192.0 * (67 * 64 + 64 * 64 + 64 * 128), 2048.0 * (131 * 128 + 128 * 128 + 128 * 256),
     512.0 * (259 * 256 + 256 * 256 + 256 * 512), 0, 0, 0, 0, 64.0 * (768 * 256 + 256 * 256), 256.0 * (384 * 256 + 256 * 256),
     1024.0 * (320 * 256 + 256 * 128), 1024.0 * (3 * 128 * 128 + 128 * 128 + 128 * 3), 0.0009e9 / 9,
-    1024.0 * (512 * 256 + 256 * 128 + 2 * (3 * 64 + 64 * 128 + 256 * 192 + 192 * 128 + 128 * 64 + 64 * 3))};
+    1024.0 * (512 * 256 + 256 * 128 + 2 * (3 * 64 + 64 * 128 + 256 * 192 + 192 * 128 + 128 * 64 + 64 * 3)), 0};
 
 void prof_mark(lsdm_ctx* c, int id, hipStream_t st) {
     if (!c->prof_on) return;
@@ -167,10 +208,10 @@ const HostTensor* find(lsdm_ctx* c, const std::string& name, std::initializer_li
     return &it->second;
 }
 
-float* upload(lsdm_ctx* c, const float* src, size_t n) {
+float* upload(lsdm_ctx* c, const float* src, size_t n, std::vector<void*>* owner = nullptr) {
     void* d = nullptr;
     if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) { fail(c, LSDM_ERR_HIP, "hipMalloc(%zu)", n * sizeof(float)); return nullptr; }
-    c->allocs.push_back(d);
+    (owner ? *owner : c->allocs).push_back(d);
     if (hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { fail(c, LSDM_ERR_HIP, "hipMemcpy H2D"); return nullptr; }
     return static_cast<float*>(d);
 }
@@ -445,8 +486,8 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
 }
 
 int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
-    run_geometry(c, c->fs[0], clouds, starts, nc, 1, st);
-    run_encoder_dense(c, c->fs[0], clouds, nc, out, st);
+    run_geometry(c, c->fs0, clouds, starts, nc, 1, st);
+    run_encoder_dense(c, c->fs0, clouds, nc, out, st);
     return check_launch(c, "scene encoder");
 }
 
@@ -461,7 +502,7 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
     launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B * g, f.h2p, st);
     if (!reuse_hm) {
         prof_mark(c, K_POSA, st);
-        launch_posa(c->posa, given_objs, B, c->hm, st);
+        launch_posa(c->posa, given_objs, B, c->posa_ws, c->hm, st);
     }
     prof_mark(c, -1, st);
 }
@@ -499,7 +540,7 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
               bool inv = false) {
     if (inv) {
         // level 1 of the encoder from the call's invariants: feature rows and 3-NN positions in this step's FPS order
-        prof_mark(c, K_SA1, st);
+        prof_mark(c, K_REMAP, st);
         const int np = c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1);
         launch_l1_remap(B * kO, c->inv_F1, np == 1 ? 128 : 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], given_objs,
                         np == 1 ? c->feat_b[0] : (void*)c->feat[0], f.nn_idx[3], f.nn_w[3], st);
@@ -511,8 +552,8 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
 int run_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
              const float* given_cats, const float* text, const int64_t* starts, const float* noise, float* out_cat, float* out_x0,
              float* out_guiding, float* out_sample, hipStream_t st, bool reuse_hm = false) {
-    run_front(c, c->fs[0], B, t, mask, given_objs, given_cats, text, starts, out_cat, reuse_hm, st);
-    run_back(c, c->fs[0], mode, eta, B, x, t, mask, given_objs, noise, out_x0, out_guiding, out_sample, st);
+    run_front(c, c->fs0, B, t, mask, given_objs, given_cats, text, starts, out_cat, reuse_hm, st);
+    run_back(c, c->fs0, mode, eta, B, x, t, mask, given_objs, noise, out_x0, out_guiding, out_sample, st);
     return check_launch(c, "step");
 }
 
@@ -533,7 +574,8 @@ int lsdm_create(lsdm_ctx** out, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(nullptr, LSDM_ERR_HIP, "no HIP device available");
     if (device < 0 || device >= n) return fail(nullptr, LSDM_ERR_ARG, "device %d out of range (%d devices)", device, n);
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, LSDM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    DeviceGuard guard(nullptr, device);
+    if (!guard.ok) return LSDM_ERR_HIP;
     lsdm_ctx* c = new lsdm_ctx();
     c->device = device;
     int cus = 0;
@@ -544,11 +586,14 @@ int lsdm_create(lsdm_ctx** out, int device) {
 
 int lsdm_destroy(lsdm_ctx* c) {
     if (!c) return LSDM_OK;
-    (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
-    for (void* p : c->allocs) (void)hipFree(p);
-    for (void* p : c->ws_allocs) (void)hipFree(p);
-    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    {
+        DeviceGuard guard(c);
+        (void)hipDeviceSynchronize();
+        for (void* p : c->allocs) (void)hipFree(p);
+        for (void* p : c->sched_allocs) (void)hipFree(p);
+        for (void* p : c->ws_allocs) (void)hipFree(p);
+        for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    }
     delete c;
     return LSDM_OK;
 }
@@ -568,7 +613,8 @@ int lsdm_set_param(lsdm_ctx* c, const char* name, const float* data, const int64
 int lsdm_set_precision(lsdm_ctx* c, int precision) {
     if (!c || precision < LSDM_PREC_F32 || precision > LSDM_PREC_BF16) return fail(c, LSDM_ERR_ARG, "lsdm_set_precision: bad precision %d", precision);
     if (precision != c->prec) {
-        HIP_TRY(c, hipSetDevice(c->device));
+        DeviceGuard guard(c);
+        if (!guard.ok) return LSDM_ERR_HIP;
         HIP_TRY(c, hipDeviceSynchronize());
         // operand packing and the workspace element types depend on it
         c->prec = precision;
@@ -585,7 +631,8 @@ int lsdm_get_precision(const lsdm_ctx* c) { return c ? c->prec : LSDM_ERR_ARG; }
 
 int lsdm_finalize_params(lsdm_ctx* c, int C) {
     if (!c || C <= 0 || C > 512) return fail(c, LSDM_ERR_ARG, "lsdm_finalize_params: bad max_cats");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     for (void* p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
     c->max_cats = C;
@@ -759,7 +806,9 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
             c->posa.gn_b[i] = upload(c, gb->data.data(), 64);
         }
     }
-    ok = ok && load_lin(c, "human_backbone.de_spiral.3.layer", 3, 64, &c->posa.last);
+    ok = ok && load_lin(c, "human_backbone.de_spiral.3.layer", 3, 64, &c->posa.last) &&
+         load_dense(c, "human_backbone.de_spiral.1.conv.layer.weight", "human_backbone.de_spiral.1.conv.layer.bias", "", 64, 64, &c->posa.d1) &&
+         load_dense(c, "human_backbone.de_spiral.2.conv.layer.weight", "human_backbone.de_spiral.2.conv.layer.bias", "", 64, 64, &c->posa.d2);
     // pcd_attention
     if (ok) {
         const HostTensor* wq = find(c, "pcd_attention.q_proj_weight", {12, 12});
@@ -836,15 +885,23 @@ int lsdm_set_schedule(lsdm_ctx* c, int T, const float* coef1, const float* coef2
                       const float* srm1, const float* acp, const float* acp_prev) {
     if (!c || T <= 0 || T > 5000 || !coef1 || !coef2 || !logvar || !sr || !srm1 || !acp || !acp_prev)
         return fail(c, LSDM_ERR_ARG, "lsdm_set_schedule: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->sched.coef1 = upload(c, coef1, T);
-    c->sched.coef2 = upload(c, coef2, T);
-    c->sched.logvar = upload(c, logvar, T);
-    c->sched.sr_acp = upload(c, sr, T);
-    c->sched.srm1_acp = upload(c, srm1, T);
-    c->sched.acp = upload(c, acp, T);
-    c->sched.acp_prev = upload(c, acp_prev, T);
-    if (!c->sched.acp_prev) return LSDM_ERR_HIP;
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
+    // kernels of earlier calls may still read the previous tables
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (void* p : c->sched_allocs) (void)hipFree(p);
+    c->sched_allocs.clear();
+    c->sched_T = 0;
+    c->sched.coef1 = upload(c, coef1, T, &c->sched_allocs);
+    c->sched.coef2 = upload(c, coef2, T, &c->sched_allocs);
+    c->sched.logvar = upload(c, logvar, T, &c->sched_allocs);
+    c->sched.sr_acp = upload(c, sr, T, &c->sched_allocs);
+    c->sched.srm1_acp = upload(c, srm1, T, &c->sched_allocs);
+    c->sched.acp = upload(c, acp, T, &c->sched_allocs);
+    c->sched.acp_prev = upload(c, acp_prev, T, &c->sched_allocs);
+    if (!c->sched.coef1 || !c->sched.coef2 || !c->sched.logvar || !c->sched.sr_acp || !c->sched.srm1_acp || !c->sched.acp ||
+        !c->sched.acp_prev)
+        return LSDM_ERR_HIP;
     c->sched_T = T;
     return LSDM_OK;
 }
@@ -852,7 +909,8 @@ int lsdm_set_schedule(lsdm_ctx* c, int T, const float* coef1, const float* coef2
 int lsdm_reserve(lsdm_ctx* c, int B) {
     if (!c || B <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_reserve: bad batch");
     if ((long long)B * kO > 65535) return fail(c, LSDM_ERR_ARG, "lsdm_reserve: batch %d exceeds 7281 chains per context (65535 clouds per launch)", B);
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     if (B <= c->cap_B) return LSDM_OK;
     HIP_TRY(c, hipDeviceSynchronize());
     for (void* p : c->ws_allocs) (void)hipFree(p);
@@ -867,22 +925,18 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
     const int nn_n[4] = {64, 256, 1024, 1024};
     {
         // front sets: one allocation per tensor, [kGroup][...]; set 0 carries the plain workspace names (the parity
-        // tests read them after single-step calls), the views of sets 1.. are registered with a "_g<j>" suffix
+        // tests read them after single-step calls), the views of sets 1.. are derived per call (lsdm_ctx::fset)
         constexpr int G = lsdm_ctx::kGroup;
         auto grouped = [&](const std::string& name, size_t per_set, auto** slot0, size_t elem) -> bool {
             typedef typename std::remove_pointer<typename std::remove_pointer<decltype(slot0)>::type>::type T;
             T* base = ws_alloc<T>(c, name.c_str(), per_set * G);
             if (!base) return false;
             c->ws_named[name] = {base, (int64_t)per_set};
-            for (int j = 0; j < G; ++j) {
-                T** slot = reinterpret_cast<T**>(reinterpret_cast<char*>(slot0) + (size_t)j * sizeof(lsdm_ctx::FrontSet));
-                *slot = base + (size_t)j * per_set;
-                if (j > 0) c->ws_named[name + "_g" + std::to_string(j)] = {*slot, (int64_t)per_set};
-            }
+            *slot0 = base;
             (void)elem;
             return true;
         };
-        lsdm_ctx::FrontSet& f0 = c->fs[0];
+        lsdm_ctx::FrontSet& f0 = c->fs0;
         for (int l = 0; l < 4 && ok; ++l) {
             ok = grouped(std::string("fps_idx") + lv[l], nc * kS[l], &f0.idx[l], 4) && grouped(std::string("xyz") + lv[l], nc * kS[l] * 3, &f0.xyz[l], 4) &&
                  grouped(std::string("ball") + lv[l], nc * kS[l] * 32, &f0.ball[l], 4) &&
@@ -895,7 +949,7 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
     ok = ok && (c->fpo4 = ws_alloc<float>(c, "fp4", nc * 64 * 256)) && (c->fpo3 = ws_alloc<float>(c, "fp3", nc * 256 * 256)) &&
          (c->fpo2 = ws_alloc<float>(c, "fp2", nc * 1024 * 128)) && (c->pcd = ws_alloc<float>(c, "pcd", nc * kN * 3)) &&
          (c->hm = ws_alloc<float>(c, "hm", (size_t)B * kN * 3)) && (c->o12 = ws_alloc<float>(c, "o12", nc * 12)) &&
-         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->inv_ball = ws_alloc<int>(c, "inv_ball", nc * kN * 32)) &&
+         (c->xs = ws_alloc<float>(c, "xs", (size_t)B * kN * 3)) && (c->posa_ws = ws_alloc<float>(c, "posa_ws", (size_t)B * kPosaWsPerSample)) && (c->inv_ball = ws_alloc<int>(c, "inv_ball", nc * kN * 32)) &&
          (c->inv_F1 = ws_alloc<float>(c, "inv_f1", nc * kN * 64)) && (c->inv_nn8_d = ws_alloc<float>(c, "inv_nn8_d", nc * kN * 8)) &&
          (c->inv_nn8_i = ws_alloc<int>(c, "inv_nn8_i", nc * kN * 8)) && (c->sa_U[0] = ws_alloc<float>(c, "sa3_u", nc * 256 * 128)) &&
          (c->sa_V[0] = ws_alloc<float>(c, "sa3_v", nc * 256 * 128)) && (c->sa_U[1] = ws_alloc<float>(c, "sa4_u", nc * 64 * 256)) &&
@@ -922,7 +976,8 @@ int lsdm_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* ma
     if (!x || !mask || !t || !given_objs || !given_cats || !text || !starts || !out_cat || !out_x0 || !out_guiding ||
         (mode != LSDM_MODE_FORWARD && !out_sample))
         return fail(c, LSDM_ERR_ARG, "lsdm_step: NULL tensor");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     return run_step(c, mode, eta, B, x, mask, t, given_objs, given_cats, text, starts, noise, out_cat, out_x0, out_guiding, out_sample,
                     static_cast<hipStream_t>(stream));
 }
@@ -936,7 +991,8 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
     if (K <= 0 || t_first >= c->sched_T || t_first - K + 1 < 0) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: steps [%d..%d] outside schedule", t_first - K + 1, t_first);
     if (!x || !mask || !given_objs || !given_cats || !text || !starts || !noise || !out_cat || !out_x0 || !out_guiding)
         return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: NULL tensor");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* cur = x;
     float* nxt = c->xs;
@@ -969,12 +1025,12 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
     }
     for (int k0 = 0; k0 < K; k0 += gmax) {
         const int g = K - k0 < gmax ? K - k0 : gmax;
-        hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);
-        run_conditioning(c, c->fs[0], B, g, c->fs[0].tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
-        run_geometry(c, c->fs[0], given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
+        hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
+        run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
+        run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
-            lsdm_ctx::FrontSet& f = c->fs[j];
+            const lsdm_ctx::FrontSet f = c->fset(j, B);
             run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st, inv);
             rc = check_launch(c, "sample step");
             if (rc) return rc;
@@ -1008,7 +1064,8 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
     if (K <= 0 || t_first >= c->sched_T || t_first - K + 1 < 0) return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps_hoisted: steps [%d..%d] outside schedule", t_first - K + 1, t_first);
     if (!x || !mask || !given_objs || !given_cats || !text || !starts || !noise || !out_cat || !out_x0 || !out_guiding)
         return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps_hoisted: NULL tensor");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* cur = x;
     float* nxt = c->xs;
@@ -1018,15 +1075,15 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
     for (int k0 = 0; k0 < K; k0 += lsdm_ctx::kGroup) {
         const int g = K - k0 < lsdm_ctx::kGroup ? K - k0 : lsdm_ctx::kGroup;
         // per group: the t-dependent conditioning of its steps in one launch per stage
-        hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs[0].tbuf, (int64_t)(t_first - k0), B, g);
-        run_conditioning(c, c->fs[0], B, g, c->fs[0].tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
+        hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
+        run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
         if (k0 == 0) {
-            run_geometry(c, c->fs[0], given_objs, starts, B * kO, 1, st);
-            run_scene_conditioning(c, c->fs[0], B, given_objs, st);
+            run_geometry(c, c->fs0, given_objs, starts, B * kO, 1, st);
+            run_scene_conditioning(c, c->fs0, B, given_objs, st);
         }
         // per step: the fused denoiser + sampler update (the only stage that reads x)
         for (int j = 0; j < g; ++j) {
-            lsdm_ctx::FrontSet& f = c->fs[j];
+            const lsdm_ctx::FrontSet f = c->fset(j, B);
             run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)(k0 + j) * xn, out_x0, out_guiding, nxt, st);
             rc = check_launch(c, "hoisted sample step");
             if (rc) return rc;
@@ -1040,7 +1097,8 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
 int lsdm_fps(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, int32_t* i1, int32_t* i2, int32_t* i3, int32_t* i4,
              float* x1, float* x2, float* x3, float* x4, void* stream) {
     if (!c || !clouds || !starts || nc <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_fps: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     int* idx[4] = {i1, i2, i3, i4};
     float* xyz[4] = {x1, x2, x3, x4};
     launch_fps_chain(clouds, starts, nc, nc, idx, xyz, static_cast<hipStream_t>(stream));
@@ -1050,7 +1108,8 @@ int lsdm_fps(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, in
 int lsdm_ball_query(lsdm_ctx* c, const float* xyz, const float* new_xyz, int nc, int N, int S, double radius, int32_t* out, void* stream) {
     if (!c || !xyz || !new_xyz || !out || nc <= 0 || S <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_ball_query: bad argument");
     if (N != 1024 && N != 256 && N != 64) return fail(c, LSDM_ERR_ARG, "lsdm_ball_query: N must be 1024, 256 or 64");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     const float r2 = (float)(radius * radius);
     launch_ball_query(xyz, new_xyz, nc, N, S, r2, out, 0, static_cast<hipStream_t>(stream));
     return check_launch(c, "ball_query");
@@ -1059,7 +1118,8 @@ int lsdm_ball_query(lsdm_ctx* c, const float* xyz, const float* new_xyz, int nc,
 int lsdm_three_nn(lsdm_ctx* c, const float* fine, const float* coarse, int nc, int N, int S, int32_t* idx, float* w, void* stream) {
     if (!c || !fine || !coarse || !idx || !w || nc <= 0 || N <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_three_nn: bad argument");
     if (S != 1024 && S != 256 && S != 64 && S != 16) return fail(c, LSDM_ERR_ARG, "lsdm_three_nn: S must be 1024, 256, 64 or 16");
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     launch_three_nn(fine, coarse, nc, N, S, idx, w, 0, static_cast<hipStream_t>(stream));
     return check_launch(c, "three_nn");
 }
@@ -1068,16 +1128,28 @@ int lsdm_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, 
     if (!c || !clouds || !starts || !out || nc <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_scene_encoder: bad argument");
     if (!c->finalized) return fail(c, LSDM_ERR_STATE, "parameters not finalised");
     if ((nc + kO - 1) / kO > c->cap_B) return fail(c, LSDM_ERR_STATE, "%d clouds exceed the reserved workspace (%d samples)", nc, c->cap_B);
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     return run_scene_encoder(c, clouds, starts, nc, out, static_cast<hipStream_t>(stream));
 }
 
 int lsdm_human_backbone(lsdm_ctx* c, const float* given_objs, int B, float* hm, void* stream) {
     if (!c || !given_objs || !hm || B <= 0) return fail(c, LSDM_ERR_ARG, "lsdm_human_backbone: bad argument");
     if (!c->finalized) return fail(c, LSDM_ERR_STATE, "parameters not finalised");
-    HIP_TRY(c, hipSetDevice(c->device));
-    launch_posa(c->posa, given_objs, B, hm, static_cast<hipStream_t>(stream));
+    if (B > c->cap_B) return fail(c, LSDM_ERR_STATE, "batch %d exceeds reserved workspace %d (lsdm_reserve)", B, c->cap_B);
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
+    launch_posa(c->posa, given_objs, B, c->posa_ws, hm, static_cast<hipStream_t>(stream));
     return check_launch(c, "posa");
+}
+
+int lsdm_nn_distance(lsdm_ctx* c, const float* a, int na, const float* b, int nb, int batch, float* out_d2, int32_t* out_idx, void* stream) {
+    if (!c || !a || !b || !out_d2 || na <= 0 || nb <= 0 || batch <= 0 || batch > 65535)
+        return fail(c, LSDM_ERR_ARG, "lsdm_nn_distance: bad argument");
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
+    launch_nn_dist(a, na, b, nb, batch, out_d2, out_idx, static_cast<hipStream_t>(stream));
+    return check_launch(c, "nn_distance");
 }
 
 int lsdm_profile_begin(lsdm_ctx* c) {
@@ -1090,7 +1162,8 @@ int lsdm_profile_begin(lsdm_ctx* c) {
 int lsdm_profile_end(lsdm_ctx* c, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit) {
     if (!c || !total_ms || !launches || capacity < K_COUNT) return fail(c, LSDM_ERR_ARG, "lsdm_profile_end: need capacity >= %d", (int)K_COUNT);
     c->prof_on = false;
-    HIP_TRY(c, hipSetDevice(c->device));
+    DeviceGuard guard(c);
+    if (!guard.ok) return LSDM_ERR_HIP;
     HIP_TRY(c, hipDeviceSynchronize());
     for (int k = 0; k < K_COUNT; ++k) { total_ms[k] = 0.0; launches[k] = 0; if (macs_per_unit) macs_per_unit[k] = kKernelMacs[k]; }
     for (size_t i = 0; i + 1 < c->prof_cur; ++i) {

@@ -2,9 +2,9 @@
 //
 //   cond_kernel        steps 1-4, 8, 10 of SURVEY.md §3.2: timestep MLP, text MLP, category head, category
 //                      embedding, object-attention weights (with the mask-order quirk Q3/Q4), translation tokens.
-//   posa_kernel        POSA Decoder with seq_length = 1 (posa/posa_models.py:310-326): per-point MLP with
-//                      GroupNorm(8,64) over the whole sample; one 1024-thread workgroup per sample, one point
-//                      per thread, activations never leave registers.
+//   posa_stage_kernel  POSA Decoder with seq_length = 1 (posa/posa_models.py:310-326): per-vertex MLP with
+//                      GroupNorm(8,64) over the whole sample; three launches of 64-vertex tiles that re-evaluate
+//                      the decoder up to their block and exchange only mergeable moment triples.
 //   upsample12_kernel  first two layers of upsampling_layer (model/sdm.py:104-111,164-167) on the (B*256) rows of
 //                      [ets || enc]; the result is written directly in the packed B-operand layout consumed by
 //                      the third layer inside denoise_kernel (denoise.hip).
@@ -135,107 +135,170 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// block-wide sum of 8 per-group partials; result broadcast to all threads through LDS
-__device__ __forceinline__ void block_sum8(float (&v)[8], float (*red)[8], float* tot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// POSA decoder (posa/posa_models.py:310-326) in three launches of 64-vertex tiles.
+//
+// GroupNorm(8, 64) takes its statistics over (8 channels x all vertices) of a sample, so every block of the decoder needs a
+// sample-wide reduction before it can normalise.  A sample is 1024 x 3 floats and a block is 4096 MAC per vertex: far
+// cheaper to RE-EVALUATE than to synchronise or to spill.  Each launch recomputes the decoder from the vertices up to its own
+// block (deterministic: every re-evaluation produces the same bits), reduces that block's pre-activations per tile with a
+// mergeable (count, mean, M2) triple, and the NEXT launch merges the tiles of its sample in a fixed order (Chan et al.; as
+// accurate as a two-pass evaluation).  Nothing but the triples (a few KB) goes through memory; the 64 -> 64 blocks run on the
+// exact-fp32 matrix pipe (mlp_core.hpp) from LDS tiles.
+//   stage A (16 tiles): block-1 statistics of the whole sample (each tile re-derives them from the 1024 vertices: 768 FMA per
+//                       thread), blocks 1-2 on its tile -> block-2 triple of the tile
+//   stage B (11 tiles): + block 3 on the first 655 vertices (index_select with the identity spiral) -> block-3 triple
+//   stage C ( 8 tiles): + Linear 64 -> 3, nearest x2 along the vertex axis cut to 1024 rows: vertex i < 512 feeds rows 2i, 2i+1
+struct Moments { float n, mean, m2; };
+__device__ __forceinline__ Moments merge(Moments a, Moments b) {
+    const float n = a.n + b.n;
+    if (n == 0.0f) return Moments{0.0f, 0.0f, 0.0f};
+    const float d = b.mean - a.mean, f = b.n / n;
+    return Moments{n, fmaf(d, f, a.mean), a.m2 + b.m2 + d * d * a.n * f};
+}
+__device__ __forceinline__ Moments shfl_xor(Moments m, int off) {
+    return Moments{__shfl_xor(m.n, off), __shfl_xor(m.mean, off), __shfl_xor(m.m2, off)};
+}
+// moments of v[0..cnt) (two-pass in registers)
+template <int N>
+__device__ __forceinline__ Moments local_moments(const float (&v)[N], bool live) {
+    if (!live) return Moments{0.0f, 0.0f, 0.0f};
+    float s = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        float s = v[g];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) red[wave][g] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        float s = 0.0f;
-        for (int w = 0; w < 16; ++w) s += red[w][threadIdx.x];
-        tot[threadIdx.x] = s;
-    }
-    __syncthreads();
+    for (int i = 0; i < N; ++i) s += v[i];
+    const float mean = s * (1.0f / N);
+    float m2 = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) v[g] = tot[g];
-    __syncthreads();
+    for (int i = 0; i < N; ++i) { const float d = v[i] - mean; m2 = fmaf(d, d, m2); }
+    return Moments{(float)N, mean, m2};
 }
 
-// GroupNorm(8, 64) over (8 channels x count points) + ReLU, in place on the thread's 64 channels
-__device__ __forceinline__ void group_norm_relu(float (&h)[64], bool active, float count, const float* __restrict__ gw,
-                                                const float* __restrict__ gb, float (*red)[8], float* tot) {
-    float s[8];
+constexpr int kPosaTile = 64, kPosaLD = 68;   // (LD / 4) odd: conflict-free ds_read_b128 of the MFMA A operand
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void posa_stage_kernel(PosaParams P, const float* __restrict__ given_objs, float* __restrict__ stat1,
+                                                         float* __restrict__ part2, float* __restrict__ part3, float* __restrict__ hm) {
+    __shared__ __attribute__((aligned(16))) float bufA[kPosaTile * kPosaLD];
+    __shared__ __attribute__((aligned(16))) float bufB[kPosaTile * kPosaLD];
+    __shared__ float w1[64 * 3], b1[64], gnw[3][64], gnb[3][64], w4[3 * 64], mean_s[8], rstd_s[8];
+    __shared__ Moments red[4][8];
+    constexpr int TILES = STAGE == 0 ? 16 : (STAGE == 1 ? 11 : 8);
+    const int b = blockIdx.x / TILES, tile = blockIdx.x - b * TILES, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* verts = given_objs + (size_t)b * kSlots * kPoints * 3;   // slot 0 = human
+    for (int e = tid; e < 192; e += 256) { w1[e] = P.lin[0].w[e]; w4[e] = P.last.w[e]; }
+    if (tid < 64) {
+        b1[tid] = P.lin[0].b[tid];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        float a = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a += h[g * 8 + k];
-        s[g] = active ? a : 0.0f;
+        for (int i = 0; i < 3; ++i) { gnw[i][tid] = P.gn_w[i][tid]; gnb[i][tid] = P.gn_b[i][tid]; }
     }
-    block_sum8(s, red, tot);
-    float mean[8], v[8];
+    __syncthreads();
+    // ---- block-1 statistics of the sample
+    if constexpr (STAGE == 0) {
+        // thread = (group g = tid & 7, vertex slot tid >> 3): 32 vertices x 8 channels of one group
+        const int g = tid & 7, v0 = tid >> 3;
+        Moments acc{0.0f, 0.0f, 0.0f};
+        for (int it = 0; it < 4; ++it) {
+            float vals[64];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        mean[g] = s[g] / count;
-        float a = 0.0f;
+            for (int q = 0; q < 8; ++q) {
+                const float* x = verts + (size_t)(v0 + 32 * (q + 8 * it)) * 3;
+                const float x0 = x[0], x1 = x[1], x2 = x[2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = h[g * 8 + k] - mean[g]; a = fmaf(d, d, a); }
-        v[g] = active ? a : 0.0f;
+                for (int k = 0; k < 8; ++k) {
+                    const int ch = g * 8 + k;
+                    vals[q * 8 + k] = fmaf(x2, w1[ch * 3 + 2], fmaf(x1, w1[ch * 3 + 1], x0 * w1[ch * 3])) + b1[ch];
+                }
+            }
+            acc = merge(acc, local_moments(vals, true));
+        }
+        // lanes with equal (tid & 7) hold the same group: xor over bits 3..5 inside the wave, then across the 4 waves
+        for (int off = 8; off < 64; off <<= 1) acc = merge(acc, shfl_xor(acc, off));
+        if (lane < 8) red[wave][lane] = acc;
+        __syncthreads();
+        if (tid < 8) {
+            Moments m = merge(merge(red[0][tid], red[1][tid]), merge(red[2][tid], red[3][tid]));
+            mean_s[tid] = m.mean;
+            rstd_s[tid] = 1.0f / sqrtf(m.m2 / m.n + 1e-5f);
+            if (tile == 0) { stat1[b * 16 + tid] = mean_s[tid]; stat1[b * 16 + 8 + tid] = rstd_s[tid]; }
+        }
+    } else {
+        if (tid < 8) { mean_s[tid] = stat1[b * 16 + tid]; rstd_s[tid] = stat1[b * 16 + 8 + tid]; }
     }
-    block_sum8(v, red, tot);
+    __syncthreads();
+    // ---- block 1 on the tile: thread = (row = tid >> 2, 16 channels)
+    {
+        const int row = tid >> 2, c0 = (tid & 3) * 16;
+        const float* x = verts + (size_t)(tile * kPosaTile + row) * 3;
+        const float x0 = x[0], x1 = x[1], x2 = x[2];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const float rstd = 1.0f / sqrtf(v[g] / count + 1e-5f);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ch = g * 8 + k;
-            h[ch] = reluf((h[ch] - mean[g]) * rstd * gw[ch] + gb[ch]);
+        for (int k = 0; k < 16; ++k) {
+            const int ch = c0 + k, g = ch >> 3;
+            const float h = fmaf(x2, w1[ch * 3 + 2], fmaf(x1, w1[ch * 3 + 1], x0 * w1[ch * 3])) + b1[ch];
+            bufA[row * kPosaLD + ch] = reluf((h - mean_s[g]) * rstd_s[g] * gnw[0][ch] + gnb[0][ch]);
         }
     }
-}
-
-__global__ __launch_bounds__(1024) void posa_kernel(PosaParams P, const float* __restrict__ given_objs, float* __restrict__ hm) {
-    __shared__ float red[16][8];
-    __shared__ float tot[8];
-    const int b = blockIdx.x, n = threadIdx.x;
-    const float* v = given_objs + ((size_t)b * kSlots * kPoints + n) * 3;  // slot 0 = human
-    const float x0 = v[0], x1 = v[1], x2 = v[2];
-    float h[64], g[64];
+    __syncthreads();
+    // ---- blocks 2 (and 3): Linear 64 -> 64 on the matrix pipe, GroupNorm from the merged tile triples, ReLU
+    // statistics layout: thread = (group g = tid >> 5, r = tid & 31) owns rows r and r + 32, 8 channels: 16 values
+    const int sg = tid >> 5, sr = tid & 31;
+    float* src = bufA;
+    float* dst = bufB;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float* w = P.lin[0].w + j * 3;
-        h[j] = fmaf(x2, w[2], fmaf(x1, w[1], x0 * w[0])) + P.lin[0].b[j];
+    for (int blk = 1; blk <= (STAGE == 0 ? 1 : 2); ++blk) {
+        layer_lds<4, kPosaTile, 64, 64, ACT_NONE>(src, kPosaLD, blk == 1 ? P.d1.w : P.d2.w, blk == 1 ? P.d1.b : P.d2.b, dst, kPosaLD);
+        __syncthreads();
+        const int valid = blk == 1 ? kPosaTile : min(kPosaTile, 655 - tile * kPosaTile);   // block 3 sees 655 vertices
+        const bool mine = blk == (STAGE == 0 ? 1 : 2) && STAGE < 2;                        // this launch produces this block's triple
+        float* part = blk == 1 ? part2 : part3;
+        const int ntile = blk == 1 ? 16 : 11;
+        if (mine) {
+            Moments m{0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = dst[(sr + 32 * hh) * kPosaLD + sg * 8 + k];
+                m = merge(m, local_moments(v, sr + 32 * hh < valid));
+            }
+            for (int off = 1; off < 32; off <<= 1) m = merge(m, shfl_xor(m, off));
+            if (sr == 0) {
+                float* o = part + ((size_t)(b * ntile + tile) * 8 + sg) * 3;
+                o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+            }
+        } else {
+            // merge the tiles of the sample in tile order (every work-group of the sample computes the same bits)
+            if (tid < 8) {
+                Moments m{0.0f, 0.0f, 0.0f};
+                for (int t = 0; t < ntile; ++t) {
+                    const float* o = part + ((size_t)(b * ntile + t) * 8 + tid) * 3;
+                    m = merge(m, Moments{o[0], o[1], o[2]});
+                }
+                mean_s[tid] = m.mean;
+                rstd_s[tid] = 1.0f / sqrtf(m.m2 / m.n + 1e-5f);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ch = sg * 8 + k, at = (sr + 32 * hh) * kPosaLD + ch;
+                    dst[at] = reluf((dst[at] - mean_s[sg]) * rstd_s[sg] * gnw[blk][ch] + gnb[blk][ch]);
+                }
+            __syncthreads();
+            float* t2 = src; src = dst; dst = t2;
+        }
     }
-    group_norm_relu(h, true, 8.0f * kPoints, P.gn_w[0], P.gn_b[0], red, tot);
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float* w = P.lin[1].w + j * 64;
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) s = fmaf(h[k], w[k], s);
-        g[j] = s + P.lin[1].b[j];
-    }
-    group_norm_relu(g, true, 8.0f * kPoints, P.gn_w[1], P.gn_b[1], red, tot);
-    // third block runs on the first 655 vertices only (index_select with the identity spiral)
-    const bool act = n < 655;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float* w = P.lin[2].w + j * 64;
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) s = fmaf(g[k], w[k], s);
-        h[j] = s + P.lin[2].b[j];
-    }
-    group_norm_relu(h, act, 8.0f * 655.0f, P.gn_w[2], P.gn_b[2], red, tot);
-    // Linear 64->3, nearest x2 along the vertex axis, cut to 1024 rows: vertex i < 512 feeds rows 2i, 2i+1
-    if (n < kPoints / 2) {
-        float o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* w = P.last.w + c * 64;
+    if constexpr (STAGE == 2) {
+        // src holds ReLU(GN3(block 3)) of the tile's 64 vertices (all < 512): Linear 64 -> 3, rows 2i and 2i + 1
+        if (tid < kPosaTile * 3) {
+            const int row = tid / 3, c = tid - row * 3;
             float s = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 64; ++k) s = fmaf(h[k], w[k], s);
-            o[c] = s + P.last.b[c];
+            for (int k = 0; k < 64; ++k) s = fmaf(src[row * kPosaLD + k], w4[c * 64 + k], s);
+            s += P.last.b[c];
+            float* o = hm + ((size_t)b * kPoints + 2 * (tile * kPosaTile + row)) * 3 + c;
+            o[0] = s;
+            o[3] = s;
         }
-        float* dst = hm + ((size_t)b * kPoints + 2 * n) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { dst[c] = o[c]; dst[3 + c] = o[c]; }
     }
 }
 
@@ -352,8 +415,14 @@ void launch_cond(const CondParams& P, const int64_t* t, const float* text, const
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st) {
     hipLaunchKernelGGL(cond_kernel, dim3(B * G), dim3(256), 0, st, P, t, text, given_cats, mask, B, C, out_cat, e0, tr, w);
 }
-void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st) {
-    hipLaunchKernelGGL(posa_kernel, dim3(B), dim3(1024), 0, st, P, given_objs, hm);
+void launch_posa(const PosaParams& P, const float* given_objs, int B, float* ws, float* hm, hipStream_t st) {
+    // ws: B * (16 + 16*24 + 11*24) floats: block-1 (mean, rstd) per sample, per-tile triples of blocks 2 and 3
+    float* stat1 = ws;
+    float* part2 = stat1 + (size_t)B * 16;
+    float* part3 = part2 + (size_t)B * 16 * 24;
+    hipLaunchKernelGGL(posa_stage_kernel<0>, dim3(B * 16), dim3(256), 0, st, P, given_objs, stat1, part2, part3, hm);
+    hipLaunchKernelGGL(posa_stage_kernel<1>, dim3(B * 11), dim3(256), 0, st, P, given_objs, stat1, part2, part3, hm);
+    hipLaunchKernelGGL(posa_stage_kernel<2>, dim3(B * 8), dim3(256), 0, st, P, given_objs, stat1, part2, part3, hm);
 }
 void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, void* h2p, hipStream_t st) {
     const dim3 grid(B * 256 / 64), block(256);

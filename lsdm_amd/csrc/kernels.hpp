@@ -32,6 +32,7 @@ struct PosaParams {
     const float* gn_w[3];  // human_backbone.de_spiral.{0,1,2}.norm.{weight,bias}
     const float* gn_b[3];
     Lin last;              // human_backbone.de_spiral.3.layer (3,64)
+    Dense d1, d2;          // lin[1], lin[2] packed for the exact-fp32 matrix pipe (mlp_core.hpp)
 };
 
 struct SceneAttnParams {
@@ -111,7 +112,9 @@ void launch_fp_pre(int which, int num_clouds, const float* points1, const float*
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st);
-void launch_posa(const PosaParams& P, const float* given_objs, int B, float* hm, hipStream_t st);
+// ws: B * 664 floats of scratch (moment triples of the GroupNorm reductions)
+void launch_posa(const PosaParams& P, const float* given_objs, int B, float* ws, float* hm, hipStream_t st);
+constexpr int kPosaWsPerSample = 16 + 16 * 24 + 11 * 24;
 // np = 0: fp32 operand for denoise_kernel; 1 / 2: bf16 planes for denoise_h_kernel
 void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, void* h2p, hipStream_t st);
 void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st);
@@ -119,6 +122,9 @@ void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* 
 void launch_denoise(const DenoiseParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
                     const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const float* h2p,
                     const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
+
+// metrics.hip: per point of A (batch,na,3) the squared distance to / index of its nearest point of B (batch,nb,3)
+void launch_nn_dist(const float* A, int na, const float* B, int nb, int batch, float* out_d2, int* out_idx, hipStream_t st);
 
 // denoise_bf.hip
 void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,

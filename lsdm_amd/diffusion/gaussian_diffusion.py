@@ -102,6 +102,16 @@ class GaussianDiffusion:
     def _scale_timesteps(self, t):
         return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
 
+    def _schedule_key(self):
+        """Digest of the seven tables the library gathers from (content, not identity)."""
+        if getattr(self, "_sched_digest", None) is None:
+            import hashlib
+            h = hashlib.sha1()
+            for a in self._device_tables():
+                h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+            self._sched_digest = h.hexdigest()
+        return self._sched_digest
+
     def _device_tables(self):
         return (self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
                 self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.alphas_cumprod,
@@ -184,7 +194,7 @@ class GaussianDiffusion:
 
     def _fused_step(self, mode, eta, model, x, mask, t, given_objs, given_cats, y, const_noise):
         inner = _unwrap(model)
-        inner._set_schedule((id(self), self.num_timesteps), self._device_tables())
+        inner._set_schedule(self._schedule_key(), self._device_tables())
         _, x0, sample = inner._run(mode, eta, x, mask, t, given_objs, given_cats, y,
                                    noise_fn=lambda: self._noise_like(x, const_noise))
         return {"sample": sample, "pred_xstart": x0}
@@ -210,7 +220,7 @@ class GaussianDiffusion:
             my_t = th.ones([B], device=device, dtype=th.long) * t_first
             img = self.q_sample(init_image, my_t, img)
         x = img.to(device=device, dtype=th.float32).contiguous().clone()
-        inner._set_schedule((id(self), self.num_timesteps), self._device_tables())
+        inner._set_schedule(self._schedule_key(), self._device_tables())
         text = inner._encode_text(y, B, x.device)      # the same features every step: encoded once
         from ..model.sdm import FPS_RANGES, NUM_SLOTS
         draw_starts = lambda: th.stack([th.randint(0, n, (B * NUM_SLOTS,), dtype=th.long) for n in FPS_RANGES])
@@ -263,9 +273,10 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                       denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
                       init_image=None, randomize_class=False, cond_fn_with_grad=False, dump_steps=None,
-                      const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=False):
-        """Reference signature (gaussian_diffusion.py:611-632) + keyword-only extensions: ``hoist_invariants`` (evaluate the
-        loop-invariant level-1 encoder work once per library call -- bit-identical results, lsdm_sample_steps_invariant), ``chunk_steps`` (steps per
+                      const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=True):
+        """Reference signature (gaussian_diffusion.py:611-632) + keyword-only extensions: ``hoist_invariants`` (default on: evaluate the
+        loop-invariant level-1 encoder work once per library call -- bit-identical results, lsdm_sample_steps_invariant; off = every
+        stage recomputed every step, lsdm_sample_steps), ``chunk_steps`` (steps per
         library call on the fused path; results do not depend on it) and ``hoist_conditioning`` (pin the FPS starts to
         the first step's draws and evaluate the scene conditioning once -- not the stock reference's behaviour)."""
         if (dump_steps is None and not progress and not randomize_class and not cond_fn_with_grad
@@ -324,19 +335,26 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
                          skip_timesteps=0, init_image=None, randomize_class=False, cond_fn_with_grad=False,
-                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=False):
-        if dump_steps is not None or const_noise:
-            raise NotImplementedError()
-        if not progress and not randomize_class and not cond_fn_with_grad and self._fusable(model, clip_denoised, denoised_fn, cond_fn):
+                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=True):
+        """Argument list of the reference's ``ddim_sample_loop`` (gaussian_diffusion.py:957-1000) with the conditioning
+        arguments threaded.  ``dump_steps`` behaves as in ``p_sample_loop`` (:661-680); ``const_noise`` is accepted for
+        signature compatibility -- the reference's DDIM step has no such argument (``ddim_sample`` :761-775 draws
+        ``randn_like``), and with the default eta = 0 the noise does not enter the sample at all."""
+        if (dump_steps is None and not progress and not randomize_class and not cond_fn_with_grad
+                and self._fusable(model, clip_denoised, denoised_fn, cond_fn)):
             return self._bulk_loop(_lib.MODE_DDIM, eta, model, shape, mask, given_objs, given_cats, y, noise, device,
                                    skip_timesteps, init_image, False, hoist_conditioning, chunk_steps, hoist_invariants)
-        final = None
-        for sample in self.ddim_sample_loop_progressive(
+        if hoist_conditioning:
+            raise NotImplementedError("hoist_conditioning needs the fused path (clip_denoised=False, no denoised_fn/cond_fn/dump_steps)")
+        final, dump = None, []
+        for i, sample in enumerate(self.ddim_sample_loop_progressive(
                 model, shape, mask, given_objs, given_cats, y, noise=noise, clip_denoised=clip_denoised,
                 denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, device=device, progress=progress,
-                eta=eta, skip_timesteps=skip_timesteps, init_image=init_image):
+                eta=eta, skip_timesteps=skip_timesteps, init_image=init_image)):
+            if dump_steps is not None and i in dump_steps:
+                dump.append(deepcopy(sample["sample"]))
             final = sample
-        return final["sample"]
+        return dump if dump_steps is not None else final["sample"]
 
     def ddim_sample_loop_progressive(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                                      denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False,

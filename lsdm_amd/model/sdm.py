@@ -142,12 +142,16 @@ class SceneDiffusionModel(nn.Module):
             self._cap = batch
 
     def _set_schedule(self, key, tables):
-        """tables: 7 fp32 numpy arrays (see lsdm_set_schedule)."""
-        if self._schedule_key != key:
-            ctx = self._context()
+        """tables: 7 numpy arrays (see lsdm_set_schedule); ``key`` identifies their CONTENT (a digest, never ``id()``:
+        two diffusion objects with the same length and different betas must not share an upload).  The library keeps the
+        tables in their own allocations, so re-finalising the parameters (load_state_dict / set_precision) leaves them
+        valid; a fresh context has none."""
+        ctx = self._context()
+        if self._schedule_key != (id(ctx), key):
             arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in tables]
             ctx.call("lsdm_set_schedule", len(arrs[0]), *[a.ctypes.data_as(_lib._vp) for a in arrs])
-            self._schedule_key = key
+            self._schedule_key = (id(ctx), key)
+            self._schedule_len = len(arrs[0])
 
     # ------------------------------------------------------------------ text boundary
     def _encode_text(self, y, batch, device):
@@ -163,9 +167,26 @@ class SceneDiffusionModel(nn.Module):
         return feats
 
     # ------------------------------------------------------------------ the hot path
-    def _run(self, mode, eta, x, mask, timesteps, given_objs, given_cats, y, fps_starts=None, noise_fn=None):
+    def _check_device(self, x):
         if not x.is_cuda:
             raise _lib.LsdmError("SceneDiffusionModel runs on the HIP device only; got a %s tensor" % x.device)
+        if x.device.index != self._device_index:
+            raise _lib.LsdmError("tensor on cuda:%d but the model's context is on cuda:%d (construct the model with device=%d)"
+                                 % (x.device.index, self._device_index, x.device.index))
+
+    @staticmethod
+    def _check_starts(starts, n_clouds):
+        """(…,4,n_clouds) start indices: level l draws from [0, FPS_RANGES[l]) (pointnet2_utils.py:72)."""
+        if starts.shape[-2:] != (4, n_clouds):
+            raise ValueError("fps_starts must be 4 vectors of B*9 = %d indices, got %s" % (n_clouds, tuple(starts.shape)))
+        lo = starts.amin(dim=-1).reshape(-1, 4).amin(dim=0).tolist()
+        hi = starts.amax(dim=-1).reshape(-1, 4).amax(dim=0).tolist()
+        for l, n in enumerate(FPS_RANGES):
+            if lo[l] < 0 or hi[l] >= n:
+                raise ValueError("fps_starts of level %d must lie in [0, %d), got [%d, %d]" % (l + 1, n, lo[l], hi[l]))
+
+    def _run(self, mode, eta, x, mask, timesteps, given_objs, given_cats, y, fps_starts=None, noise_fn=None):
+        self._check_device(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError("x must be a contiguous float32 tensor (it is updated in place)")
         B, O, N, _ = given_objs.shape
@@ -179,10 +200,19 @@ class SceneDiffusionModel(nn.Module):
         if given_cats.shape != (B, O, self.max_cats):
             raise ValueError("given_cats must be (B,9,%d)" % self.max_cats)
         t = timesteps.to(device=dev, dtype=torch.long).contiguous()
+        if t.shape != (B,):
+            raise ValueError("timesteps must be (B,)")
+        # the kernels index the positional table (5000 rows) and, in the sampler modes, the schedule tables by t
+        t_lo, t_hi = (int(v) for v in torch.aminmax(timesteps))
+        t_max = 5000 if mode == _lib.MODE_FORWARD else getattr(self, "_schedule_len", 0)
+        if t_lo < 0 or t_hi >= t_max:
+            raise ValueError("timesteps must lie in [0, %d), got [%d, %d]" % (t_max, t_lo, t_hi))
         text = self._encode_text(y, B, dev)
         if fps_starts is None:
             # reference draw order and generator: CPU global RNG, sa1..sa4
             fps_starts = [torch.randint(0, n, (B * O,), dtype=torch.long) for n in FPS_RANGES]
+        else:
+            self._check_starts(torch.stack([s.reshape(-1) for s in fps_starts]).long(), B * O)
         starts = torch.stack([s.reshape(-1) for s in fps_starts]).to(device=dev, dtype=torch.long).contiguous()
         noise = noise_fn() if noise_fn is not None else None
         out_cat = torch.empty(B, 1, self.max_cats, device=dev)
@@ -202,6 +232,7 @@ class SceneDiffusionModel(nn.Module):
         same results with the loop-invariant level-1 encoder work evaluated once per call; or
         lsdm_sample_steps_hoisted with one pinned (4,B*9) start tensor).  ``x`` (device, contiguous) holds the result;
         ``starts`` (K,4,B*9) int64 and ``noise`` (K,B,1024,3) are the pre-drawn RNG streams of the K steps."""
+        self._check_device(x)
         B = x.shape[0]
         dev = x.device
         ctx = self._context()

@@ -20,12 +20,25 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_samples(local, dist=None):
-    """All-gathers (B_local, ...) tensors into (B_local * world, ...) in rank order.  ``dist`` is the initialised
-    ``torch.distributed`` module or None for a single process."""
+def gather_samples(local, dist=None, total=None):
+    """All-gathers (B_local, ...) tensors into (sum of B_local, ...) in rank order.  ``dist`` is the initialised
+    ``torch.distributed`` module or None for a single process.  Equal shard sizes (the bench: 64 chains per rank) take one
+    ``all_gather_into_tensor``; with ``total`` = the job's unit count split by ``shard_range`` (sizes differing by one when
+    ``total % world != 0``) every rank pads its shard to the largest size for the same single collective and the padding
+    rows are dropped afterwards."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    sizes = [local.shape[0]] * world if total is None else [shard_range(total, r, world)[1] - shard_range(total, r, world)[0]
+                                                            for r in range(world)]
+    if sizes[dist.get_rank()] != local.shape[0]:
+        raise ValueError("rank %d holds %d units, shard_range(%s) assigns %d" % (dist.get_rank(), local.shape[0], total, sizes[dist.get_rank()]))
+    big = max(sizes)
+    send = local.contiguous()
+    if send.shape[0] < big:
+        send = torch.cat([send, send.new_zeros((big - send.shape[0],) + tuple(send.shape[1:]))])
+    out = torch.empty((world * big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send)
+    if min(sizes) == big:
+        return out
+    return torch.cat([out[r * big:r * big + n] for r, n in enumerate(sizes)])

@@ -17,7 +17,8 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from ..data import ProxTextDataset, synthetic_text_features, write_synthetic_dataset
+from ..data import (HumaniseDataset, ProxTextDataset, synthetic_text_features, write_synthetic_dataset,
+                    write_synthetic_humanise)
 from ..metrics import accuracy, calculate_fscore, chamfer_distance, emd
 
 
@@ -80,7 +81,8 @@ class HipBackend:
         mv = lambda v: v.to(self.device)
         out = fn(self.model, shape, mv(mask), mv(given_objs), mv(given_cats), y=y, clip_denoised=False, model_kwargs=None,
                  skip_timesteps=0, init_image=None, progress=False, dump_steps=None, noise=None, const_noise=False)
-        return out.float().cpu(), self.model.saved_cat.cpu(), self.model.saved_guiding_points.cpu()
+        # the sample stays on the device: chamfer / F-score run there (run/test_sdm.py:185-186: pred = sample.float().to(device))
+        return out.float(), self.model.saved_cat, self.model.saved_guiding_points
 
 
 def list_mean(values):
@@ -94,12 +96,16 @@ def main(argv=None, backend_factory=None):
     data_dir, objs_dir = args.data_dir, args.objs_dir
     text_encoder = None
     if args.synthetic:
-        data_dir, objs_dir = write_synthetic_dataset(args.data_dir, args.synthetic, seed=args.seed)
+        if args.datatype == 'proxd':
+            data_dir, objs_dir = write_synthetic_dataset(args.data_dir, args.synthetic, seed=args.seed)
+        else:   # HUMANISE layout: two prompts per scene (BASELINE configs[4])
+            data_dir, objs_dir = write_synthetic_humanise(args.data_dir, (args.synthetic + 1) // 2, 2, seed=args.seed)
         text_encoder = synthetic_text_features
-    if objs_dir is None:
-        objs_dir = 'data/protext/objs' if args.datatype == 'proxd' else 'data/humanise/objs'
-    max_cats = 13 if args.datatype == 'proxd' else 11
-    dataset = ProxTextDataset(data_dir, objs_data_dir=objs_dir, max_cats=max_cats)
+    # the reference picks the loader by --datatype (run/test_sdm.py:110-117); each has its own category table
+    if args.datatype == 'proxd':
+        dataset = ProxTextDataset(data_dir, objs_data_dir=objs_dir or 'data/protext/objs', max_cats=13)
+    else:
+        dataset = HumaniseDataset(data_dir, objs_data_dir=objs_dir or 'data/humanise/objs', max_cats=11)
     loader = DataLoader(dataset, batch_size=1, shuffle=False, num_workers=0)
     backend = (backend_factory or HipBackend)(args, text_encoder)
     lookup = {}
@@ -113,18 +119,19 @@ def main(argv=None, backend_factory=None):
         for mask, given_objs, given_cats, target_obj, target_cat, y in loader:
             with torch.no_grad():
                 pred, pred_cat, guiding = backend.sample(list(target_obj.shape), mask, given_objs, given_cats, y)
-            chamfer_s = chamfer_distance(pred, target_obj.float())
+            target_obj = target_obj.float().to(pred.device)
+            chamfer_s = float(chamfer_distance(pred, target_obj))
             chamfer_list.append(chamfer_s)
             emd_list.append(emd(pred, target_obj))
             f1_list.append(calculate_fscore(pred.squeeze(0), target_obj.squeeze(0))[0])
-            pred_cat = pred_cat.squeeze(1)
+            pred_cat = pred_cat.squeeze(1).cpu()
             tgt = torch.argmax(target_cat, dim=1)
             total_topk.append(accuracy(pred_cat, tgt, topk=(3,))[0].item())
             total_acc.append((torch.argmax(pred_cat, dim=1) == tgt).sum().item())
             stem = lookup[y[0]]
             f.write("Chamfer distance for seq {}: {:.4f}".format(stem, chamfer_s) + '\n')
-            np.save(os.path.join(args.output_dir, 'predictions', stem + '.npy'), pred[0].numpy())
-            np.save(os.path.join(args.output_dir, 'guiding_points', stem + '.npy'), guiding[0].numpy())
+            np.save(os.path.join(args.output_dir, 'predictions', stem + '.npy'), pred[0].cpu().numpy())
+            np.save(os.path.join(args.output_dir, 'guiding_points', stem + '.npy'), guiding[0].cpu().numpy())
         f.write("Final Chamfer distance: {:.4f}".format(list_mean(chamfer_list)) + '\n')
         f.write("Final EMD: {:.4f}".format(list_mean(emd_list)) + '\n')
         f.write("Final F1 score: {:.4f}".format(list_mean(f1_list)) + '\n')

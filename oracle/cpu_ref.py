@@ -162,10 +162,20 @@ def three_nn(xyz1, xyz2):
     return idx, w
 
 
-def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=None):
-    """PointNetFeaturePropagation.forward (pointnet2_utils.py:273-312), channel-last in/out."""
+def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=None, nn_inject=None):
+    """PointNetFeaturePropagation.forward (pointnet2_utils.py:273-312), channel-last in/out.
+
+    ``nn_inject`` (tests only): use these (B,N,3) neighbour indices instead of the sort's -- the weights follow from the
+    distances at those indices by the same formula.  Used to attribute a deviation to the reference's unspecified order
+    of exactly tied distances (``torch.sort`` is not stable): with the other implementation's equally-near choice injected,
+    everything downstream must agree to rounding."""
     B, N, _ = xyz1.shape
     idx, w = three_nn(xyz1, xyz2)
+    if nn_inject is not None:
+        idx = nn_inject.long()
+        d = torch.gather(square_distance(xyz1, xyz2), 2, idx)
+        recip = 1.0 / (d + 1e-8)
+        w = recip / torch.sum(recip, dim=2, keepdim=True)
     interp = torch.sum(gather_rows(points2, idx) * w[..., None], dim=2)  # (B,N,D2)
     h = interp if points1 is None else torch.cat([points1, interp], dim=-1)
     h = h.permute(0, 2, 1)
@@ -181,18 +191,35 @@ def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=No
     return out
 
 
-def scene_encoder(sd, clouds, starts, taps=None):
-    """get_backbone.forward (pointnet2.py:61-80).  clouds (BO,N,3); starts = 4 int64 tensors (BO,)."""
+def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72):
+    """get_backbone.forward (pointnet2.py:61-80).  clouds (BO,N,3); starts = 4 int64 tensors (BO,).
+
+    Clouds are independent (eval-mode BatchNorm), so more than ``chunk`` of them are evaluated ``chunk`` at a time -- the
+    (BO,1024,1024) distance temporaries of 576 clouds would need tens of GB -- with identical results.
+    ``nn_inject``: optional {"fp4"|"fp3"|"fp2"|"fp1": (BO,N,3) indices}, see feature_propagation."""
+    if clouds.shape[0] > chunk:
+        outs, parts = [], []
+        for lo in range(0, clouds.shape[0], chunk):
+            sl = slice(lo, lo + chunk)
+            tp = {} if taps is not None else None
+            inj = None if nn_inject is None else {k: v[sl] for k, v in nn_inject.items()}
+            outs.append(scene_encoder(sd, clouds[sl], [s[sl] for s in starts], tp, inj, chunk))
+            parts.append(tp)
+        if taps is not None:
+            for k in parts[0]:
+                taps[k] = torch.cat([tp[k] for tp in parts])
+        return torch.cat(outs)
+    inj = nn_inject or {}
     l0_xyz = clouds
     l0_points = clouds  # dimension=3: features are the coordinates themselves (:63-64)
     l1_xyz, l1_points = set_abstraction(sd, "sa1", 0, l0_xyz, l0_points, starts[0], taps)
     l2_xyz, l2_points = set_abstraction(sd, "sa2", 1, l1_xyz, l1_points, starts[1], taps)
     l3_xyz, l3_points = set_abstraction(sd, "sa3", 2, l2_xyz, l2_points, starts[2], taps)
     l4_xyz, l4_points = set_abstraction(sd, "sa4", 3, l3_xyz, l3_points, starts[3], taps)
-    l3_points = feature_propagation(sd, "fp4", 2, l3_xyz, l4_xyz, l3_points, l4_points, taps)
-    l2_points = feature_propagation(sd, "fp3", 2, l2_xyz, l3_xyz, l2_points, l3_points, taps)
-    l1_points = feature_propagation(sd, "fp2", 2, l1_xyz, l2_xyz, l1_points, l2_points, taps)
-    l0_feat = feature_propagation(sd, "fp1", 3, l0_xyz, l1_xyz, None, l1_points, taps)
+    l3_points = feature_propagation(sd, "fp4", 2, l3_xyz, l4_xyz, l3_points, l4_points, taps, inj.get("fp4"))
+    l2_points = feature_propagation(sd, "fp3", 2, l2_xyz, l3_xyz, l2_points, l3_points, taps, inj.get("fp3"))
+    l1_points = feature_propagation(sd, "fp2", 2, l1_xyz, l2_xyz, l1_points, l2_points, taps, inj.get("fp2"))
+    l0_feat = feature_propagation(sd, "fp1", 3, l0_xyz, l1_xyz, None, l1_points, taps, inj.get("fp1"))
     h = l0_feat.permute(0, 2, 1)
     h = _conv_bn_relu(h, sd["pcd_backbone.conv1.weight"], sd["pcd_backbone.conv1.bias"], _bn(sd, "pcd_backbone.bn1"), 1)
     h = F.conv1d(h, sd["pcd_backbone.conv2.weight"], sd["pcd_backbone.conv2.bias"])
@@ -249,8 +276,9 @@ def denoise_mlp(sd, z, emb):
     return h
 
 
-def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_starts=None, taps=None):
+def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_starts=None, taps=None, pcd_override=None):
     """One denoising-network evaluation.  Mutates ``x`` in place (Q5).  Returns (out_cat, out, guiding).
+    ``pcd_override`` (tests only): a precomputed scene-encoder output (B,O,3072) used instead of running the encoder.
 
     x (B,N,3), mask (B,O), timesteps (B,) int64, given_objs (B,O,N,3), given_cats (B,O,C),
     text_features (B,512) = the CLIP ``encode_text`` output (boundary, see module docstring).
@@ -275,7 +303,10 @@ def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_s
     hm = human_backbone(sd, given_objs[:, 0].clone())
     if fps_starts is None:
         fps_starts = draw_fps_starts(B * O)
-    pcd = scene_encoder(sd, given_objs.reshape(B * O, N, 3), fps_starts, taps).reshape(B, O, -1)
+    if pcd_override is not None:
+        pcd = pcd_override.reshape(B, O, -1)
+    else:
+        pcd = scene_encoder(sd, given_objs.reshape(B * O, N, 3), fps_starts, taps).reshape(B, O, -1)
     # 8. object attention weights (sdm.py:180-182): 8 heads x 16, float mask ADDED (Q4), row (b,h) of the
     #    mask is mask[(b*8+h) % B] (Q3); only the head-averaged weights are used (Q6).
     wq, wk = sd["attn_layer.q_proj_weight"], sd["attn_layer.k_proj_weight"]
@@ -385,9 +416,9 @@ class Sampler:
         self.saved_cat = None
         self.saved_guiding_points = None
 
-    def p_mean_variance(self, x, mask, t, given_objs, given_cats, text_features, fps_starts=None, taps=None):
+    def p_mean_variance(self, x, mask, t, given_objs, given_cats, text_features, fps_starts=None, taps=None, pcd_override=None):
         """gaussian_diffusion.py:282-393 (+ respace.py:125-130: the model receives ``t`` unchanged, Q8)."""
-        out_cat, x0, guiding = forward(self.sd, x, mask, t, given_objs, given_cats, text_features, fps_starts, taps)
+        out_cat, x0, guiding = forward(self.sd, x, mask, t, given_objs, given_cats, text_features, fps_starts, taps, pcd_override)
         self.saved_cat, self.saved_guiding_points = out_cat, guiding
         mean = _coef(self.tab["posterior_mean_coef1"], t, x) * x0 + _coef(self.tab["posterior_mean_coef2"], t, x) * x
         return {
@@ -397,9 +428,9 @@ class Sampler:
             "pred_xstart": x0,
         }
 
-    def p_sample(self, x, mask, t, given_objs, given_cats, text_features, fps_starts=None, noise=None):
+    def p_sample(self, x, mask, t, given_objs, given_cats, text_features, fps_starts=None, noise=None, taps=None, pcd_override=None):
         """gaussian_diffusion.py:501-561.  RNG order: 4 FPS randints (inside forward) then randn_like."""
-        out = self.p_mean_variance(x, mask, t, given_objs, given_cats, text_features, fps_starts)
+        out = self.p_mean_variance(x, mask, t, given_objs, given_cats, text_features, fps_starts, taps, pcd_override)
         if noise is None:
             noise = torch.randn_like(x)
         nz = (t != 0).float().view(-1, 1, 1)

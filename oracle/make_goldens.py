@@ -12,6 +12,10 @@ Golden sets:
   G4  short p_sample_loop chains (skip_timesteps = 1000-K) with per-step samples; B in {1,3,16}.
   G6  hoisted conditioning: the reference with its FPS re-draw pinned to the first forward's starts, K = 4 steps.
   G5  DDIM-50: reference p_mean_variance + the arithmetic of gaussian_diffusion.py:790-811.
+  G7  BASELINE configs[4]: humanise defaults (C=11), two prompts sharing one scene, 'ddim250' composed as G5, K = 3 steps.
+  G8  CLI metrics: emd / accuracy of the reference's util/evaluation.py on seeded clouds and logits.
+  G9  p_sample_loop argument variants (gaussian_diffusion.py:611-759): noise=, init_image + skip_timesteps, dump_steps;
+      and what const_noise=True does in the reference (a 4-D repeat inherited from MDM: a (B,B,1024,3) sample).
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
 import argparse
@@ -275,6 +279,90 @@ def g5():
         img = mean_pred + nz * sigma * noise
         samples.append(img.clone())
     save("g5_ddim50", samples=torch.stack(samples), meta=np.array([B, C, K, 61, 52]))
+
+
+def g7():
+    """configs[4] shapes on the real reference: get_default_model_humanise (C = 11), 2 prompts x 1 scene, ddim250 (stride 4,
+    Q8: the model sees the respaced index), composed exactly like G5."""
+    diff = ref_diffusion("ddim250")
+    assert diff.num_timesteps == 250
+    B, C, K = 2, 11, 3
+    kw = mu.get_default_model_humanise()
+    m = SDM(**kw, use_cuda=False).eval()
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
+    one = make_synthetic_batch(1, seed=31, max_cats=C)
+    bt = {k: v.repeat(2, *([1] * (v.dim() - 1))).contiguous() for k, v in one.items()}
+    bt["text_features"] = make_synthetic_batch(2, seed=32, max_cats=C)["text_features"]
+    clip._model.features = bt["text_features"]
+    torch.manual_seed(9)
+    img = torch.randn(B, 1024, 3)
+    samples = []
+    for i in list(range(diff.num_timesteps))[::-1][:K]:
+        t = torch.tensor([i] * B)
+        x = img
+        out = diff.p_mean_variance(m, x, bt["mask"], t, bt["given_objs"], bt["given_cats"], ["p"] * B, clip_denoised=False)
+        eps = diff._predict_eps_from_xstart(x, t, out["pred_xstart"])
+        ab = gd._extract_into_tensor(diff.alphas_cumprod, t, x.shape)
+        abp = gd._extract_into_tensor(diff.alphas_cumprod_prev, t, x.shape)
+        sigma = 0.0 * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        noise = torch.randn_like(x)
+        mean_pred = out["pred_xstart"] * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
+        nz = (t != 0).float().view(-1, 1, 1)
+        img = mean_pred + nz * sigma * noise
+        samples.append(img.clone())
+    save("g7_ddim250_humanise", samples=torch.stack(samples), saved_cat=m.saved_cat, guiding=m.saved_guiding_points,
+         meta=np.array([B, C, K, 9, 31, 32]))
+
+
+def g8():
+    """emd / accuracy of the reference's util/evaluation.py (open3d is an import-only placeholder there; calculate_fscore
+    needs the real package and is pinned against its definition instead, tests/test_metrics.py)."""
+    import util.evaluation as ev
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(3, 1024, 3, generator=g)
+    b = a + 0.3 * torch.randn(3, 1024, 3, generator=g)
+    emds = [float(ev.emd(a[i:i + 1], b[i:i + 1])) for i in range(3)]
+    emds.append(float(ev.emd(a[0, :200], b[1, :333])))              # unequal sizes, 2-D inputs
+    logits = torch.randn(16, 13, generator=g)
+    target = torch.randint(0, 13, (16,), generator=g)
+    acc = [float(v) for v in ev.accuracy(logits, target, topk=(1, 3, 5))]
+    save("g8_metrics", a=a, b=b, emd=np.array(emds), logits=logits, target=target, acc=np.array(acc))
+
+
+def g9():
+    """Argument variants of p_sample_loop on the real reference, B = 2, C = 13, K = 3 steps."""
+    diff = ref_diffusion()
+    B, C, K = 2, 13, 3
+    m = ref_model(C)
+    bt = make_synthetic_batch(B, seed=91, max_cats=C)
+    clip._model.features = bt["text_features"]
+    args = (m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], ["p"] * B)
+    g = torch.Generator().manual_seed(92)
+    noise0 = torch.randn(B, 1024, 3, generator=g)
+    init = 0.5 * torch.randn(B, 1024, 3, generator=g)
+    out = {}
+    torch.manual_seed(93)      # noise= given: no x_T draw; skip_timesteps with init_image None -> q_sample(zeros)
+    out["noise_arg"] = diff.p_sample_loop(*args, noise=noise0.clone(), clip_denoised=False, skip_timesteps=1000 - K)
+    torch.manual_seed(94)      # init_image: x_T drawn, then q_sample(init_image, t = K-1)
+    out["init_image"] = diff.p_sample_loop(*args, clip_denoised=False, skip_timesteps=1000 - K, init_image=init.clone())
+    torch.manual_seed(95)
+    dump = diff.p_sample_loop(*args, clip_denoised=False, skip_timesteps=1000 - K, dump_steps=[0, 2])
+    assert isinstance(dump, list) and len(dump) == 2
+    out["dump0"], out["dump2"] = dump
+    # const_noise=True: `noise[[0]].repeat(B, 1, 1, 1)` on a 3-D sample gives (B,1,1024,3); one step returns a (B,B,1024,3)
+    # tensor whose [i, j] = mean_j + sigma * noise_0 ... recorded as evidence; a second step cannot run on it
+    torch.manual_seed(96)
+    cn = diff.p_sample_loop(*args, clip_denoised=False, skip_timesteps=999, const_noise=True)
+    out["const_noise_shape"] = np.array(cn.shape)
+    out["const_noise_diag"] = torch.stack([cn[j, j] for j in range(B)])     # chain j with noise row 0
+    try:
+        torch.manual_seed(96)
+        diff.p_sample_loop(*args, clip_denoised=False, skip_timesteps=998, const_noise=True)
+        out["const_noise_two_steps_ok"] = np.array(1)
+    except Exception as e:
+        print("const_noise over two steps fails in the reference:", type(e).__name__, str(e)[:100])
+        out["const_noise_two_steps_ok"] = np.array(0)
+    save("g9_loop_variants", noise0=noise0, init=init, meta=np.array([B, C, K, 91, 92]), **out)
 
 
 def long_chain(steps):

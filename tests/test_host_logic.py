@@ -123,7 +123,8 @@ class OracleBackend:
 
     def __init__(self, args, text_encoder):
         from oracle import cpu_ref
-        self.smp = cpu_ref.Sampler(make_synthetic_state_dict(seed=0), timestep_respacing=args.timestep_respacing or None)
+        C = 13 if args.datatype == "proxd" else 11
+        self.smp = cpu_ref.Sampler(make_synthetic_state_dict(seed=0, max_cats=C), timestep_respacing=args.timestep_respacing or None)
         self.text_encoder, self.use_ddim = text_encoder, args.use_ddim
 
     def sample(self, shape, mask, given_objs, given_cats, y):
@@ -156,6 +157,26 @@ def test_cli_plumbing_synthetic_proxd_test(tmp_path):
     mask, verts, cats, tgt, tcat, prompt = ds[0]
     assert mask[0] == 0 and mask.sum() >= 1 and verts.shape == (9, 1024, 3) and cats.shape == (9, 13) and cats[0, 0] == 1
     assert tgt.shape == (1024, 3) and tcat.sum() == 1 and prompt.startswith("synthetic prompt")
+
+
+def test_integration_md_shows_the_executed_binding_verbatim():
+    """INTEGRATION.md path B is integration/sdm_hip.py, the file tests/test_hip_configs.py executes on the GPU."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = open(os.path.join(ROOT, "integration", "sdm_hip.py")).read()
+    assert "```python\n" + code + "```" in doc
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """`--gpus N` is honoured or refused, never ignored: with a launcher's WORLD_SIZE that disagrees the run stops before
+    touching a device (without one, bench.py re-executes itself under torch.distributed.run with N ranks)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+    import bench
+    src = open(bench.__file__).read()
+    assert "respawn_ranks(a.gpus)" in src and "torch.distributed.run" in src
 
 
 def test_metrics_known_answers():

@@ -1,0 +1,118 @@
+"""CPU tests of the rows next to the hot path: the CLI's metrics against values recorded from the
+reference's util/evaluation.py (G8) and against their definitions, the HUMANISE loader on a synthetic tree, and the CLIP
+text hook with a stub ``clip`` module (``encode_text`` itself is third party: parity unpinned)."""
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from lsdm_amd import metrics
+from lsdm_amd.data import HUMANISE_CATEGORY_IDS, HumaniseDataset, ProxTextDataset, write_synthetic_dataset, write_synthetic_humanise
+
+torch.set_grad_enabled(False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_emd_and_accuracy_vs_reference_golden(golden):
+    g = golden("g8_metrics")
+    a, b = T(g["a"]), T(g["b"])
+    got = [metrics.emd(a[i:i + 1], b[i:i + 1]) for i in range(3)] + [metrics.emd(a[0, :200], b[1, :333])]
+    np.testing.assert_allclose(got, g["emd"], rtol=0, atol=1e-12)
+    acc = [float(v) for v in metrics.accuracy(T(g["logits"]), T(g["target"]).long(), topk=(1, 3, 5))]
+    assert acc == [float(v) for v in g["acc"]]
+
+
+def test_chamfer_and_fscore_vs_brute_force_definitions(golden):
+    """pytorch3d.loss.chamfer_distance defaults (mean of squared NN distances per direction, summed) and
+    util/evaluation.py:28-52 (open3d compute_point_cloud_distance = Euclidean NN distance; th = 0.1) on 1024-point clouds,
+    evaluated with explicit loops over one direction at a time in float64."""
+    g = golden("g8_metrics")
+    a, b = T(g["a"])[:1], T(g["b"])[:1]
+    A, B = a[0].double().numpy(), b[0].double().numpy()
+    d_ab = np.array([((B - p) ** 2).sum(1).min() for p in A])
+    d_ba = np.array([((A - p) ** 2).sum(1).min() for p in B])
+    assert abs(float(metrics.chamfer_distance(a, b)) - (d_ab.mean() + d_ba.mean())) <= 1e-6
+    f, p, r = metrics.calculate_fscore(a[0], b[0], th=0.1)         # gt = a, pr = b
+    recall, precision = (np.sqrt(d_ba) < 0.1).mean(), (np.sqrt(d_ab) < 0.1).mean()
+    assert (p, r) == (precision, recall) and abs(f - 2 * recall * precision / (recall + precision)) <= 1e-12
+    assert metrics.calculate_fscore(a[0][:0], b[0]) == (0, 0, 0)
+    assert metrics.calculate_fscore(a[0], a[0] + 10.0)[0] == 0
+
+
+def test_humanise_loader_round_trip(tmp_path):
+    """posa.dataset.HUMANISE (posa/dataset.py:477-602) on a synthetic tree: C = 11 with its own category table, scene =
+    seq[:9] + '_00', two prompts per scene sharing the scene's objects, files of unknown categories skipped, human slot
+    mask 0, third context line unstripped."""
+    data_dir, objs_dir = write_synthetic_humanise(str(tmp_path), num_scenes=2, prompts_per_scene=2, seed=3)
+    ds = HumaniseDataset(data_dir, objs_data_dir=objs_dir)
+    assert len(ds) == 4 and ds.handle == 1 and ds.max_cats == 11
+    assert all("window_99" not in objs for objs in ds.objs.values())
+    items = [ds[i] for i in range(4)]
+    for mask, verts, cats, tgt, tcat, prompt in items:
+        assert mask.shape == (9,) and mask[0] == 0 and mask.sum() >= 1
+        assert verts.shape == (9, 1024, 3) and cats.shape == (9, 11) and cats[0, 0] == 1
+        k = int(mask.sum())
+        assert torch.equal(cats[1:k + 1].sum(dim=1), torch.ones(k)) and float(cats[k + 1:].sum()) == 0 and float(verts[k + 1:].abs().sum()) == 0
+        assert tgt.shape == (1024, 3) and tcat.shape == (11,) and tcat.sum() == 1 and prompt.startswith("synthetic humanise prompt")
+    # the two prompts of a scene see the same objects and differ in prompt / target
+    assert torch.equal(items[0][1][1:], items[1][1][1:]) and items[0][5] != items[1][5] and not torch.equal(items[0][3], items[1][3])
+    # stored vertices come back bit-exact
+    name = sorted(ds.objs["scene0000_00"])[0]
+    np.testing.assert_array_equal(ds.objs["scene0000_00"][name], np.load("%s/scene0000_00/%s.npy" % (objs_dir, name)))
+    assert ds.cats["scene0000_00"][name] == HUMANISE_CATEGORY_IDS[name.split("_")[0]]
+    # a proxd category id would overflow C = 11: the two loaders are not interchangeable
+    pdir, pobjs = write_synthetic_dataset(str(tmp_path / "p"), 2, seed=1)
+    assert ProxTextDataset(pdir, objs_data_dir=pobjs)[0][2].shape == (9, 13)
+
+
+def test_default_clip_encoder_with_stub_clip_module(monkeypatch):
+    """model/sdm.py:245-259: tokenize with context 22 (truncate), zero-pad the tokens to 77, encode_text(...).float().
+    The stub records what the hook hands to the third-party package."""
+    seen = {}
+    clip = types.ModuleType("clip")
+
+    class FakeClip:
+        def eval(self):
+            seen["eval"] = True
+            return self
+
+        def encode_text(self, tok):
+            seen["tokens"] = tok.clone()
+            return torch.arange(tok.shape[0] * 512, dtype=torch.float16).view(tok.shape[0], 512)
+
+    def load(name, device=None, jit=None):
+        seen["load"] = (name, str(device), jit)
+        return FakeClip(), None
+
+    def tokenize(texts, context_length=77, truncate=False):
+        seen["tokenize"] = (list(texts), context_length, truncate)
+        return torch.full((len(texts), context_length), 7, dtype=torch.int32)
+
+    clip.load, clip.tokenize = load, tokenize
+    monkeypatch.setitem(sys.modules, "clip", clip)
+    from lsdm_amd.model.sdm import SceneDiffusionModel, _default_clip_encoder
+    enc = _default_clip_encoder("ViT-B/32", "cpu")
+    out = enc(["a chair", "a table"])
+    assert seen["load"] == ("ViT-B/32", "cpu", False) and seen["eval"]
+    assert seen["tokenize"] == (["a chair", "a table"], 22, True)
+    tok = seen["tokens"]
+    assert tok.shape == (2, 77) and bool((tok[:, :22] == 7).all()) and bool((tok[:, 22:] == 0).all())
+    assert out.dtype == torch.float32 and out.shape == (2, 512)
+    # the model routes list[str] prompts through it and checks the (B,512) boundary
+    m = SceneDiffusionModel(clip_dim=512, pcd_dim=3, use_cuda=False)
+    feats = m._encode_text(["x", "y"], 2, torch.device("cpu"))
+    assert feats.shape == (2, 512) and feats.dtype == torch.float32
+    with pytest.raises(ValueError):
+        m._encode_text(["x"], 2, torch.device("cpu"))
+
+
+def test_missing_clip_package_is_reported(monkeypatch):
+    monkeypatch.setitem(sys.modules, "clip", None)
+    from lsdm_amd.model.sdm import _default_clip_encoder
+    with pytest.raises(RuntimeError, match="clip"):
+        _default_clip_encoder("ViT-B/32", "cpu")

@@ -172,3 +172,45 @@ def test_g5_ddim50(golden):
         out = smp.ddim_sample(img, bt["mask"], torch.tensor([i] * B), bt["given_objs"], bt["given_cats"], bt["text_features"])
         img = out["sample"]
         assert maxabs(img, g["samples"][k]) <= 1e-4, k
+
+
+# ---------------------------------------------------------------- G7: configs[4] shapes
+def test_g7_humanise_two_prompts_ddim250(golden):
+    g = golden("g7_ddim250_humanise")
+    B, C, K, seed, bt_seed, txt_seed = [int(v) for v in g["meta"]]
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    one = make_synthetic_batch(1, seed=bt_seed, max_cats=C)
+    bt = {k: v.repeat(2, *([1] * (v.dim() - 1))).contiguous() for k, v in one.items()}
+    bt["text_features"] = make_synthetic_batch(2, seed=txt_seed, max_cats=C)["text_features"]
+    smp = cpu_ref.Sampler(sd, timestep_respacing="ddim250")
+    got = []
+    torch.manual_seed(seed)
+    smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=250 - K,
+                    use_ddim=True, on_step=lambda i, o: got.append(o["sample"].clone()))
+    # (the golden chain starts from x_T itself: skip_timesteps without an init image would q_sample zeros first)
+    torch.manual_seed(seed)
+    img = torch.randn(B, 1024, 3)
+    for k, i in enumerate(list(range(250))[::-1][:K]):
+        out = smp.ddim_sample(img, bt["mask"], torch.tensor([i] * B), bt["given_objs"], bt["given_cats"], bt["text_features"])
+        img = out["sample"]
+        assert maxabs(img, g["samples"][k]) <= 5e-5, k
+    assert maxabs(smp.saved_cat, g["saved_cat"]) <= 1e-6 and maxabs(smp.saved_guiding_points, g["guiding"]) <= 5e-5
+    assert len(got) == K
+
+
+# ---------------------------------------------------------------- G9: p_sample_loop argument variants
+def test_g9_loop_variants(golden):
+    g = golden("g9_loop_variants")
+    B, C, K, bt_seed, _ = [int(v) for v in g["meta"]]
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
+    smp = cpu_ref.Sampler(sd)
+    args = ([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"])
+    torch.manual_seed(93)
+    assert maxabs(smp.sample_loop(*args, noise=T(g["noise0"]).clone(), skip_timesteps=1000 - K), g["noise_arg"]) <= 5e-5
+    torch.manual_seed(94)
+    assert maxabs(smp.sample_loop(*args, init_image=T(g["init"]).clone(), skip_timesteps=1000 - K), g["init_image"]) <= 5e-5
+    dump = {}
+    torch.manual_seed(95)
+    smp.sample_loop(*args, skip_timesteps=1000 - K, on_step=lambda i, o: dump.__setitem__(i, o["sample"].clone()))
+    assert maxabs(dump[K - 1], g["dump0"]) <= 5e-5 and maxabs(dump[0], g["dump2"]) <= 5e-5      # on_step is keyed by t

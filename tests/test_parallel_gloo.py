@@ -65,6 +65,43 @@ def test_sharded_chains_allgather_world2():
         assert float((torch.from_numpy(got[r]) - ref[0]).abs().max()) <= 1e-5
 
 
+def _ragged_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 5
+    lo, hi = shard_range(total, rank, world)
+    units = torch.arange(total * 6, dtype=torch.float32).view(total, 2, 3)
+    got = gather_samples(units[lo:hi], dist, total=total)
+    try:        # a shard that disagrees with shard_range is refused on every rank BEFORE the collective (no hang)
+        gather_samples(units[:1 + 3 * rank], dist, total=total)
+        bad = False
+    except ValueError:
+        bad = True
+    dist.barrier()
+    if rank == 0:
+        q.put((got.numpy(), bad))
+    else:
+        assert bad
+    dist.destroy_process_group()
+
+
+def test_ragged_shards_allgather_world2():
+    """total % world != 0: shard sizes differ by one; one padded all-gather, padding rows dropped, rank order kept."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, bad = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert bad
+    np.testing.assert_array_equal(got, np.arange(30, dtype=np.float32).reshape(5, 2, 3))
+
+
 def test_shard_helpers():
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert [shard_range(512, r, 8) for r in range(8)][-1] == (448, 512)
