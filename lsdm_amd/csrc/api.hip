@@ -51,15 +51,15 @@ struct lsdm_ctx {
     // First SA layer split across the grouping (encoder_u.hip, bf16x3): per level i (0: sa3, 1: sa4) the feature columns of
     // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
     // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
-    DenseH sa_uw[2], sa_ub[2];
+    DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
     // first FP layer split at the concat boundary (encoder_u.hip): columns of points1 (+ bias) / of the interpolated points2;
     // index 0: fp3, 1: fp2
     DenseH fp_a[2], fp_y[2];
     float* fp_ybuf[2] = {};
     int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
-    const float* sa_wx[2] = {};
-    float *sa_U[2] = {}, *sa_V[2] = {};
-    int sa_split = getenv("LSDM_SA_SPLIT") ? atoi(getenv("LSDM_SA_SPLIT")) : 2;   // A/B switch: number of levels (from sa3) using it
+    const float* sa_wx[3] = {};
+    float *sa_U[3] = {}, *sa_V[3] = {};
+    int sa_split = getenv("LSDM_SA_SPLIT") ? atoi(getenv("LSDM_SA_SPLIT")) : 3;   // A/B switch: 1 sa3, 2 + sa4, 3 + sa2
     void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
     void* fpo_b[3] = {};
     CondParams cond{};
@@ -115,14 +115,16 @@ struct lsdm_ctx {
         f.e0 += o * B * 256;
         f.tr += o * nc * 12;
         f.w += o * nc;
-        // upsample12_kernel packs one chain as 256 x 512 fp32 (f32), bf16 hi + lo (bf16x3: the same bytes) or bf16 hi only
-        f.h2p += o * B * (prec == LSDM_PREC_BF16 ? 256 * 256 : 256 * 512);
+        // upsample12_kernel packs one row as 256 x 512 fp32 (f32) or -- the timestep half only -- 128 x 512 bf16 hi + lo (bf16x3) /
+        // bf16 hi (bf16); offsets in floats
+        f.h2p += o * B * (prec == LSDM_PREC_F32 ? 256 * 512 : (prec == LSDM_PREC_BF16X3 ? 128 * 512 : 64 * 512));
         f.tbuf += o * B;
         return f;
     }
     float* feat[4] = {};
     float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
     float *hm = nullptr, *o12 = nullptr, *xs = nullptr, *posa_ws = nullptr;
+    float *h2x = nullptr, *ctext = nullptr;   // bf16 modes: text half of the up-sampling (per call), see denoise_bf.hip
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -427,6 +429,11 @@ void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* 
 }
 
 // dense stages of get_backbone.forward (4 x SA, 4 x FP + head) on the geometry of a front set
+// skip_sa1 (loop-invariant schedule): level 1 comes from the call's invariants.  In bf16x3 with the split sa2 / fp2 layers the
+// invariants stay in SOURCE order (inv_F1, sa_U[2] / sa_V[2]) and are read through the step's FPS order f.idx[0]; otherwise
+// l1_remap_kernel has re-ordered the feature rows into feat[0].
+bool inv_in_source_order(const lsdm_ctx* c) { return c->prec == LSDM_PREC_BF16X3 && c->sa_split >= 3 && c->sa_reg > 1 && c->fp_pre >= 1; }
+
 void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int nc, float* out, hipStream_t st, bool skip_sa1 = false) {
     const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
     if (c->prec == LSDM_PREC_F32) {
@@ -456,10 +463,15 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     for (int l = skip_sa1 ? 1 : 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
-        if (np == 2 && l == 2 && c->sa_split >= 1) {
+        if (np == 2 && l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
+            // sa2: U, V per level-1 point -- per step in FPS order, or (loop-invariant schedule) once per call in source order
+            const bool src = skip_sa1 && inv_in_source_order(c);
+            if (!src) launch_lin_u(1, nc * 1024, c->feat[0], lvl_xyz[1], c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
+            launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
+        } else if (np == 2 && l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
             launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
-            launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+            launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
             launch_sa_h_pre(nc, c->sa_U[1], c->sa_V[1], f.idx[3], lvl_xyz[4], f.ball[3], c->sa_h[3], c->feat[3], st);
@@ -473,12 +485,15 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
     prof_mark(c, K_FP3, st);
     if (np == 2 && c->fp_pre >= 2)
-        launch_fp_pre(3, nc, c->feat[1], c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, st);
+        launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, st);
     else
         launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
     prof_mark(c, K_FP2, st);
-    if (np == 2 && c->fp_pre >= 1)
-        launch_fp_pre(2, nc, c->feat[0], c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, st);
+    if (np == 2 && c->fp_pre >= 1 && skip_sa1 && inv_in_source_order(c))
+        launch_fp_pre(2, nc, static_cast<const float*>(c->inv_F1), f.idx[0], c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1],
+                      c->fp_h[2][1], c->fpo2, st);
+    else if (np == 2 && c->fp_pre >= 1)
+        launch_fp_pre(2, nc, c->feat[0], nullptr, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, st);
     else
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_mark(c, K_FP1, st);
@@ -499,8 +514,14 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
     prof_mark(c, K_COND, st);
     launch_cond(c->cond, t, text, given_cats, mask, B, g, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
     prof_mark(c, K_UP12, st);
-    launch_upsample12(c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1), f.e0, c->up0, c->up2.w, c->up2.b, B * g, f.h2p, st);
+    const int np = c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1);
+    launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B * g, 0, f.h2p, st);
     if (!reuse_hm) {
+        // once per call: what depends on (given_objs, text) only
+        if (np != 0) {
+            launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B, 128, c->h2x, st);
+            launch_ctext(np, c->den_h, B, c->h2x, c->ctext, st);
+        }
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->posa_ws, c->hm, st);
     }
@@ -522,15 +543,17 @@ void run_scene_conditioning(lsdm_ctx* c, const FrontSet& f, int B, const float* 
 }
 
 // the fused per-point denoiser + sampler update (the only stage that reads x)
+// nsteps > 1 (bf16 modes, hoisted conditioning): that many consecutive steps of the front sets f, f+1, ... in ONE launch; the
+// final sample lands in x
 void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
-                 const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
+                 const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st, int nsteps = 1) {
     prof_mark(c, K_DENOISE, st);
     if (c->prec == LSDM_PREC_F32)
         launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm, f.h2p, noise, out_x0, out_guiding,
                        out_sample, st);
     else
-        launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm,
-                         f.h2p, noise, out_x0, out_guiding, out_sample, st);
+        launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, nsteps, x, t, mask, c->pcd, f.w, c->o12, c->hm,
+                         f.h2p, c->ctext, noise, out_x0, out_guiding, out_sample, st);
     prof_mark(c, -1, st);
 }
 
@@ -543,7 +566,7 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
         prof_mark(c, K_REMAP, st);
         const int np = c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1);
         launch_l1_remap(B * kO, c->inv_F1, np == 1 ? 128 : 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], given_objs,
-                        np == 1 ? c->feat_b[0] : (void*)c->feat[0], f.nn_idx[3], f.nn_w[3], st);
+                        inv_in_source_order(c) ? nullptr : (np == 1 ? c->feat_b[0] : (void*)c->feat[0]), f.nn_idx[3], f.nn_w[3], st);
     }
     run_scene_conditioning(c, f, B, given_objs, st, inv);
     run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st);
@@ -725,6 +748,28 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                 std::vector<int> ident(128);
                 for (int k = 0; k < 128; ++k) ident[k] = k;
                 ok = c->sa_uw[0].w && c->sa_uw[0].b && c->sa_wx[0] && build_chain_blob(c, layers, ident, np, &c->sa_ub[0]);
+            }
+            // sa2: first layer (64 x 67) split the same way; layers 2-3 as a resident fragment blob (sa_ur_kernel)
+            if (ok) {
+                const std::string p2 = "pcd_backbone.sa2";
+                std::vector<float> W2, B2;
+                ok = fold_dense(c, p2 + ".mlp_convs.0.weight", p2 + ".mlp_convs.0.bias", p2 + ".mlp_bns.0", 64, 67, W2, B2);
+                if (ok) {
+                    std::vector<float> wf((size_t)64 * 64), wx((size_t)64 * 3);
+                    for (int n = 0; n < 64; ++n) {
+                        for (int k = 0; k < 3; ++k) wx[(size_t)n * 3 + k] = W2[(size_t)n * 67 + k];
+                        for (int k = 0; k < 64; ++k) wf[(size_t)n * 64 + k] = W2[(size_t)n * 67 + 3 + k];
+                    }
+                    std::vector<uint16_t> pk = pack_weight_h(wf, 64, 64, np, {});
+                    c->sa_uw[2].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pk.data()), pk.size() / 2));
+                    c->sa_uw[2].b = upload(c, B2.data(), B2.size());
+                    c->sa_wx[2] = upload(c, wx.data(), wx.size());
+                    std::vector<ChainLayer> layers = {{p2 + ".mlp_convs.1.weight", p2 + ".mlp_convs.1.bias", p2 + ".mlp_bns.1", 64, 64},
+                                                      {p2 + ".mlp_convs.2.weight", p2 + ".mlp_convs.2.bias", p2 + ".mlp_bns.2", 128, 64}};
+                    std::vector<int> ident(64);
+                    for (int k = 0; k < 64; ++k) ident[k] = k;
+                    ok = c->sa_uw[2].w && c->sa_uw[2].b && c->sa_wx[2] && build_chain_blob(c, layers, ident, np, &c->sa_ub[2]);
+                }
             }
             // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
             {
@@ -953,8 +998,10 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->inv_F1 = ws_alloc<float>(c, "inv_f1", nc * kN * 64)) && (c->inv_nn8_d = ws_alloc<float>(c, "inv_nn8_d", nc * kN * 8)) &&
          (c->inv_nn8_i = ws_alloc<int>(c, "inv_nn8_i", nc * kN * 8)) && (c->sa_U[0] = ws_alloc<float>(c, "sa3_u", nc * 256 * 128)) &&
          (c->sa_V[0] = ws_alloc<float>(c, "sa3_v", nc * 256 * 128)) && (c->sa_U[1] = ws_alloc<float>(c, "sa4_u", nc * 64 * 256)) &&
-         (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256)) && (c->fp_ybuf[1] = ws_alloc<float>(c, "fp2_y", nc * 256 * 256)) &&
-         (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256));
+         (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256)) && (c->sa_U[2] = ws_alloc<float>(c, "sa2_u", nc * 1024 * 64)) &&
+         (c->sa_V[2] = ws_alloc<float>(c, "sa2_v", nc * 1024 * 64)) && (c->fp_ybuf[1] = ws_alloc<float>(c, "fp2_y", nc * 256 * 256)) &&
+         (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256)) &&
+         (c->h2x = ws_alloc<float>(c, "h2x", (size_t)B * 128 * 512)) && (c->ctext = ws_alloc<float>(c, "ctext", (size_t)B * kN * 128));
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)
@@ -1019,6 +1066,8 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, st);
             else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, st);
         }
+        if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
+            launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
         prof_mark(c, K_NN1, st);
         launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, st);
         prof_mark(c, -1, st);
@@ -1080,6 +1129,13 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
         if (k0 == 0) {
             run_geometry(c, c->fs0, given_objs, starts, B * kO, 1, st);
             run_scene_conditioning(c, c->fs0, B, given_objs, st);
+        }
+        if (c->prec != LSDM_PREC_F32) {
+            // the whole group in one launch: a tile's x stays on chip between its steps (denoise_bf.hip)
+            run_denoise(c, c->fs0, mode, eta, B, cur, c->fs0.tbuf, mask, noise + (size_t)k0 * xn, out_x0, out_guiding, nullptr, st, g);
+            rc = check_launch(c, "hoisted sample steps");
+            if (rc) return rc;
+            continue;
         }
         // per step: the fused denoiser + sampler update (the only stage that reads x)
         for (int j = 0; j < g; ++j) {

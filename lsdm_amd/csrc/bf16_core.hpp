@@ -50,13 +50,46 @@ __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 __device__ __forceinline__ float bf_hi_as_float(__bf16 h) { return (float)h; }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// hi / lo split of a PAIR of fp32 values: hi = bf16(v) (one v_cvt_pk_bf16_f32 for both), lo = bf16(v - hi) with v - hi formed by
+// v_dot2c_f32_bf16 straight from the packed hi pair (hi x (-1, 0) + v: exact, the difference is representable) -- no unpacking
+// of hi back to fp32: 3 VALU instructions per pair of values less than the convert / shift / subtract form.
+template <int NP>
+__device__ __forceinline__ void split2(float v0, float v1, bf16x2& hi, bf16x2& lo) {
+    hi[0] = (__bf16)v0; hi[1] = (__bf16)v1;
+    if constexpr (NP == 2) {
+        // the multipliers (-1, 0) / (0, -1) must sit in REGISTERS: written as literals hipcc (ROCm 7.2) folds them into the
+        // inline constant -1.0, which the instruction does not read as a bf16 pair (tools/ubench/split_test.hip: half of
+        // all lo words wrong); the empty asm makes the values opaque
+        unsigned u0 = 0x0000bf80u, u1 = 0xbf800000u;
+        asm("" : "+s"(u0), "+s"(u1));
+        const bf16x2 m0 = __builtin_bit_cast(bf16x2, u0), m1 = __builtin_bit_cast(bf16x2, u1);
+        const float l0 = __builtin_amdgcn_fdot2_f32_bf16(hi, m0, v0, false);
+        const float l1 = __builtin_amdgcn_fdot2_f32_bf16(hi, m1, v1, false);
+        lo[0] = (__bf16)l0; lo[1] = (__bf16)l1;
+    }
+}
+
 // split 4 fp32 values into bf16 hi (and lo) quads
 template <int NP>
 __device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, bf16x4& hi, bf16x4& lo) {
-    hi[0] = (__bf16)v0; hi[1] = (__bf16)v1; hi[2] = (__bf16)v2; hi[3] = (__bf16)v3;
-    if constexpr (NP == 2) {
-        lo[0] = (__bf16)(v0 - (float)hi[0]); lo[1] = (__bf16)(v1 - (float)hi[1]);
-        lo[2] = (__bf16)(v2 - (float)hi[2]); lo[3] = (__bf16)(v3 - (float)hi[3]);
+    bf16x2 h0, l0, h1, l1;
+    split2<NP>(v0, v1, h0, l0);
+    split2<NP>(v2, v3, h1, l1);
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    if constexpr (NP == 2) { lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1]; }
+}
+
+// split 8 fp32 values into the two bf16x8 operand fragments of a k-step
+template <int NP>
+__device__ __forceinline__ void split8_h(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        bf16x2 h, l;
+        split2<NP>(v[j], v[j + 1], h, l);
+        hi[j] = h[0]; hi[j + 1] = h[1];
+        if constexpr (NP == 2) { lo[j] = l[0]; lo[j + 1] = l[1]; }
     }
 }
 
@@ -99,8 +132,8 @@ __device__ __forceinline__ void wfrag_load(WFrag<NP, kgroup(NKB)>& w, const __bf
     const __bf16* wp = Wp + ((size_t)(cb * 32 + (lane & 31)) * NP) * 16 + 8 * (lane >> 5) + (size_t)kb0 * ws;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        w.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws);
-        if constexpr (NP == 2) w.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)u * ws + 16);
+        w.h[u] = gload<bf16x8>(wp + (size_t)u * ws);
+        if constexpr (NP == 2) w.l[u] = gload<bf16x8>(wp + (size_t)u * ws + 16);
     }
 }
 
@@ -124,8 +157,8 @@ __device__ __forceinline__ void mma_kloop_pre_h(f32x16 (&acc)[RB], const __bf16*
     if constexpr (NG > 1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            w2.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(U + u) * ws);
-            if constexpr (NP == 2) w2.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(U + u) * ws + 16);
+            w2.h[u] = gload<bf16x8>(wp + (size_t)(U + u) * ws);
+            if constexpr (NP == 2) w2.l[u] = gload<bf16x8>(wp + (size_t)(U + u) * ws + 16);
         }
     }
     [[maybe_unused]] WFrag<NP, kgroup(TAIL > 0 ? TAIL : 1)> wt;
@@ -139,8 +172,8 @@ __device__ __forceinline__ void mma_kloop_pre_h(f32x16 (&acc)[RB], const __bf16*
         if (g + 2 < NG) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                src.h[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 2) * U + u) * ws);
-                if constexpr (NP == 2) src.l[u] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((g + 2) * U + u) * ws + 16);
+                src.h[u] = gload<bf16x8>(wp + (size_t)((g + 2) * U + u) * ws);
+                if constexpr (NP == 2) src.l[u] = gload<bf16x8>(wp + (size_t)((g + 2) * U + u) * ws + 16);
             }
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this group's MFMAs
@@ -205,7 +238,35 @@ struct SplitH {
 // their latency hides behind the MFMAs)
 __device__ __forceinline__ void load_bias_h(f32x4 (&bv)[4], const float* __restrict__ bias, int cb, int lane) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bias + cb * 32 + 8 * q + 4 * (lane >> 5));
+    for (int q = 0; q < 4; ++q) bv[q] = gload<f32x4>(bias + cb * 32 + 8 * q + 4 * (lane >> 5));
+}
+
+// accumulators of a transposed block start from the bias (row = channel 8q + 4h + j of accumulator 4q + j): the epilogue
+// then needs no add
+template <int RB>
+__device__ __forceinline__ void acc_bias_h(f32x16 (&acc)[RB], const f32x4 (&bv)[4]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[rb][4 * q + j] = bv[q][j];
+}
+
+// epilogue of a transposed (WA) layer whose accumulators started from the bias: activation + split -> LDS [point][channel]
+template <int ACT, int RB, int NP>
+__device__ __forceinline__ void store_lds_b_h(const f32x16 (&acc)[RB], int rb0, int cb, __bf16* out, int ldo, int plane, int lane) {
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = cb * 32 + 8 * q + 4 * h;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            store_split4<NP>(out + ((rb0 + rb) * 32 + p) * ldo + n, plane, apply_act_fast<ACT>(acc[rb][4 * q + 0]),
+                             apply_act_fast<ACT>(acc[rb][4 * q + 1]), apply_act_fast<ACT>(acc[rb][4 * q + 2]),
+                             apply_act_fast<ACT>(acc[rb][4 * q + 3]));
+        }
+    }
 }
 
 // epilogue of a transposed (WA) layer: bias + activation + split -> LDS [point][channel]
@@ -237,11 +298,11 @@ __device__ __forceinline__ void layer_lds_h(const __bf16* X, int ldx, int xplane
 #pragma unroll 1
     for (int cb = cb0; cb < TS::CB; cb += TS::CSTEP) {
         f32x16 acc[TS::RB];
-        acc_zero_h(acc);
         f32x4 bv[4];
         load_bias_h(bv, L.b, cb, lane);
+        acc_bias_h(acc, bv);
         mma_kloop_h<TS::RB, NP, true, K / 16>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb, 0, lane);
-        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, bv, out, ldo, oplane, lane);
+        store_lds_b_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, out, ldo, oplane, lane);
     }
 }
 
@@ -258,19 +319,19 @@ __device__ __forceinline__ void layer_lds_pre_h(const __bf16* X, int ldx, int xp
     const int cb0 = wave % TS::CSTEP, rg = wave / TS::CSTEP;
     {
         f32x16 acc[TS::RB];
-        acc_zero_h(acc);
+        acc_bias_h(acc, bv0);
         mma_kloop_pre_h<TS::RB, NP, true, K / 16>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb0, 0, lane, w0);
         hook();
-        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb0, bv0, out, ldo, oplane, lane);
+        store_lds_b_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb0, out, ldo, oplane, lane);
     }
 #pragma unroll 1
     for (int cb = cb0 + TS::CSTEP; cb < TS::CB; cb += TS::CSTEP) {
         f32x16 acc[TS::RB];
-        acc_zero_h(acc);
         f32x4 bv[4];
         load_bias_h(bv, L.b, cb, lane);
+        acc_bias_h(acc, bv);
         mma_kloop_h<TS::RB, NP, true, K / 16>(acc, X + rg * TS::RB * 32 * ldx, ldx, xplane, L.w, N, cb, 0, lane);
-        store_lds_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, bv, out, ldo, oplane, lane);
+        store_lds_b_h<ACT, TS::RB, NP>(acc, rg * TS::RB, cb, out, ldo, oplane, lane);
     }
 }
 

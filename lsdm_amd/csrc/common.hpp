@@ -17,7 +17,13 @@ constexpr int kNSample = 32;       // ball-query group size (pointnet2.py:46-49)
 __device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 __device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
-__device__ __forceinline__ float reluf(float v) { return v > 0.0f ? v : 0.0f; }
+// ReLU as ONE VALU instruction: a signed-integer max on the bit pattern (negative floats and -0 are negative integers).  The C
+// forms `v > 0 ? v : 0` / fmaxf cost two (compare + select, or a canonicalising max before the max); an inline-asm v_max_f32
+// is invisible to the compiler's MFMA -> VALU hazard handling and read stale accumulators (measured: nondeterministic results).
+__device__ __forceinline__ float reluf(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 
 // Activations of the split-bf16 dense stacks (bf16x3 / bf16 modes): the same functions evaluated with the hardware
 // exp2 / reciprocal (1 ulp each) instead of libm's erff / expf / IEEE division -- the denoiser applies ~640 GELU / sigmoid
@@ -36,6 +42,21 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return v * (v < 0.0f ? q : 1.0f - q);
 }
 __device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// Explicit GLOBAL load of a V from p.  A pointer that went through an opaque `asm("" : "+s"(p))` (used to keep loop-invariant
+// loads inside a loop) has lost its address space: plain loads through it become FLAT loads, which count on vmcnt AND
+// lgkmcnt and make the compiler wait with vmcnt(0) -- every younger prefetch is waited for as well.  (Neither a cast chain
+// through address space 1 nor an assume(!is_shared && !is_private) brings the inference back with ROCm 7.2.)
+template <class V, class T>
+__device__ __forceinline__ V gload(const T* p) {
+    return *(const __attribute__((address_space(1))) V*)(p);
+}
+// opaque copy of a pointer: same value, unknown to loop-invariant code motion
+template <class T>
+__device__ __forceinline__ const T* opaque_ptr(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
 
 // C/D map of the 32x32 MFMA shapes (dtype-independent on gfx950): col = lane & 31, row = acc_row(r, lane)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

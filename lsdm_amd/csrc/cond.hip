@@ -307,13 +307,15 @@ __global__ __launch_bounds__(256) void posa_stage_kernel(PosaParams P, const flo
 // output packed as the per-sample "weight" operand of the third layer inside the denoise kernel:
 //   NP = 0 : fp32  h2p[b][kb = k/8][c][k%8]                  (denoise_kernel, mlp_core.hpp)
 //   NP = 1,2: bf16 h2p[b][kb = k/16][c][plane][k%16]         (denoise_h_kernel, bf16_core.hpp; plane 1 = lo part)
-template <int NP>
-__global__ __launch_bounds__(256) void upsample12_kernel(const float* __restrict__ e0, Lin up0, Dense up2, void* __restrict__ h2p_v) {
+//   NC / c_off: the launch covers channels c_off .. c_off + NC of e0's 256 ([ets (128) || enc (128)]); the bf16 modes keep the
+//   timestep half (per step) and the text half (per call, ctext_kernel) apart: h2p[b][k/16][c - c_off][plane][k%16], NC = 128
+template <int NP, int NC>
+__global__ __launch_bounds__(256) void upsample12_kernel(const float* __restrict__ e0, int c_off, Lin up0, Dense up2, void* __restrict__ h2p_v) {
     constexpr int TM = 64, LDA = lds_ld(128);
     __shared__ __attribute__((aligned(16))) float bufA[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TM;           // 64 consecutive channels c of one sample
-    const int b = r0 >> 8, c0 = r0 & 255;
+    const int b = blockIdx.x / (NC / TM), c0 = (blockIdx.x % (NC / TM)) * TM;   // 64 consecutive channels c of one row of e0
+    const int r0 = b * 256 + c_off + c0;
     for (int e = tid; e < TM * 128; e += 256) {
         const int row = e >> 7, j = e & 127;
         bufA[row * LDA + j] = gelu(fmaf(e0[r0 + row], up0.w[j], up0.b[j]));
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void upsample12_kernel(const float* __restrict
                 if constexpr (NP == 0) {
                     static_cast<float*>(h2p_v)[(((size_t)b * 64 + (k >> 3)) * 256 + c) * 8 + (k & 7)] = v;
                 } else {
-                    __bf16* dst = static_cast<__bf16*>(h2p_v) + ((((size_t)b * 32 + (k >> 4)) * 256 + c) * NP) * 16 + (k & 15);
+                    __bf16* dst = static_cast<__bf16*>(h2p_v) + ((((size_t)b * 32 + (k >> 4)) * NC + c) * NP) * 16 + (k & 15);
                     const __bf16 hi = (__bf16)v;
                     dst[0] = hi;
                     if constexpr (NP == 2) dst[16] = (__bf16)(v - (float)hi);
@@ -424,12 +426,12 @@ void launch_posa(const PosaParams& P, const float* given_objs, int B, float* ws,
     hipLaunchKernelGGL(posa_stage_kernel<1>, dim3(B * 11), dim3(256), 0, st, P, given_objs, stat1, part2, part3, hm);
     hipLaunchKernelGGL(posa_stage_kernel<2>, dim3(B * 8), dim3(256), 0, st, P, given_objs, stat1, part2, part3, hm);
 }
-void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, void* h2p, hipStream_t st) {
-    const dim3 grid(B * 256 / 64), block(256);
+void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int rows, int c_off, void* h2p, hipStream_t st) {
+    const dim3 block(256);
     const Dense up2{up2_wp, up2_b};
-    if (np == 0) hipLaunchKernelGGL(upsample12_kernel<0>, grid, block, 0, st, e0, up0, up2, h2p);
-    else if (np == 1) hipLaunchKernelGGL(upsample12_kernel<1>, grid, block, 0, st, e0, up0, up2, h2p);
-    else hipLaunchKernelGGL(upsample12_kernel<2>, grid, block, 0, st, e0, up0, up2, h2p);
+    if (np == 0) hipLaunchKernelGGL((upsample12_kernel<0, 256>), dim3(rows * 4), block, 0, st, e0, 0, up0, up2, h2p);
+    else if (np == 1) hipLaunchKernelGGL((upsample12_kernel<1, 128>), dim3(rows * 2), block, 0, st, e0, c_off, up0, up2, h2p);
+    else hipLaunchKernelGGL((upsample12_kernel<2, 128>), dim3(rows * 2), block, 0, st, e0, c_off, up0, up2, h2p);
 }
 void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st) {
     hipLaunchKernelGGL(scene_attn_kernel, dim3(B * kSlots), dim3(256), 0, st, P, pcd, w, tr, o);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
     f32x16 acc[NCB][TS::RB];
     f32x4 bv1[NCB][4];
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) { acc_zero_h(acc[q]); load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane); }
+    for (int q = 0; q < NCB; ++q) { load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane); acc_bias_h(acc[q], bv1[q]); }
     for (int ch = 0; ch < K0 / KC; ++ch) {
         if (ch > 0) __syncthreads();
         static_assert((TM * (KC / 4)) % NT == 0 && (D1 % KC == 0), "gather tiling: a chunk is all points1 or all interpolation");
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
     }
     if constexpr (!HEAD) __syncthreads();   // bufB aliases the chunk buffer
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, TS::RB, NP>(acc[q], rg * TS::RB, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
+    for (int q = 0; q < NCB; ++q) store_lds_b_h<ACT_RELU, TS::RB, NP>(acc[q], rg * TS::RB, cb0 + q * TS::CSTEP, bufB, LDB, PB, lane);
     __syncthreads();
 
     if constexpr (!HEAD) {

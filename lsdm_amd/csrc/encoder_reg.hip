@@ -23,13 +23,7 @@ namespace lsdm {
 namespace {
 
 template <int NP>
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        if constexpr (NP == 2) lo[j] = (__bf16)(v[j] - (float)hi[j]);
-    }
-}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) { split8_h<NP>(v, hi, lo); }
 
 // weight fragment (nb, s, plane) of a layer whose fragments start at `base` (LDS): 1 KiB each, lane-linear
 template <int NP>
@@ -45,9 +39,15 @@ __device__ __forceinline__ void layer_reg(const bf16x8 (&xh)[KS], const bf16x8 (
     const int h = lane >> 5;
 #pragma unroll
     for (int nb = 0; nb < N / 32; ++nb) {
+        // accumulators 8*s2 .. 8*s2+7 = channels 32*nb + 16*s2 + {0..3, 8..11} + 4h  ->  next layer's k-step 2*nb + s2.
+        // They START from the bias (the LDS read lands in the accumulator registers: no zeroing, no add in the epilogue).
         f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * q + j] = bq[j];
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bf16x8 wh = wfrag_lds<NP>(W, KS, nb, s, 0, lane);
@@ -58,17 +58,11 @@ __device__ __forceinline__ void layer_reg(const bf16x8 (&xh)[KS], const bf16x8 (
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
         }
-        // accumulators 8*s2 .. 8*s2+7 = channels 32*nb + 16*s2 + {0..3, 8..11} + 4h  ->  next layer's k-step 2*nb + s2
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 16 * s2 + 4 * h);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 16 * s2 + 8 + 4 * h);
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = reluf(acc[8 * s2 + j] + b0[j]);
-                v[4 + j] = reluf(acc[8 * s2 + 4 + j] + b1[j]);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);
             split8<NP>(v, yh[2 * nb + s2], yl[2 * nb + s2]);
         }
         __builtin_amdgcn_sched_barrier(0);   // one channel block at a time: keeps the unrolled LDS weight reads from piling up in VGPRs
@@ -251,12 +245,12 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
         const __bf16* src = blob_w + panel_off(q);
         // the panels are the same every round: without this the compiler hoists all NPANEL fetches out of the persistent
         // loop and parks them in ~200 VGPRs
-        asm volatile("" : "+s"(src));
+        src = opaque_ptr(src);   // keeps the (round-invariant) panel fetches inside the persistent loop, as global loads
         const int n16 = panel_nf(q) * 64;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int e = tid + i * NT;
-            if (e < n16) stage[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)e * 8);
+            if (e < n16) stage[i] = gload<bf16x8>(src + (size_t)e * 8);
         }
     };
     auto commit = [&](int q) {      // registers -> LDS buffer q & 1

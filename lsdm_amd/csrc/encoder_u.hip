@@ -10,6 +10,8 @@
 //
 //   lin_u_kernel : U = X x Wf^T + xyz x Wx^T + b,  V = xyz x Wx^T     (rows = source points of all clouds)
 //   sa_u_kernel  : register-chained two-layer stack on ReLU(U_j - V_i) + max over the 32 neighbours (sa3; cf. sa_s_kernel)
+#include <cstdlib>
+
 #include "bf16_core.hpp"
 #include "kernels.hpp"
 
@@ -18,13 +20,7 @@ namespace lsdm {
 namespace {
 
 template <int NP>
-__device__ __forceinline__ void split8u(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        if constexpr (NP == 2) lo[j] = (__bf16)(v[j] - (float)hi[j]);
-    }
-}
+__device__ __forceinline__ void split8u(const float (&v)[8], bf16x8& hi, bf16x8& lo) { split8_h<NP>(v, hi, lo); }
 template <int NP>
 __device__ __forceinline__ bf16x8 wfrag_lds_u(const __bf16* base, int NS, int nb, int s, int plane, int lane) {
     return *reinterpret_cast<const bf16x8*>(base + ((size_t)((nb * NS + s) * NP + plane) * 64 + lane) * 8);
@@ -164,12 +160,12 @@ __global__ __launch_bounds__(NW * 64) void sa_u_kernel(const float* __restrict__
     bf16x8 stage[PIECES];
     auto fetch = [&](int q) {
         const __bf16* src = blob_w + panel_off(q);
-        asm volatile("" : "+s"(src));   // keeps the (round-invariant) panel fetches inside the persistent loop
+        src = opaque_ptr(src);   // keeps the (round-invariant) panel fetches inside the persistent loop, as global loads
         const int n16 = panel_nf(q) * 64;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int e = tid + i * NT;
-            if (e < n16) stage[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)e * 8);
+            if (e < n16) stage[i] = gload<bf16x8>(src + (size_t)e * 8);
         }
     };
     auto commit = [&](int q) {
@@ -241,6 +237,257 @@ __global__ __launch_bounds__(NW * 64) void sa_u_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// sa_u2_kernel: the same stack with layer 2 RESIDENT in LDS and only layer 3 streamed.
+//
+// sa_u_kernel moves every weight panel of both layers from L2 into LDS once per round of NW = 4 centroids (192 KB per 128
+// points): at two work-groups per CU that is ~100 GB/s per CU, ~26 TB/s on the chip -- the L2 limit, not the matrix pipe, sets
+// its pace (38 % MFMA busy).  Here a work-group has 8 waves (one per centroid, 256 points per round), keeps the 64 KB of
+// layer-2 fragments in LDS for its whole life (no barrier inside layer 2: the waves drift apart and overlap their epilogues
+// with each other's MFMAs) and streams the 128 KB of layer 3 through two 16 KB buffers: 0.5 KB per point instead of 1.5 KB.
+// The bias of a transposed block initialises its accumulators (the ds_read lands in the accumulator registers: no zeroing,
+// no add in the epilogue).
+template <int C1, int C2, int C3, int NW, int NP>
+__global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                         const int* __restrict__ cent_idx, const int* __restrict__ ball, int NSRC, int S,
+                                                         long long total_centroids, const __bf16* __restrict__ blob_w,
+                                                         const float* __restrict__ blob_b, float* __restrict__ out) {
+    constexpr int NT = NW * 64;
+    constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
+    constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
+    constexpr int F2 = KS2 * NP, F3 = KS3 * NP;
+    constexpr int W2E = NB2 * F2 * 512;
+    static_assert(NB3 % 2 == 0, "panel count must be even (double-buffer parity is compile-time)");
+    constexpr int PIECES = (F3 * 64 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) __bf16 w2[W2E];
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][F3 * 512];
+    __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < W2E / 8; e += NT) *reinterpret_cast<bf16x8*>(w2 + (size_t)e * 8) = *reinterpret_cast<const bf16x8*>(blob_w + (size_t)e * 8);
+    for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
+    const float* b2 = bl;
+    const float* b3 = bl + C2;
+    const int p = lane & 31, h = lane >> 5;
+    const __bf16* w3g = blob_w + W2E;
+
+    // Layer-3 panels are requested TWO panel steps ahead (a step is 24 MFMAs per wave, ~1.5k cycles with two waves per SIMD;
+    // the loaded L2 latency is more than that): panel r travels through register set r % 2 into LDS buffer r % 2.
+    bf16x8 stage[2][PIECES];
+    auto fetch = [&](int q) {
+        const __bf16* src = w3g + (size_t)q * F3 * 512;
+        src = opaque_ptr(src);   // keeps the (round-invariant) panel fetches inside the persistent loop, as global loads
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int e = tid + i * NT;
+            if ((F3 * 64) % NT == 0 || e < F3 * 64) stage[q & 1][i] = gload<bf16x8>(src + (size_t)e * 8);
+        }
+    };
+    auto commit = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int e = tid + i * NT;
+            if ((F3 * 64) % NT == 0 || e < F3 * 64) *reinterpret_cast<bf16x8*>(&wl[q & 1][(size_t)e * 8]) = stage[q & 1][i];
+        }
+    };
+    fetch(0);
+    commit(0);
+    fetch(1);
+    __syncthreads();
+
+    const long long rounds = (total_centroids + NW - 1) / NW;
+    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
+    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
+    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    // the neighbour / centroid indices of a round are requested during the previous round (first of two dependent latencies)
+    auto cent_of = [&](long long rd) { const long long ce = rd * NW + wave; return ce < total_centroids ? ce : total_centroids - 1; };
+    int idx_n = 0, ci_n = 0;
+    if (rbeg < rend) { const long long ce = cent_of(rbeg); idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
+    for (long long rd = rbeg; rd < rend; ++rd) {
+        long long cent = rd * NW + wave;
+        const bool live = cent < total_centroids;
+        if (!live) cent = total_centroids - 1;
+        const long long c = cent / S;
+        const float* urow = U + ((size_t)c * NSRC + idx_n) * C1 + 8 * h;
+        const float* vrow = V + ((size_t)c * NSRC + ci_n) * C1 + 8 * h;
+        bf16x8 yh[KS2], yl[KS2];
+        {
+            f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
+                v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
+            }
+            if (rd + 1 < rend) { const long long ce = cent_of(rd + 1); idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
+                                    reluf(u1[s][0] - v1[s][0]), reluf(u1[s][1] - v1[s][1]), reluf(u1[s][2] - v1[s][2]), reluf(u1[s][3] - v1[s][3])};
+                split8u<NP>(t, yh[s], yl[s]);
+            }
+        }
+        // ---- layer 2 from the resident fragments: no barrier, accumulators start from the bias
+        bf16x8 zh[KS3], zl[KS3];
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb) {
+            int lz = 0;
+            asm volatile("" : "+v"(lz));      // opaque zero: the (round-invariant) LDS reads stay inside the loop
+            const float* bq = b2 + lz + 32 * nb + 4 * h;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bq + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+            }
+            const __bf16* W = w2 + lz + (size_t)nb * F2 * 512;
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const bf16x8 wh = wfrag_lds_u<NP>(W, KS2, 0, s, 0, lane);
+                if constexpr (NP == 2) {
+                    const bf16x8 wlo = wfrag_lds_u<NP>(W, KS2, 0, s, 1, lane);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, yh[s], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh[s], acc, 0, 0, 0);
+                if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);
+                split8u<NP>(v, zh[2 * nb + s2], zl[2 * nb + s2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- layer 3 streamed: one 16 KB panel per 32-channel block, direct orientation, max over the 32 neighbours
+#define PANEL_BEGIN(Q) { fetch(((Q) + 2) % NB3); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz));
+#define PANEL_END(Q) commit(((Q) + 1) % NB3); __syncthreads(); }
+#pragma unroll
+        for (int nb = 0; nb < NB3; ++nb) {
+            PANEL_BEGIN(nb)
+            f32x16 acc;
+            mma_panel_u<KS3, NP, false>(acc, W, zh, zl, lane);
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (live && lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[lz + nb * 32 + lane]);
+            PANEL_END(nb)
+        }
+#undef PANEL_BEGIN
+#undef PANEL_END
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sa_ur_kernel: the split first layer for a NARROW level (sa2: 64 -> 64 -> 128 on ReLU(U_j - V_i)) -- all fragments of both
+// remaining layers (48 KB as hi + lo) stay in LDS for the life of a persistent work-group, each wave carries one centroid
+// through the stack in registers (encoder_reg.hip::sa_r_kernel without its first layer: 72 instead of 102 MFMAs per centroid).
+// `remap` (optional, per cloud NSRC entries): U / V are indexed by remap[position] instead of the position -- the loop-invariant
+// schedule evaluates U, V once per call in SOURCE order and reads them through the step's level-1 FPS order.
+template <int C1, int C2, int C3, int NW, int NP>
+__global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                         const int* __restrict__ cent_idx, const int* __restrict__ ball,
+                                                         const int* __restrict__ remap, int NSRC, int S, long long total_centroids,
+                                                         const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
+                                                         float* __restrict__ out) {
+    constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
+    constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
+    constexpr int W2E = NB2 * KS2 * NP * 512, W3E = NB3 * KS3 * NP * 512;
+    __shared__ __attribute__((aligned(16))) __bf16 wl[W2E + W3E];
+    __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < (W2E + W3E) / 8; e += NW * 64)
+        *reinterpret_cast<bf16x8*>(wl + (size_t)e * 8) = *reinterpret_cast<const bf16x8*>(blob_w + (size_t)e * 8);
+    for (int e = tid; e < C2 + C3; e += NW * 64) bl[e] = blob_b[e];
+    __syncthreads();
+    const __bf16* W2 = wl;
+    const __bf16* W3 = wl + W2E;
+    const float* b2 = bl;
+    const float* b3 = bl + C2;
+    const int p = lane & 31, h = lane >> 5;
+    const long long chunk = ((total_centroids + gridDim.x - 1) / gridDim.x + NW - 1) / NW * NW;
+    const long long cbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk;
+    const long long cend = cbeg + chunk < total_centroids ? cbeg + chunk : total_centroids;
+    for (long long cent = cbeg + wave; cent < cend; cent += NW) {
+        const long long c = cent / S;
+        int idx = ball[cent * kNSample + p];
+        int ci = cent_idx[cent];
+        if (remap) { idx = remap[c * NSRC + idx]; ci = remap[c * NSRC + ci]; }
+        const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
+        const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 8 * h;
+        bf16x8 yh[KS2], yl[KS2];
+        {
+            f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
+                v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
+            }
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
+                                    reluf(u1[s][0] - v1[s][0]), reluf(u1[s][1] - v1[s][1]), reluf(u1[s][2] - v1[s][2]), reluf(u1[s][3] - v1[s][3])};
+                split8u<NP>(t, yh[s], yl[s]);
+            }
+        }
+        // ---- layer 2: accumulators start from the bias; block nb feeds k-steps 2 nb, 2 nb + 1 of layer 3
+        bf16x8 zh[KS3], zl[KS3];
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
+            }
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const bf16x8 wh = wfrag_lds_u<NP>(W2, KS2, nb, s, 0, lane);
+                if constexpr (NP == 2) {
+                    const bf16x8 wlo = wfrag_lds_u<NP>(W2, KS2, nb, s, 1, lane);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, yh[s], acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);
+                split8u<NP>(v, zh[2 * nb + s2], zl[2 * nb + s2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- layer 3, direct orientation, max over the 32 neighbours (ReLU(x + b) is monotone: pool first)
+#pragma unroll
+        for (int nb = 0; nb < NB3; ++nb) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) {
+                const bf16x8 wh = wfrag_lds_u<NP>(W3, KS3, nb, s, 0, lane);
+                if constexpr (NP == 2) {
+                    const bf16x8 wlo = wfrag_lds_u<NP>(W3, KS3, nb, s, 1, lane);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], wh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wlo, acc, 0, 0, 0);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wh, acc, 0, 0, 0);
+            }
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[nb * 32 + lane]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // FP stage with the interpolated operand PRE-MULTIPLIED at the coarse level (fp2, fp3).  The first FP layer is linear in
 // [p1 || sum_j w_j p2_j] (pointnet2_utils.py:299-312), so with W = [Wa | Wb]:  W x [...] + b = Wa x p1 + sum_j w_j (Wb x p2_j) + b.
 // Y = p2 x Wb^T is evaluated once per COARSE point (lin_u_kernel<.., XYZ = false>, S = N/4 rows); here the three Y rows of a
@@ -248,9 +495,10 @@ __global__ __launch_bounds__(NW * 64) void sa_u_kernel(const float* __restrict__
 // from which every wave initialises its accumulators; the matrix pipe then only contracts over the D1 columns of p1.
 // One LDS region is reused in sequence: interpolated tile (fp32) -> p1 operand tile -> layer-1 activations.
 template <int D1, int C1, int C2>
-__global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict__ points1, const float* __restrict__ y,
-                                                        const int* __restrict__ nn_idx, const float* __restrict__ nn_w, int N, int S,
-                                                        DenseH l1, DenseH l2, float* __restrict__ out) {
+__global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
+                                                        const float* __restrict__ y, const int* __restrict__ nn_idx,
+                                                        const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
+                                                        float* __restrict__ out) {
     constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
     constexpr int LDT = C1 + 4;                              // fp32 tile row (floats): 16-byte aligned, rows 4 banks apart
     constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
@@ -266,11 +514,21 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
     const int n0 = tl * TM;
     const float* p1 = points1 + ((size_t)c * N + n0) * D1;
     const float* yb = y + (size_t)c * S * C1;
-    // the p1 tile is requested first (consumed in phase C)
+    // the p1 tile is requested first (consumed in phase C); p1_remap (optional): row i of the cloud is points1[p1_remap[i]]
+    // (loop-invariant schedule: the level-1 features stay in SOURCE order, the step's FPS order is the index list)
     constexpr int XIT = TM * (D1 / 4) / NT;
     f32x4 gx[XIT];
+    if (p1_remap) {
 #pragma unroll
-    for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4);
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tid + it * NT;
+            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
+            gx[it] = load4f(points1 + ((size_t)c * N + p1_remap[(size_t)c * N + n0 + row]) * D1 + 4 * c4);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4);
+    }
     // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
     {
         const int row = tid >> 2, sub = tid & 3;
@@ -354,29 +612,36 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
 }
 
 // which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
-void launch_fp_pre(int which, int nc, const float* points1, const float* fpo_coarse, DenseH wb, float* ybuf, const int* nn_idx,
-                   const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st) {
+void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
+                   const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st) {
     const int S = which == 2 ? 256 : 64;
     const int R = nc * S;   // Y = coarse-level FP output x Wb^T
     hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
     if (which == 2)
-        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out);
+        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out);
     else
-        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out);
+        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out);
 }
 
 // ---------------------------------------------------------------------------------------------
 void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st) {
     const dim3 grid((R + 63) / 64), block(256);
-    if (level == 2) hipLaunchKernelGGL((lin_u_kernel<128, 128>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
+    if (level == 1) hipLaunchKernelGGL((lin_u_kernel<64, 64>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
+    else if (level == 2) hipLaunchKernelGGL((lin_u_kernel<128, 128>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
     else hipLaunchKernelGGL((lin_u_kernel<256, 256>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
 }
 
-void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const __bf16* blob_w,
-                 const float* blob_b, float* out, hipStream_t st) {
-    if (level == 2) {
+void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
+                 const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
+    if (level == 1) {
+        const long long tot = (long long)nc * 256;
+        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out);
+    } else if (level == 2) {
         const long long tot = (long long)nc * 64;
-        hipLaunchKernelGGL((sa_u_kernel<128, 128, 256, 4, 2>), dim3(512), dim3(256), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
+        // LSDM_SA3_V1=1: the older kernel that streams both layers (A/B switch for measurements)
+        static const bool v1 = getenv("LSDM_SA3_V1") && atoi(getenv("LSDM_SA3_V1")) != 0;
+        if (v1) hipLaunchKernelGGL((sa_u_kernel<128, 128, 256, 4, 2>), dim3(512), dim3(256), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
+        else hipLaunchKernelGGL((sa_u2_kernel<128, 128, 256, 8, 2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
     }
 }
 

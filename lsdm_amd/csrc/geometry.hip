@@ -638,9 +638,11 @@ __global__ __launch_bounds__(256) void l1_remap_kernel(const unsigned char* __re
     const int ppr = row_bytes / 16;
     const unsigned char* fsrc = F1 + (size_t)c * N * row_bytes;
     unsigned char* fdst = feat1 + (size_t)c * N * row_bytes;
-    for (int e = tid; e < N * ppr; e += NT) {
-        const int i = e / ppr, q = e - i * ppr;
-        *reinterpret_cast<f32x4*>(fdst + (size_t)i * row_bytes + q * 16) = *reinterpret_cast<const f32x4*>(fsrc + (size_t)id[i] * row_bytes + q * 16);
+    if (feat1) {   // (NULL: the consumers read F1 through idx1 themselves)
+        for (int e = tid; e < N * ppr; e += NT) {
+            const int i = e / ppr, q = e - i * ppr;
+            *reinterpret_cast<f32x4*>(fdst + (size_t)i * row_bytes + q * 16) = *reinterpret_cast<const f32x4*>(fsrc + (size_t)id[i] * row_bytes + q * 16);
+        }
     }
     // 3-NN of the fine points from their 8 candidates: smallest (distance, level-1 position); certified when the 8th
     // candidate is strictly farther than the chosen third (otherwise more ties than candidates: exhaustive path below)

@@ -101,13 +101,15 @@ void launch_sa_h_pre(int num_clouds, const float* U, const float* V, const int* 
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
-// point (level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on ReLU(U_j - V_i)
+// point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
+// ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
 void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
-void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const __bf16* blob_w,
-                 const float* blob_b, float* out, hipStream_t st);
+void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
+                 const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
-void launch_fp_pre(int which, int num_clouds, const float* points1, const float* fpo_coarse, DenseH wb, float* ybuf, const int* nn_idx,
-                   const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st);
+// p1_remap (optional): row i of a cloud's points1 is points1[p1_remap[i]]
+void launch_fp_pre(int which, int num_clouds, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
+                   const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st);
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
@@ -115,8 +117,9 @@ void launch_cond(const CondParams& P, const int64_t* t, const float* text, const
 // ws: B * 664 floats of scratch (moment triples of the GroupNorm reductions)
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* ws, float* hm, hipStream_t st);
 constexpr int kPosaWsPerSample = 16 + 16 * 24 + 11 * 24;
-// np = 0: fp32 operand for denoise_kernel; 1 / 2: bf16 planes for denoise_h_kernel
-void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int B, void* h2p, hipStream_t st);
+// np = 0: fp32 operand for denoise_kernel (all 256 channels of e0 per row); 1 / 2: bf16 planes for denoise_h_kernel /
+// ctext_kernel, the 128 channels from c_off (0: timestep half, one row per (step, sample); 128: text half, one row per sample)
+void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int rows, int c_off, void* h2p, hipStream_t st);
 void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st);
 // denoise.hip
 void launch_denoise(const DenoiseParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
@@ -127,8 +130,12 @@ void launch_denoise(const DenoiseParams& P, const StepCoefs& sc, int mode, float
 void launch_nn_dist(const float* A, int na, const float* B, int nb, int batch, float* out_d2, int* out_idx, hipStream_t st);
 
 // denoise_bf.hip
-void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
-                      const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2p,
-                      const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
+// ctext (B,1024,128) fp32: the text half of combine_extraction's pre-activation, once per call (h2x: text half of the
+// second up-sampling activation, one row per sample)
+void launch_ctext(int np, const DenoiseHParams& P, int B, const void* h2x, float* ctext, hipStream_t st);
+// nsteps consecutive steps in one launch (h2t / t / noise hold nsteps rows; nsteps > 1 writes the final sample to x)
+void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, float* x, const int64_t* t,
+                      const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
+                      const float* ctext, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
 
 }  // namespace lsdm

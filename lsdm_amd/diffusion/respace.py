@@ -51,6 +51,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def p_mean_variance(self, model, *args, **kwargs):
         return super().p_mean_variance(self._wrap_model(model), *args, **kwargs)
 
+    def training_losses(self, model, *args, **kwargs):
+        return super().training_losses(self._wrap_model(model), *args, **kwargs)
+
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
