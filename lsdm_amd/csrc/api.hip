@@ -52,6 +52,9 @@ struct lsdm_ctx {
     // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
     // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
     DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
+    DenseH fp1_s{}, fp2_s{};     // fp1 + head / fp2 as register-chained blobs (encoder_reg.hip::fp_s_kernel, fp_ps_kernel)
+    int fp2_reg = getenv("LSDM_FP2_REG") ? atoi(getenv("LSDM_FP2_REG")) : 0;   // A/B switch (measured: 317 us vs 287 us for fp_pre_kernel)
+    int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
     // first FP layer split at the concat boundary (encoder_u.hip): columns of points1 (+ bias) / of the interpolated points2;
     // index 0: fp3, 1: fp2
     DenseH fp_a[2], fp_y[2];
@@ -119,6 +122,17 @@ struct lsdm_ctx {
         // bf16 hi (bf16); offsets in floats
         f.h2p += o * B * (prec == LSDM_PREC_F32 ? 256 * 512 : (prec == LSDM_PREC_BF16X3 ? 128 * 512 : 64 * 512));
         f.tbuf += o * B;
+        return f;
+    }
+    // Multi-step calls in the bf16 modes: every chain of the batch is at the same timestep, so the conditioning vectors that do
+    // not depend on t (text / category embeddings, attention weights, translation tokens: rows of set 0) are evaluated once
+    // per call and the timestep half of the up-sampling has ONE row per step (row j of set 0's h2p) -- run_conditioning(shared).
+    bool shared_t() const { return prec != LSDM_PREC_F32; }
+    FrontSet fset_steps(int j, int B) const {
+        FrontSet f = fset(j, B);
+        if (!shared_t()) return f;
+        f.e0 = fs0.e0; f.tr = fs0.tr; f.w = fs0.w;
+        f.h2p = fs0.h2p + (size_t)j * (prec == LSDM_PREC_BF16X3 ? 128 * 512 : 64 * 512);
         return f;
     }
     float* feat[4] = {};
@@ -296,14 +310,20 @@ bool fold_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname,
 //   later layers: 32*(s/2) + 8*(2*(s%2) + j/4) + 4*h + j%4  -- the channels a lane owns in accumulator registers
 //                 8*(s%2) .. 8*(s%2)+7 of block s/2 of the previous layer's transposed product
 // followed (separately) by the fp32 biases of the layers back to back, BatchNorm folded.
-struct ChainLayer { std::string w, b, bn; int N, K; };
+struct ChainLayer { std::string w, b, bn; int N, K; int padN = 0; };   // padN: rows zero-padded to that many channels
 bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const std::vector<int>& first_map, int np, DenseH* out) {
     std::vector<uint16_t> blob;
     std::vector<float> biases;
     for (size_t li = 0; li < layers.size(); ++li) {
-        const int N = layers[li].N, K = layers[li].K;
+        int N = layers[li].N;
+        const int K = layers[li].K;
         std::vector<float> W, Bv;
         if (!fold_dense(c, layers[li].w, layers[li].b, layers[li].bn, N, K, W, Bv)) return false;
+        if (layers[li].padN > N) {
+            N = layers[li].padN;
+            W.resize((size_t)N * K, 0.0f);
+            Bv.resize(N, 0.0f);
+        }
         const int KS = li == 0 ? ((int)first_map.size() + 15) / 16 : K / 16;
         for (int nb = 0; nb < N / 32; ++nb)
             for (int s = 0; s < KS; ++s)
@@ -324,6 +344,41 @@ bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const 
         biases.insert(biases.end(), Bv.begin(), Bv.end());
     }
     if (blob.size() % 2) blob.push_back(0);
+    out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
+    out->b = upload(c, biases.data(), biases.size());
+    return out->w && out->b;
+}
+
+// Fragment blob of encoder_reg.hip::fp_ps_kernel (fp2 on the pre-multiplied interpolation operand): per panel nb = 0..7
+//   [Wa = conv0[:, 0:64] block nb: 4 k-steps x np planes][conv1 columns of block nb: 4 channel blocks x 2 k-steps x np planes]
+// with the fragment element order of build_chain_blob (first layer: k-slot (s, h, j) = input channel 16 s + 8 h + j; second
+// layer: the accumulator order of the first layer's transposed product); biases [conv0 (256) | conv1 (128)], BatchNorm folded.
+bool build_fp2_blob(lsdm_ctx* c, int np, DenseH* out) {
+    const std::string pre = "pcd_backbone.fp2";
+    std::vector<float> W0, B0, W1, B1;
+    if (!fold_dense(c, pre + ".mlp_convs.0.weight", pre + ".mlp_convs.0.bias", pre + ".mlp_bns.0", 256, 320, W0, B0) ||
+        !fold_dense(c, pre + ".mlp_convs.1.weight", pre + ".mlp_convs.1.bias", pre + ".mlp_bns.1", 128, 256, W1, B1))
+        return false;
+    std::vector<uint16_t> blob;
+    auto frag = [&](const std::vector<float>& W, int K, int nb, int s, int pl, bool first) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int n = nb * 32 + (lane & 31), h = lane >> 5;
+                const int k = first ? 16 * s + 8 * h + j : 32 * (s / 2) + 8 * (2 * (s % 2) + j / 4) + 4 * h + j % 4;
+                const float v = W[(size_t)n * K + k];
+                const uint16_t hi = f2bf(v);
+                blob.push_back(pl == 0 ? hi : f2bf(v - bf2f(hi)));
+            }
+    };
+    for (int nb1 = 0; nb1 < 8; ++nb1) {
+        for (int s = 0; s < 4; ++s)
+            for (int pl = 0; pl < np; ++pl) frag(W0, 320, nb1, s, pl, true);
+        for (int nb2 = 0; nb2 < 4; ++nb2)
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int pl = 0; pl < np; ++pl) frag(W1, 256, nb2, 2 * nb1 + s2, pl, false);
+    }
+    std::vector<float> biases = B0;
+    biases.insert(biases.end(), B1.begin(), B1.end());
     out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
     out->b = upload(c, biases.data(), biases.size());
     return out->w && out->b;
@@ -489,15 +544,21 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     else
         launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
     prof_mark(c, K_FP2, st);
-    if (np == 2 && c->fp_pre >= 1 && skip_sa1 && inv_in_source_order(c))
-        launch_fp_pre(2, nc, static_cast<const float*>(c->inv_F1), f.idx[0], c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1],
-                      c->fp_h[2][1], c->fpo2, st);
-    else if (np == 2 && c->fp_pre >= 1)
-        launch_fp_pre(2, nc, c->feat[0], nullptr, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, st);
-    else
+    if (np == 2 && c->fp_pre >= 1) {
+        const bool src = skip_sa1 && inv_in_source_order(c);   // level-1 features in source order, read through f.idx[0]
+        const float* p1 = src ? static_cast<const float*>(c->inv_F1) : c->feat[0];
+        const int* remap = src ? f.idx[0] : nullptr;
+        if (c->fp2_reg) {
+            launch_fp_y(nc * 256, c->fpo3, c->fp_y[1], c->fp_ybuf[1], st);
+            launch_fp_ps(nc, p1, remap, c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp2_s.w, c->fp2_s.b, c->fpo2, st);
+        } else {
+            launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, st);
+        }
+    } else
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_mark(c, K_FP1, st);
-    launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
+    if (np == 2 && c->fp1_reg) launch_fp_s(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
+    else launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
 }
 
 int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
@@ -510,20 +571,35 @@ int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, i
 // category MLPs + up-sampling layers 1-2, one launch each for the group; `t` holds g*B timesteps (step-major).
 // The human branch depends on given_objs only and is evaluated once per multi-step call.
 void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, const float* mask, const float* given_objs,
-                      const float* given_cats, const float* text, float* out_cat, bool reuse_hm, hipStream_t st) {
-    prof_mark(c, K_COND, st);
-    launch_cond(c->cond, t, text, given_cats, mask, B, g, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
-    prof_mark(c, K_UP12, st);
+                      const float* given_cats, const float* text, float* out_cat, bool reuse_hm, hipStream_t st, bool shared = false) {
     const int np = c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1);
-    launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B * g, 0, f.h2p, st);
+    shared = shared && np != 0;
+    prof_mark(c, K_COND, st);
+    if (!shared) {
+        launch_cond(c->cond, t, text, given_cats, mask, B, g, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
+        prof_mark(c, K_UP12, st);
+        launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B * g, 0, f.h2p, st);
+    } else if (!reuse_hm) {
+        // per call: the sample rows (text / category embeddings, attention weights, translation tokens) of set 0
+        launch_cond(c->cond, t, text, given_cats, mask, B, 1, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
+    }
     if (!reuse_hm) {
         // once per call: what depends on (given_objs, text) only
         if (np != 0) {
+            prof_mark(c, K_UP12, st);
             launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B, 128, c->h2x, st);
             launch_ctext(np, c->den_h, B, c->h2x, c->ctext, st);
         }
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->posa_ws, c->hm, st);
+    }
+    if (shared) {
+        // per group: one timestep-embedding row per STEP (t of step j = t[j * B]) into the first halves of rows 0 .. g-1 of e0
+        // (their text halves were consumed above), and its up-sampling rows
+        prof_mark(c, K_COND, st);
+        launch_cond_time(c->cond, t, B, g, f.e0, st);
+        prof_mark(c, K_UP12, st);
+        launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, g, 0, f.h2p, st);
     }
     prof_mark(c, -1, st);
 }
@@ -546,13 +622,14 @@ void run_scene_conditioning(lsdm_ctx* c, const FrontSet& f, int B, const float* 
 // nsteps > 1 (bf16 modes, hoisted conditioning): that many consecutive steps of the front sets f, f+1, ... in ONE launch; the
 // final sample lands in x
 void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
-                 const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st, int nsteps = 1) {
+                 const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st, int nsteps = 1,
+                 bool shared = false) {
     prof_mark(c, K_DENOISE, st);
     if (c->prec == LSDM_PREC_F32)
         launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm, f.h2p, noise, out_x0, out_guiding,
                        out_sample, st);
     else
-        launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, nsteps, x, t, mask, c->pcd, f.w, c->o12, c->hm,
+        launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, nsteps, shared ? 0 : 1, x, t, mask, c->pcd, f.w, c->o12, c->hm,
                          f.h2p, c->ctext, noise, out_x0, out_guiding, out_sample, st);
     prof_mark(c, -1, st);
 }
@@ -560,7 +637,7 @@ void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, flo
 // BACK of a step: dense encoder stages, collapsed scene attention, the fused per-point denoiser + sampler update
 void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float* x, const int64_t* t, const float* mask,
               const float* given_objs, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st,
-              bool inv = false) {
+              bool inv = false, bool shared = false) {
     if (inv) {
         // level 1 of the encoder from the call's invariants: feature rows and 3-NN positions in this step's FPS order
         prof_mark(c, K_REMAP, st);
@@ -569,7 +646,7 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
                         inv_in_source_order(c) ? nullptr : (np == 1 ? c->feat_b[0] : (void*)c->feat[0]), f.nn_idx[3], f.nn_w[3], st);
     }
     run_scene_conditioning(c, f, B, given_objs, st, inv);
-    run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st);
+    run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st, 1, shared);
 }
 
 int run_step(lsdm_ctx* c, int mode, float eta, int B, float* x, const float* mask, const int64_t* t, const float* given_objs,
@@ -770,6 +847,18 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                     for (int k = 0; k < 64; ++k) ident[k] = k;
                     ok = c->sa_uw[2].w && c->sa_uw[2].b && c->sa_wx[2] && build_chain_blob(c, layers, ident, np, &c->sa_ub[2]);
                 }
+            }
+            // fp1 + head: the five layers as one chain (conv2's three rows zero-padded to a 32-channel block)
+            if (ok) {
+                const std::string f1 = "pcd_backbone.fp1", pb = "pcd_backbone";
+                std::vector<ChainLayer> layers = {{f1 + ".mlp_convs.0.weight", f1 + ".mlp_convs.0.bias", f1 + ".mlp_bns.0", 128, 128},
+                                                  {f1 + ".mlp_convs.1.weight", f1 + ".mlp_convs.1.bias", f1 + ".mlp_bns.1", 128, 128},
+                                                  {f1 + ".mlp_convs.2.weight", f1 + ".mlp_convs.2.bias", f1 + ".mlp_bns.2", 128, 128},
+                                                  {pb + ".conv1.weight", pb + ".conv1.bias", pb + ".bn1", 128, 128},
+                                                  {pb + ".conv2.weight", pb + ".conv2.bias", "", 3, 128, 32}};
+                std::vector<int> ident(128);
+                for (int k = 0; k < 128; ++k) ident[k] = k;
+                ok = build_chain_blob(c, layers, ident, np, &c->fp1_s) && build_fp2_blob(c, np, &c->fp2_s);
             }
             // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
             {
@@ -1075,12 +1164,12 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
     for (int k0 = 0; k0 < K; k0 += gmax) {
         const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
-        run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
+        run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st, /*shared=*/true);
         run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
-            const lsdm_ctx::FrontSet f = c->fset(j, B);
-            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st, inv);
+            const lsdm_ctx::FrontSet f = c->fset_steps(j, B);
+            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st, inv, c->shared_t());
             rc = check_launch(c, "sample step");
             if (rc) return rc;
             float* tmp = cur; cur = nxt; nxt = tmp;
@@ -1125,14 +1214,14 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
         const int g = K - k0 < lsdm_ctx::kGroup ? K - k0 : lsdm_ctx::kGroup;
         // per group: the t-dependent conditioning of its steps in one launch per stage
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
-        run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st);
+        run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st, /*shared=*/true);
         if (k0 == 0) {
             run_geometry(c, c->fs0, given_objs, starts, B * kO, 1, st);
             run_scene_conditioning(c, c->fs0, B, given_objs, st);
         }
         if (c->prec != LSDM_PREC_F32) {
             // the whole group in one launch: a tile's x stays on chip between its steps (denoise_bf.hip)
-            run_denoise(c, c->fs0, mode, eta, B, cur, c->fs0.tbuf, mask, noise + (size_t)k0 * xn, out_x0, out_guiding, nullptr, st, g);
+            run_denoise(c, c->fs0, mode, eta, B, cur, c->fs0.tbuf, mask, noise + (size_t)k0 * xn, out_x0, out_guiding, nullptr, st, g, true);
             rc = check_launch(c, "hoisted sample steps");
             if (rc) return rc;
             continue;

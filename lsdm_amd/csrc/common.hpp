@@ -58,6 +58,20 @@ __device__ __forceinline__ const T* opaque_ptr(const T* p) {
     return p;
 }
 
+// One wave-wide LDS-DMA copy: lane l's 16 bytes at gsrc -> LDS byte address lds_dst + 16 l (lds_dst wave-uniform).  Written
+// as inline asm so that hipcc does not count it: with the builtin it waits vmcnt(0) before the next LDS read of ANY buffer,
+// which makes the copy synchronous.  The issuer waits itself (lds_dma_wait) before the barrier that publishes the data.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <class T>
+__device__ __forceinline__ unsigned lds_addr(const T* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) T*)p;
+}
+
 // C/D map of the 32x32 MFMA shapes (dtype-independent on gfx950): col = lane & 31, row = acc_row(r, lane)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -29,14 +29,16 @@ __device__ __forceinline__ void dense_vec(const float* in, int K, Lin l, float* 
 __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* __restrict__ t, const float* __restrict__ text,
                                                    const float* __restrict__ given_cats, const float* __restrict__ mask, int B,
                                                    int C, float* __restrict__ out_cat, float* __restrict__ e0,
-                                                   float* __restrict__ tr_out, float* __restrict__ w_out) {
+                                                   float* __restrict__ tr_out, float* __restrict__ w_out, int time_only, int tstride) {
     __shared__ float sa[512], sb[512], enc[128], ecat[kSlots * 32], trh[kSlots * 128];
     __shared__ float q[128], kk[kSlots * 128], logit[8 * kSlots];
     // A launch may cover G consecutive steps of the same batch (grid = G*B): block r = step*B + b reads the conditioning
     // of sample b and step `step`'s timestep, and writes row r of e0 / tr / w (the front sets are contiguous).
+    // time_only: row r = one STEP of a multi-step call whose chains all sit at the same timestep t[r * tstride] -- only the
+    // timestep embedding (first half of row r of e0) is evaluated; everything else of the conditioning is per call.
     const int r = blockIdx.x, b = r % B, tid = threadIdx.x;
     // 1. timestep embedding: pe[t] -> Linear -> SiLU -> Linear  (diffusion_utils.py:14-21)
-    const float* pe = P.pe + (size_t)t[r] * 128;
+    const float* pe = P.pe + (size_t)t[(size_t)r * tstride] * 128;
     if (tid < 128) sa[tid] = pe[tid];
     __syncthreads();
     for (int j = tid; j < 128; j += 256) {
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
     }
     __syncthreads();
     dense_vec<ACT_NONE>(sb, 128, P.time2, e0 + (size_t)r * 256, 128);
+    if (time_only) return;
     // 2. text embedding 512 -> 256 -> 256 -> 128, GELU after every layer (Q9)
     __syncthreads();
     for (int k = tid; k < 512; k += 256) sa[k] = text[(size_t)b * 512 + k];
@@ -415,7 +418,10 @@ __global__ __launch_bounds__(256) void scene_attn_kernel(SceneAttnParams P, cons
 // ---------------------------------------------------------------------------------------------
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st) {
-    hipLaunchKernelGGL(cond_kernel, dim3(B * G), dim3(256), 0, st, P, t, text, given_cats, mask, B, C, out_cat, e0, tr, w);
+    hipLaunchKernelGGL(cond_kernel, dim3(B * G), dim3(256), 0, st, P, t, text, given_cats, mask, B, C, out_cat, e0, tr, w, 0, 1);
+}
+void launch_cond_time(const CondParams& P, const int64_t* t, int tstride, int rows, float* e0, hipStream_t st) {
+    hipLaunchKernelGGL(cond_kernel, dim3(rows), dim3(256), 0, st, P, t, nullptr, nullptr, nullptr, 1, 0, nullptr, e0, nullptr, nullptr, 1, tstride);
 }
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* ws, float* hm, hipStream_t st) {
     // ws: B * (16 + 16*24 + 11*24) floats: block-1 (mean, rstd) per sample, per-tile triples of blocks 2 and 3

@@ -169,11 +169,12 @@ __device__ __forceinline__ void launder_params(DenoiseHParams& P) {
     P.fin2.b = opaque_ptr(P.fin2.b);
 }
 
-// h2t: the timestep half of the second up-sampling activation of step s, sample b at h2t + (s * B + b) * 32 * 128 * NP * 16;
+// h2t: the timestep half of the second up-sampling activation: row (s * B + b) of step s, sample b when h2t_per_sample, row s
+// otherwise (multi-step calls: every chain of the batch is at the same timestep), 32 * 128 * NP * 16 elements per row;
 // t: (nsteps, B); noise: (nsteps, B, 1024, 3).  out_sample != NULL: the sample of the (single) step goes there and x keeps x + g (Q5);
 // out_sample == NULL (sampling modes): a chain of nsteps steps whose final sample is written to x.
 template <int NP>
-__global__ __launch_bounds__(NT, 2) void denoise_h_kernel(DenoiseHParams P0_, StepCoefs sc, int mode, float eta, int B, int nsteps,
+__global__ __launch_bounds__(NT, 2) void denoise_h_kernel(DenoiseHParams P0_, StepCoefs sc, int mode, float eta, int B, int nsteps, int h2t_per_sample,
                                                        float* __restrict__ x, const int64_t* __restrict__ t, const float* __restrict__ mask,
                                                        const float* __restrict__ pcd, const float* __restrict__ w,
                                                        const float* __restrict__ o12, const float* __restrict__ hm,
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(NT, 2) void denoise_h_kernel(DenoiseHParams P0_, St
             if (!chain) x[gi] = xv;
         }
         // ---- timestep half of e, then emb = GELU(W_comb[:, :128] . e_t + ctext + b) -> R1 ---------------------------------
-        upsample_half_h<NP>(P, n0, h2t + (size_t)(step * B + b) * 32 * NE * NP * 16, R0, R2);
+        upsample_half_h<NP>(P, n0, h2t + (size_t)(h2t_per_sample ? step * B + b : step) * 32 * NE * NP * 16, R0, R2);
         const int p = lane & 31, h = lane >> 5;
         {
             f32x16 acc[1];
@@ -312,15 +313,15 @@ void launch_ctext(int np, const DenoiseHParams& P, int B, const void* h2x, float
     else hipLaunchKernelGGL(ctext_kernel<1>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, h2, ctext);
 }
 
-void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, float* x, const int64_t* t,
+void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int h2t_per_sample, float* x, const int64_t* t,
                       const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
                       const float* ctext, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
     const __bf16* h2 = static_cast<const __bf16*>(h2t);
     if (np == 2)
-        hipLaunchKernelGGL(denoise_h_kernel<2>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, nsteps, x, t, mask, pcd, w, o12, hm,
+        hipLaunchKernelGGL(denoise_h_kernel<2>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, nsteps, h2t_per_sample, x, t, mask, pcd, w, o12, hm,
                            h2, ctext, noise, out_x0, out_guiding, out_sample);
     else
-        hipLaunchKernelGGL(denoise_h_kernel<1>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, nsteps, x, t, mask, pcd, w, o12, hm,
+        hipLaunchKernelGGL(denoise_h_kernel<1>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, nsteps, h2t_per_sample, x, t, mask, pcd, w, o12, hm,
                            h2, ctext, noise, out_x0, out_guiding, out_sample);
 }
 

@@ -612,11 +612,15 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
 }
 
 // which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
+// Y = coarse-level FP output x Wb^T, R = num_clouds * S rows of 256 channels
+void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
+    hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
+}
+
 void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st) {
     const int S = which == 2 ? 256 : 64;
-    const int R = nc * S;   // Y = coarse-level FP output x Wb^T
-    hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
+    launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
     if (which == 2)
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out);
     else

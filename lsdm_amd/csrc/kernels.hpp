@@ -100,6 +100,14 @@ void launch_sa_h_pre(int num_clouds, const float* U, const float* V, const int* 
 // encoder_reg.hip: register-chained SA kernel for levels 0 and 1 (weights resident in LDS)
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
+// fp2 as a register-chained stack on the pre-multiplied interpolation operand y (launch_fp_y): points1 (nc,1024,64) [through
+// p1_remap when given], y (nc,256,256), out (nc,1024,128)
+void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
+void launch_fp_ps(int num_clouds, const float* points1, const int* p1_remap, const float* y, const int* nn_idx, const float* nn_w,
+                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st);
+// fp1 + head as one register-chained stack (bf16x3): points2 (nc,1024,128) fp32, out (nc,1024,3)
+void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b,
+                 float* out, hipStream_t st);
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
 // point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
 // ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
@@ -114,6 +122,8 @@ void launch_fp_pre(int which, int num_clouds, const float* points1, const int* p
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
                  float* out_cat, float* e0, float* tr, float* w, hipStream_t st);
+// timestep embedding only: row r of e0 (256 floats per row, first 128 written) <- t[r * tstride]
+void launch_cond_time(const CondParams& P, const int64_t* t, int tstride, int rows, float* e0, hipStream_t st);
 // ws: B * 664 floats of scratch (moment triples of the GroupNorm reductions)
 void launch_posa(const PosaParams& P, const float* given_objs, int B, float* ws, float* hm, hipStream_t st);
 constexpr int kPosaWsPerSample = 16 + 16 * 24 + 11 * 24;
@@ -133,8 +143,9 @@ void launch_nn_dist(const float* A, int na, const float* B, int nb, int batch, f
 // ctext (B,1024,128) fp32: the text half of combine_extraction's pre-activation, once per call (h2x: text half of the
 // second up-sampling activation, one row per sample)
 void launch_ctext(int np, const DenoiseHParams& P, int B, const void* h2x, float* ctext, hipStream_t st);
-// nsteps consecutive steps in one launch (h2t / t / noise hold nsteps rows; nsteps > 1 writes the final sample to x)
-void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, float* x, const int64_t* t,
+// nsteps consecutive steps in one launch (t / noise hold nsteps rows; out_sample == NULL in a sampling mode: the final sample goes
+// to x).  h2t rows: one per (step, sample) when h2t_per_sample, one per step otherwise (all chains at the same timestep)
+void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int h2t_per_sample, float* x, const int64_t* t,
                       const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
                       const float* ctext, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
 
