@@ -55,6 +55,9 @@ struct lsdm_ctx {
     DenseH fp1_s{}, fp2_s{};     // fp1 + head / fp2 as register-chained blobs (encoder_reg.hip::fp_s_kernel, fp_ps_kernel)
     int fp2_reg = getenv("LSDM_FP2_REG") ? atoi(getenv("LSDM_FP2_REG")) : 0;   // A/B switch (measured: 317 us vs 287 us for fp_pre_kernel)
     int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
+    DenseH den_r{};              // the per-point denoiser as a register-chained blob (denoise_reg.hip)
+    int den_reg = getenv("LSDM_DEN_REG") ? atoi(getenv("LSDM_DEN_REG")) : 1;   // A/B switch: 0 = the LDS-tiled denoise_h_kernel
+    float* s_stash = nullptr;    // denoise_r_kernel: S of the last step, parked between its two denoiser passes
     // first FP layer split at the concat boundary (encoder_u.hip): columns of points1 (+ bias) / of the interpolated points2;
     // index 0: fp3, 1: fp2
     DenseH fp_a[2], fp_y[2];
@@ -98,6 +101,7 @@ struct lsdm_ctx {
         int* nn_idx[4] = {};
         float* nn_w[4] = {};
         float *e0 = nullptr, *tr = nullptr, *w = nullptr, *h2p = nullptr;
+        float* ctime = nullptr;         // shared-timestep groups: this step's tile of launch_ctext(time_half), else NULL
         int64_t* tbuf = nullptr;
     } fs0;                              // set 0 = base of every [kGroup][...] allocation
     // Set j of a group of steps at batch B.  The batched launches of a group (fill_steps, cond, upsample12, FPS chain, ball
@@ -133,12 +137,14 @@ struct lsdm_ctx {
         if (!shared_t()) return f;
         f.e0 = fs0.e0; f.tr = fs0.tr; f.w = fs0.w;
         f.h2p = fs0.h2p + (size_t)j * (prec == LSDM_PREC_BF16X3 ? 128 * 512 : 64 * 512);
+        f.ctime = ct_time + (size_t)j * 1024 * 128;
         return f;
     }
     float* feat[4] = {};
     float *fpo4 = nullptr, *fpo3 = nullptr, *fpo2 = nullptr, *pcd = nullptr;
     float *hm = nullptr, *o12 = nullptr, *xs = nullptr, *posa_ws = nullptr;
     float *h2x = nullptr, *ctext = nullptr;   // bf16 modes: text half of the up-sampling (per call), see denoise_bf.hip
+    float* ct_time = nullptr;                 // bf16 modes: timestep half of combine_extraction's pre-activation, [kGroup][1024][128]
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -384,6 +390,58 @@ bool build_fp2_blob(lsdm_ctx* c, int np, DenseH* out) {
     return out->w && out->b;
 }
 
+// Fragment blob of denoise_reg.hip::denoise_r_kernel, fragments [nb][k-step s][plane][lane][8] per layer, layers back to back:
+//   S  = combination_extraction.0[:, 128:256] (6 x 8), pose_embedding.2 (4 x 4)           -- k-slot (s, h, j) = column 16 s + 8 h + j
+//   combination_extraction.0[:, 0:128] (6 x 8), combination_extraction.2 (4 x 12), pose_final.0 (2 x 8), pose_final.2 zero-padded
+//   to 32 rows (1 x 4)                                                                       -- accumulator order of the previous layer
+// biases (fp32): [cex0 192 | pose2 128 | cex2 128 | fin0 64 | combine_extraction.0 128 | pose_embedding.0 as (w0, w1, w2, b) x 64 | fin2 3 + pad]
+bool build_denoise_reg_blob(lsdm_ctx* c, int np, DenseH* out) {
+    std::vector<float> Wc0, Bc0, Wp2, Bp2, Wc2, Bc2, Wf0, Bf0, Wf2, Bf2, Wcomb, Bcomb, Wp0, Bp0;
+    if (!fold_dense(c, "input_process.combination_extraction.0.weight", "input_process.combination_extraction.0.bias", "", 192, 256, Wc0, Bc0) ||
+        !fold_dense(c, "input_process.pose_embedding.2.weight", "input_process.pose_embedding.2.bias", "", 128, 64, Wp2, Bp2) ||
+        !fold_dense(c, "input_process.combination_extraction.2.weight", "input_process.combination_extraction.2.bias", "", 128, 192, Wc2, Bc2) ||
+        !fold_dense(c, "output_process.pose_final.0.weight", "output_process.pose_final.0.bias", "", 64, 128, Wf0, Bf0) ||
+        !fold_dense(c, "output_process.pose_final.2.weight", "output_process.pose_final.2.bias", "", 3, 64, Wf2, Bf2) ||
+        !fold_dense(c, "combine_extraction.0.weight", "combine_extraction.0.bias", "", 128, 256, Wcomb, Bcomb) ||
+        !fold_dense(c, "input_process.pose_embedding.0.weight", "input_process.pose_embedding.0.bias", "", 64, 3, Wp0, Bp0))
+        return false;
+    Wf2.resize((size_t)32 * 64, 0.0f);
+    std::vector<uint16_t> blob;
+    // one layer: NB channel blocks x KS k-steps; W is (N, ldw) row-major, the layer reads columns col0 .. col0 + 16 KS - 1
+    auto layer = [&](const std::vector<float>& W, int ldw, int col0, int NB, int KS, bool first) {
+        for (int nb = 0; nb < NB; ++nb)
+            for (int s = 0; s < KS; ++s)
+                for (int pl = 0; pl < np; ++pl)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int n = nb * 32 + (lane & 31), h = lane >> 5;
+                            const int k = first ? 16 * s + 8 * h + j : 32 * (s / 2) + 8 * (2 * (s % 2) + j / 4) + 4 * h + j % 4;
+                            const float v = W[(size_t)n * ldw + col0 + k];
+                            const uint16_t hi = f2bf(v);
+                            blob.push_back(pl == 0 ? hi : f2bf(v - bf2f(hi)));
+                        }
+    };
+    layer(Wc0, 256, 128, 6, 8, true);
+    layer(Wp2, 64, 0, 4, 4, true);
+    layer(Wc0, 256, 0, 6, 8, false);
+    layer(Wc2, 192, 0, 4, 12, false);
+    layer(Wf0, 128, 0, 2, 8, false);
+    layer(Wf2, 64, 0, 1, 4, false);
+    std::vector<float> biases;
+    biases.insert(biases.end(), Bc0.begin(), Bc0.end());
+    biases.insert(biases.end(), Bp2.begin(), Bp2.end());
+    biases.insert(biases.end(), Bc2.begin(), Bc2.end());
+    biases.insert(biases.end(), Bf0.begin(), Bf0.end());
+    biases.insert(biases.end(), Bcomb.begin(), Bcomb.end());
+    for (int n = 0; n < 64; ++n) { biases.push_back(Wp0[n * 3]); biases.push_back(Wp0[n * 3 + 1]); biases.push_back(Wp0[n * 3 + 2]); biases.push_back(Bp0[n]); }
+    for (int n = 0; n < 3; ++n) biases.push_back(Bf2[n]);
+    biases.push_back(0.0f);
+    if (blob.size() % 2) blob.push_back(0);
+    out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
+    out->b = upload(c, biases.data(), biases.size());
+    return out->w && out->b;
+}
+
 // SA level: three layers; the kernels order the first layer's K as [features (D) || xyz - centroid (3) || 0], the
 // reference as [xyz - centroid (3) || features (D)]
 bool build_sa_reg_blob(lsdm_ctx* c, const std::string& prefix, int D, const int (&mlp)[3], int np, DenseH* out) {
@@ -579,6 +637,8 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         launch_cond(c->cond, t, text, given_cats, mask, B, g, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
         prof_mark(c, K_UP12, st);
         launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B * g, 0, f.h2p, st);
+        // per-sample timesteps: the timestep half of combine_extraction's pre-activation per (step, sample) row
+        if (np != 0 && c->den_reg && g == 1) launch_ctext(np, c->den_h, B, f.h2p, c->ct_time, true, st);
     } else if (!reuse_hm) {
         // per call: the sample rows (text / category embeddings, attention weights, translation tokens) of set 0
         launch_cond(c->cond, t, text, given_cats, mask, B, 1, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
@@ -588,7 +648,7 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         if (np != 0) {
             prof_mark(c, K_UP12, st);
             launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B, 128, c->h2x, st);
-            launch_ctext(np, c->den_h, B, c->h2x, c->ctext, st);
+            launch_ctext(np, c->den_h, B, c->h2x, c->ctext, false, st);
         }
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->posa_ws, c->hm, st);
@@ -600,6 +660,7 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         launch_cond_time(c->cond, t, B, g, f.e0, st);
         prof_mark(c, K_UP12, st);
         launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, g, 0, f.h2p, st);
+        launch_ctext(np, c->den_h, g, f.h2p, c->ct_time, true, st);
     }
     prof_mark(c, -1, st);
 }
@@ -628,9 +689,13 @@ void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, flo
     if (c->prec == LSDM_PREC_F32)
         launch_denoise(c->den, c->sched, mode, eta, B, x, t, mask, c->pcd, f.w, c->o12, c->hm, f.h2p, noise, out_x0, out_guiding,
                        out_sample, st);
+    else if (c->den_reg)
+        launch_denoise_r(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_r, c->den_h.pwt, c->sched, mode, eta, B, nsteps, shared ? 0 : 1, x, t, mask, c->pcd, f.w,
+                         c->o12, c->hm, c->ctext, shared && f.ctime ? f.ctime : c->ct_time, noise, c->s_stash, out_x0, out_guiding, out_sample,
+                         c->fps_slots / 16, st);
     else
         launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, nsteps, shared ? 0 : 1, x, t, mask, c->pcd, f.w, c->o12, c->hm,
-                         f.h2p, c->ctext, noise, out_x0, out_guiding, out_sample, st);
+                         f.h2p, c->ctext, shared ? (f.ctime ? f.ctime : c->ct_time) : nullptr, noise, out_x0, out_guiding, out_sample, st);
     prof_mark(c, -1, st);
 }
 
@@ -1009,6 +1074,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                 ok = c->den_h.fin2m.w != nullptr;
             }
         }
+        ok = ok && build_denoise_reg_blob(c, np, &c->den_r);
     }
     if (!ok) return c->err.empty() ? fail(c, LSDM_ERR_PARAM, "parameter upload failed") : LSDM_ERR_PARAM;
     c->finalized = true;
@@ -1090,7 +1156,9 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256)) && (c->sa_U[2] = ws_alloc<float>(c, "sa2_u", nc * 1024 * 64)) &&
          (c->sa_V[2] = ws_alloc<float>(c, "sa2_v", nc * 1024 * 64)) && (c->fp_ybuf[1] = ws_alloc<float>(c, "fp2_y", nc * 256 * 256)) &&
          (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256)) &&
-         (c->h2x = ws_alloc<float>(c, "h2x", (size_t)B * 128 * 512)) && (c->ctext = ws_alloc<float>(c, "ctext", (size_t)B * kN * 128));
+         (c->h2x = ws_alloc<float>(c, "h2x", (size_t)B * 128 * 512)) && (c->ctext = ws_alloc<float>(c, "ctext", (size_t)B * kN * 128)) &&
+         (c->ct_time = ws_alloc<float>(c, "ct_time", (size_t)(B > lsdm_ctx::kGroup ? B : lsdm_ctx::kGroup) * kN * 128)) &&
+         (c->s_stash = ws_alloc<float>(c, "s_stash", (size_t)B * (kN / 32) * 6 * 16 * 64));
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)

@@ -84,8 +84,13 @@ __device__ __forceinline__ void upsample_half_h(const DenoiseHParams& P, int n0,
 }
 
 // ---- once per call: the text half of combine_extraction's pre-activation, ctext (B, 1024, 128) fp32 -----------------------
+// kb0 = NE / 16: the text half (columns 128..255 of combine_extraction), one row of h2x per chain, once per call;
+// kb0 = 0: the TIMESTEP half (columns 0..127) for one row of h2 per STEP -- multi-step calls run every chain of the batch at the
+// same timestep, so W_comb[:, :128] . GELU(W4 . h2t + b4) is the same (1024, 128) tile for all of them: evaluated once per step
+// here instead of once per (chain, step) inside denoise_h_kernel (which runs the identical instruction sequence when the
+// timesteps differ per sample, so the two paths agree bit for bit).
 template <int NP>
-__global__ __launch_bounds__(NT) void ctext_kernel(DenoiseHParams P, const __bf16* __restrict__ h2x, float* __restrict__ ctext) {
+__global__ __launch_bounds__(NT) void ctext_kernel(DenoiseHParams P, const __bf16* __restrict__ h2x, float* __restrict__ ctext, int kb0) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (P0 + P1)];
     __bf16* R0 = smem;
     __bf16* R2 = R0 + NP * P0;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(NT) void ctext_kernel(DenoiseHParams P, const __bf1
     __syncthreads();
     f32x16 acc[1];
     acc_zero_h(acc);
-    mma_kloop_h<1, NP, true, NE / 16>(acc, R0, LD0, P0, P.comb.w, 128, wave, NE / 16, lane);   // columns 128..255 of combine_extraction
+    mma_kloop_h<1, NP, true, NE / 16>(acc, R0, LD0, P0, P.comb.w, 128, wave, kb0, lane);
     const int p = lane & 31, h = lane >> 5;
     float* dst = ctext + ((size_t)b * kPoints + n0 + p) * 128 + wave * 32 + 4 * h;
 #pragma unroll
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(NT, 2) void denoise_h_kernel(DenoiseHParams P0_, St
                                                        const float* __restrict__ pcd, const float* __restrict__ w,
                                                        const float* __restrict__ o12, const float* __restrict__ hm,
                                                        const __bf16* __restrict__ h2t, const float* __restrict__ ctext,
+                                                       const float* __restrict__ ctime,
                                                        const float* __restrict__ noise, float* __restrict__ out_x0,
                                                        float* __restrict__ out_guiding, float* __restrict__ out_sample) {
     __shared__ __attribute__((aligned(16))) __bf16 smem[NP * (P0 + 2 * P1 + P3)];
@@ -237,21 +243,33 @@ __global__ __launch_bounds__(NT, 2) void denoise_h_kernel(DenoiseHParams P0_, St
             xt[tid] = xv;
             if (!chain) x[gi] = xv;
         }
-        // ---- timestep half of e, then emb = GELU(W_comb[:, :128] . e_t + ctext + b) -> R1 ---------------------------------
-        upsample_half_h<NP>(P, n0, h2t + (size_t)(h2t_per_sample ? step * B + b : step) * 32 * NE * NP * 16, R0, R2);
+        // ---- emb = GELU(W_comb[:, :128] . e_t + (ctext + b)) -> R1.  ctime != NULL: the timestep product of this step comes from
+        // ctext_kernel(kb0 = 0) (one (1024, 128) tile per step, shared by the chains); otherwise it is evaluated here per sample
         const int p = lane & 31, h = lane >> 5;
         {
             f32x16 acc[1];
+            if (ctime) {
+                const float* cm = ctime + ((size_t)step * kPoints + n0 + p) * 128 + wave * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(cm + 8 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[0][4 * q + j] = v[j];
+                }
+            } else {
+                upsample_half_h<NP>(P, n0, h2t + (size_t)(h2t_per_sample ? step * B + b : step) * 32 * NE * NP * 16, R0, R2);
+                acc_zero_h(acc);
+                __syncthreads();
+                mma_kloop_h<1, NP, true, NE / 16>(acc, R0, LD0, P0, P.comb.w, 128, wave, 0, lane);
+            }
             const float* ct = ctext + ((size_t)b * kPoints + n0 + p) * 128 + wave * 32 + 4 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 cv = *reinterpret_cast<const f32x4*>(ct + 8 * q);
                 const f32x4 bv = gload<f32x4>(P.comb.b + wave * 32 + 8 * q + 4 * h);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0][4 * q + j] = cv[j] + bv[j];
+                for (int j = 0; j < 4; ++j) acc[0][4 * q + j] += cv[j] + bv[j];
             }
-            __syncthreads();
-            mma_kloop_h<1, NP, true, NE / 16>(acc, R0, LD0, P0, P.comb.w, 128, wave, 0, lane);
             store_lds_nb_h<ACT_GELU, NP>(acc[0], wave, R1, LD1, P1, lane);
         }
         __syncthreads();
@@ -307,22 +325,23 @@ __global__ __launch_bounds__(NT, 2) void denoise_h_kernel(DenoiseHParams P0_, St
     }
 }
 
-void launch_ctext(int np, const DenoiseHParams& P, int B, const void* h2x, float* ctext, hipStream_t st) {
+void launch_ctext(int np, const DenoiseHParams& P, int rows, const void* h2x, float* ctext, bool time_half, hipStream_t st) {
     const __bf16* h2 = static_cast<const __bf16*>(h2x);
-    if (np == 2) hipLaunchKernelGGL(ctext_kernel<2>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, h2, ctext);
-    else hipLaunchKernelGGL(ctext_kernel<1>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, h2, ctext);
+    const int kb0 = time_half ? 0 : NE / 16;
+    if (np == 2) hipLaunchKernelGGL(ctext_kernel<2>, dim3(kPoints / TM * rows), dim3(NT), 0, st, P, h2, ctext, kb0);
+    else hipLaunchKernelGGL(ctext_kernel<1>, dim3(kPoints / TM * rows), dim3(NT), 0, st, P, h2, ctext, kb0);
 }
 
 void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int h2t_per_sample, float* x, const int64_t* t,
                       const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
-                      const float* ctext, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
+                      const float* ctext, const float* ctime, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st) {
     const __bf16* h2 = static_cast<const __bf16*>(h2t);
     if (np == 2)
         hipLaunchKernelGGL(denoise_h_kernel<2>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, nsteps, h2t_per_sample, x, t, mask, pcd, w, o12, hm,
-                           h2, ctext, noise, out_x0, out_guiding, out_sample);
+                           h2, ctext, ctime, noise, out_x0, out_guiding, out_sample);
     else
         hipLaunchKernelGGL(denoise_h_kernel<1>, dim3(kPoints / TM * B), dim3(NT), 0, st, P, sc, mode, eta, B, nsteps, h2t_per_sample, x, t, mask, pcd, w, o12, hm,
-                           h2, ctext, noise, out_x0, out_guiding, out_sample);
+                           h2, ctext, ctime, noise, out_x0, out_guiding, out_sample);
 }
 
 }  // namespace lsdm

@@ -1,0 +1,455 @@
+// The x/t-dependent tail of a denoising step as a REGISTER-CHAINED stack on the split-bf16 MFMA core, gfx950.
+//
+// Same arithmetic contract as denoise_bf.hip (guidance g with the Q1/Q2 scrambles, in-place x += g, the per-point denoiser of
+// model/sdm.py:196-217 through InputProcess / OutputProcess of model/diffusion_utils.py:51-78,98-122, posterior / DDIM update of
+// gaussian_diffusion.py:258-280,545-561,790-811), different execution shape:
+//
+//   * denoise_h_kernel keeps a 32-point tile's activations in LDS and runs every layer as "fetch weights from L2 -> MFMAs -> epilogue
+//     to LDS -> work-group barrier": ten dependent phases of a few hundred cycles of matrix work each, two work-groups per CU --
+//     the kernel is latency-bound (MFMA pipe 18 % busy).
+//   * Here a WAVE owns 32 points of one chain and carries their activations through the whole stack in registers (the
+//     accumulator -> operand identity of encoder_reg.hip: in the transposed product D[channel][point] the accumulators 8 s2 .. 8 s2 + 7
+//     of channel block nb ARE the lane's k-slots of k-step 2 nb + s2 of the next layer; the host packs the weight fragments in that
+//     k order).  Weights go through LDS as PANELS of <= 48 KB shared by the 8 waves of the work-group (256 points per panel
+//     pass), double-buffered, copied global -> LDS by the LDS-DMA path while the waves work on the previous panel; one barrier
+//     per panel.  Per step: [S_a S_b | pose2 | cex0_a cex0_b | cex2_a cex2_b | fin0]; pose_final.2 (3 rows zero-padded to one
+//     channel block) stays resident.
+//   * The timestep half of combine_extraction's pre-activation comes from ctext_kernel(kb0 = 0) (`ctime`; one tile per step when
+//     all chains share the timestep, one per (step, chain) otherwise), the text half from `ctext`: emb = GELU(ctime + ctext + b) is
+//     formed straight into operand fragments.  S = W_cex0[:, 128:] . emb + b is shared by the two denoiser passes of a step's last
+//     forward; the first pass consumes its registers in place, so on the last step it is parked in a global scratch tile
+//     (24 KB per wave) and read back for the guiding-point pass.
+//   * nsteps consecutive steps run in one launch (hoisted-conditioning groups): x never leaves the wave's LDS slot between steps.
+#include "bf16_core.hpp"
+#include "kernels.hpp"
+
+namespace lsdm {
+
+namespace {
+
+constexpr int NW = 8, NT = NW * 64;
+
+template <int NP>
+struct RL {   // fragment (1 KiB = 512 bf16) offsets of the blob, see api.hip::build_denoise_reg_blob
+    static constexpr int S_KS = 8, S_NB = 6;      // combination_extraction.0[:, 128:256] (emb half), first-layer k order
+    static constexpr int P2_KS = 4, P2_NB = 4;    // pose_embedding.2 64 -> 128, first-layer k order
+    static constexpr int C0_KS = 8, C0_NB = 6;    // combination_extraction.0[:, 0:128] (pose half), accumulator k order
+    static constexpr int C2_KS = 12, C2_NB = 4;   // combination_extraction.2 192 -> 128
+    static constexpr int F0_KS = 8, F0_NB = 2;    // pose_final.0 128 -> 64
+    static constexpr int F2_KS = 4;               // pose_final.2 64 -> 3 (one zero-padded block)
+    static constexpr int OFF_S = 0;
+    static constexpr int OFF_P2 = OFF_S + S_NB * S_KS * NP;
+    static constexpr int OFF_C0 = OFF_P2 + P2_NB * P2_KS * NP;
+    static constexpr int OFF_C2 = OFF_C0 + C0_NB * C0_KS * NP;
+    static constexpr int OFF_F0 = OFF_C2 + C2_NB * C2_KS * NP;
+    static constexpr int OFF_F2 = OFF_F0 + F0_NB * F0_KS * NP;
+    static constexpr int TOTAL = OFF_F2 + F2_KS * NP;
+    static constexpr int PANEL = 24 * NP;         // largest panel
+    // panels of a step: (offset, fragments)
+    static constexpr int SA = OFF_S, SA_N = 24 * NP, SB = OFF_S + 24 * NP, SB_N = 24 * NP;
+    static constexpr int P2 = OFF_P2, P2_N = 16 * NP;
+    static constexpr int C0A = OFF_C0, C0B = OFF_C0 + 24 * NP, C0_N = 24 * NP;
+    static constexpr int C2A = OFF_C2, C2B = OFF_C2 + 24 * NP, C2_N = 24 * NP;
+    static constexpr int F0 = OFF_F0, F0_N = 16 * NP;
+};
+// bias block (floats), same order as the host builds it
+constexpr int B_CEX0 = 0, B_POSE2 = 192, B_CEX2 = 320, B_FIN0 = 448, B_COMB = 512, B_POSE0 = 640, B_FIN2 = 896, B_TOTAL = 900;
+
+__device__ __forceinline__ float scrambled_r(const float* __restrict__ pcd_b, const float* __restrict__ w_b, int op, int pp, int cp) {
+    const int f = (op * kPoints + pp) * 3 + cp;
+    const int j = f / kSlots, o = f - j * kSlots;
+    return pcd_b[o * (kPoints * 3) + j] * w_b[o];
+}
+
+// LDS traffic of ONE wave with itself (write by some lanes, read by others): in-order inside the wave, the compiler only has to
+// keep the program order
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NP>
+__device__ __forceinline__ bf16x8 wfrag(const __bf16* base, int KS, int nb, int s, int plane, int lane) {
+    return *reinterpret_cast<const bf16x8*>(base + ((size_t)((nb * KS + s) * NP + plane) * 64 + lane) * 8);
+}
+
+// acc += W(block nb of a panel whose first block sits at W) (x) X(registers); transposed product D[channel][point]
+template <int KS, int NP>
+__device__ __forceinline__ void mma_t(f32x16& acc, const __bf16* W, int nb, const bf16x8 (&xh)[KS], const bf16x8 (&xl)[KS], int lane) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 wh = wfrag<NP>(W, KS, nb, s, 0, lane);
+        if constexpr (NP == 2) {
+            const bf16x8 wlo = wfrag<NP>(W, KS, nb, s, 1, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh[s], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);
+        if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound the LDS weight fragments in flight (VGPRs)
+    }
+}
+
+__device__ __forceinline__ void acc_from_bias(f32x16& acc, const float* bias32, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * q + j] = bq[j];
+    }
+}
+
+// activation + split of a transposed block into the next layer's k-steps 2 nb, 2 nb + 1
+template <int ACT, int NP>
+__device__ __forceinline__ void act_split(const f32x16& acc, bf16x8& h0, bf16x8& l0, bf16x8& h1, bf16x8& l1) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = apply_act_fast<ACT>(acc[8 * s2 + j]);
+        if (s2 == 0) split8_h<NP>(v, h0, l0); else split8_h<NP>(v, h1, l1);
+    }
+}
+
+}  // namespace
+
+template <int NP>
+__global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, Lin pwt, StepCoefs sc,
+                                                       int mode, float eta, int B, int nsteps, int ctime_per_sample, float* __restrict__ x,
+                                                       const int64_t* __restrict__ t, const float* __restrict__ mask,
+                                                       const float* __restrict__ pcd, const float* __restrict__ w,
+                                                       const float* __restrict__ o12, const float* __restrict__ hm,
+                                                       const float* __restrict__ ctext, const float* __restrict__ ctime,
+                                                       const float* __restrict__ noise, float* __restrict__ stash,
+                                                       float* __restrict__ out_x0, float* __restrict__ out_guiding,
+                                                       float* __restrict__ out_sample) {
+    using L = RL<NP>;
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][L::PANEL * 512];
+    __shared__ __attribute__((aligned(16))) __bf16 wf2[L::F2_KS * NP * 512];
+    __shared__ __attribute__((aligned(16))) float bl[B_TOTAL + 4];
+    __shared__ float fsm[NW][4 * 96 + 32];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int p = lane & 31, h = lane >> 5;
+    for (int e = tid; e < L::F2_KS * NP * 64; e += NT)
+        *reinterpret_cast<bf16x8*>(wf2 + (size_t)e * 8) = gload<bf16x8>(blob_w + (size_t)L::OFF_F2 * 512 + (size_t)e * 8);
+    for (int e = tid; e < B_TOTAL; e += NT) bl[e] = blob_b[e];
+    float* zt = fsm[wave];            // mutated x of the wave's 32 points (x 3)
+    float* gt = zt + 96;              // guidance / guiding points
+    float* xs = gt + 96;              // current sample between steps
+    float* res = xs + 96;             // denoiser output
+    float* oterm = res + 96;          // W15[c, 3:15] . o[b, o', :]   (27 values)
+
+    // panel `off` (fragment index in the blob, `n` fragments) -> LDS buffer `buf`: each wave copies n / NW fragments
+    auto fetch = [&](int off, int n, int buf) {
+        const __bf16* src = opaque_ptr(blob_w) + (size_t)off * 512;
+        for (int i = wave; i < n; i += NW)
+            lds_dma16(src + (size_t)i * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[buf][(size_t)i * 512])));
+    };
+    fetch(L::SA, L::SA_N, 0);
+    lds_dma_wait();
+    __syncthreads();
+
+    const int total = B * (kPoints / 32);                       // 32-point blocks
+    const int rounds = (total + NW - 1) / NW;
+    const int rchunk = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int rbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
+    const int rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    const bool chain = out_sample == nullptr && mode != MODE_FORWARD;
+
+    for (int rd = rbeg; rd < rend; ++rd) {
+        const int blk_raw = rd * NW + wave;
+        const bool live = blk_raw < total;
+        const int blk = live ? blk_raw : total - 1;
+        const int b = blk / (kPoints / 32), n0 = (blk - b * (kPoints / 32)) * 32;
+        const float* pcd_b = pcd + (size_t)b * kSlots * kPoints * 3;
+        const float* w_b = w + (size_t)b * kSlots;
+        const size_t g0 = ((size_t)b * kPoints + n0) * 3;       // first element of the wave's (32, 3) tile
+        // ---- guidance g (fp32): depends on the scene conditioning only ----------------------------------------------------
+        if (lane < kSlots * 3) {
+            const int op = lane / 3, c = lane - op * 3;
+            float s = 0.0f;
+            for (int k = 0; k < 12; ++k) s = fmaf(o12[((size_t)b * kSlots + op) * 12 + k], pwt.w[c * 15 + 3 + k], s);
+            oterm[lane] = s;
+        }
+        wave_sync();
+#pragma unroll 1
+        for (int i = lane; i < 96; i += 64) {
+            const int row = i / 3, c = i - row * 3, n = n0 + row;
+            float acc = 0.0f;
+            for (int op = 0; op < kSlots; ++op) {
+                const float p0 = scrambled_r(pcd_b, w_b, op, n, 0), p1 = scrambled_r(pcd_b, w_b, op, n, 1), p2 = scrambled_r(pcd_b, w_b, op, n, 2);
+                float s = fmaf(p2, pwt.w[c * 15 + 2], fmaf(p1, pwt.w[c * 15 + 1], p0 * pwt.w[c * 15]));
+                s = gelu_fast(s + oterm[op * 3 + c] + pwt.b[c]);
+                // (N,-1,B,O) view: the multiplier of flat element f is mask.flatten()[f % (B*O)]  (Q2)
+                const long long f = (((long long)b * kSlots + op) * kPoints + n) * 3 + c;
+                acc += s * mask[f % ((long long)B * kSlots)];
+            }
+            gt[i] = (acc + hm[g0 + i]) / 2.0f;
+            xs[i] = x[g0 + i];
+        }
+        wave_sync();
+
+        // one denoiser pass on the (32, 3) tile zsrc (LDS) -> res; consumes S in place.  nxt_*: the panel to prefetch during fin0
+        auto pass = [&](const float* zsrc, f32x16 (&S)[6], int nxt_off, int nxt_n) {
+            int lz = 0;
+            // pose_embedding.0: 3 -> 64 sigmoid (K = 3: VALU) straight into the K = 64 operand: k-slot (s, h, j) = channel 16 s + 8 h + j
+            bf16x8 ah[4], al[4];
+            {
+                const float z0 = zsrc[p * 3], z1 = zsrc[p * 3 + 1], z2 = zsrc[p * 3 + 2];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x4 wb = *reinterpret_cast<const f32x4*>(bl + B_POSE0 + 4 * (16 * s + 8 * h + j));
+                        v[j] = sigmoid_fast(fmaf(z2, wb[2], fmaf(z1, wb[1], z0 * wb[0])) + wb[3]);
+                    }
+                    split8_h<NP>(v, ah[s], al[s]);
+                }
+            }
+            // ---- panel pose2 (buffer 0): 64 -> 128 sigmoid ---------------------------------------------------------------------
+            bf16x8 ph[8], pl[8];
+            fetch(L::C0A, L::C0_N, 1);
+            asm volatile("" : "+v"(lz));
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                f32x16 acc;
+                acc_from_bias(acc, bl + lz + B_POSE2 + 32 * nb, h);
+                mma_t<4, NP>(acc, &wl[0][0] + lz, nb, ah, al, lane);
+                act_split<ACT_SIGMOID, NP>(acc, ph[2 * nb], pl[2 * nb], ph[2 * nb + 1], pl[2 * nb + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_dma_wait();
+            __syncthreads();
+            // ---- panels cex0_a (buffer 1), cex0_b (buffer 0): [pose || emb] 256 -> 192 sigmoid; the emb half is S -------------------
+            bf16x8 ch[12], cl[12];
+            fetch(L::C0B, L::C0_N, 0);
+            asm volatile("" : "+v"(lz));
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                mma_t<8, NP>(S[nb], &wl[1][0] + lz, nb, ph, pl, lane);
+                act_split<ACT_SIGMOID, NP>(S[nb], ch[2 * nb], cl[2 * nb], ch[2 * nb + 1], cl[2 * nb + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_dma_wait();
+            __syncthreads();
+            fetch(L::C2A, L::C2_N, 1);
+            asm volatile("" : "+v"(lz));
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                mma_t<8, NP>(S[3 + nb], &wl[0][0] + lz, nb, ph, pl, lane);
+                act_split<ACT_SIGMOID, NP>(S[3 + nb], ch[6 + 2 * nb], cl[6 + 2 * nb], ch[7 + 2 * nb], cl[7 + 2 * nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_dma_wait();
+            __syncthreads();
+            // ---- panels cex2_a (buffer 1), cex2_b (buffer 0): 192 -> 128 sigmoid -----------------------------------------------------
+            bf16x8 dh[8], dl[8];
+            fetch(L::C2B, L::C2_N, 0);
+            asm volatile("" : "+v"(lz));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 acc;
+                acc_from_bias(acc, bl + lz + B_CEX2 + 32 * nb, h);
+                mma_t<12, NP>(acc, &wl[1][0] + lz, nb, ch, cl, lane);
+                act_split<ACT_SIGMOID, NP>(acc, dh[2 * nb], dl[2 * nb], dh[2 * nb + 1], dl[2 * nb + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_dma_wait();
+            __syncthreads();
+            fetch(L::F0, L::F0_N, 1);
+            asm volatile("" : "+v"(lz));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 acc;
+                acc_from_bias(acc, bl + lz + B_CEX2 + 64 + 32 * nb, h);
+                mma_t<12, NP>(acc, &wl[0][0] + lz, nb, ch, cl, lane);
+                act_split<ACT_SIGMOID, NP>(acc, dh[4 + 2 * nb], dl[4 + 2 * nb], dh[5 + 2 * nb], dl[5 + 2 * nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_dma_wait();
+            __syncthreads();
+            // ---- panel fin0 (buffer 1): 128 -> 64 GELU; then pose_final.2 (resident): 64 -> 3 GELU, direct orientation ---------------
+            bf16x8 fh[4], fl[4];
+            if (nxt_n > 0) fetch(nxt_off, nxt_n, 0);
+            asm volatile("" : "+v"(lz));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 acc;
+                acc_from_bias(acc, bl + lz + B_FIN0 + 32 * nb, h);
+                mma_t<8, NP>(acc, &wl[1][0] + lz, nb, dh, dl, lane);
+                act_split<ACT_GELU, NP>(acc, fh[2 * nb], fl[2 * nb], fh[2 * nb + 1], fl[2 * nb + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 wh = wfrag<NP>(wf2 + lz, 4, 0, s, 0, lane);
+                    if constexpr (NP == 2) {
+                        const bf16x8 wlo = wfrag<NP>(wf2 + lz, 4, 0, s, 1, lane);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s], wh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s], wlo, acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s], wh, acc, 0, 0, 0);
+                }
+                const int c = lane & 31;
+                if (c < 3) {
+                    const float bv = bl[lz + B_FIN2 + c];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[acc_row(r, lane) * 3 + c] = gelu_fast(acc[r] + bv);
+                }
+            }
+            lds_dma_wait();
+            __syncthreads();
+        };
+
+#pragma unroll 1
+        for (int step = 0; step < nsteps; ++step) {
+            const bool last = step == nsteps - 1;
+            // in-place update of x (Q5); the caller's tensor sees it when the launch is a single step
+#pragma unroll 1
+            for (int i = lane; i < 96; i += 64) {
+                const float xv = xs[i] + gt[i];
+                zt[i] = xv;
+                if (!chain && live) x[g0 + i] = xv;
+            }
+            wave_sync();
+            // ---- emb = GELU(ctime + (ctext + b)) -> K = 128 operand: k-slot (s, h, j) = channel 16 s + 8 h + j ----------------------
+            bf16x8 eh[8], el[8];
+            {
+                const float* cm = opaque_ptr(ctime) + ((size_t)(ctime_per_sample ? step * B + b : step) * kPoints + n0 + p) * 128 + 8 * h;
+                const float* ct = opaque_ptr(ctext) + ((size_t)b * kPoints + n0 + p) * 128 + 8 * h;
+                int lz = 0;
+                asm volatile("" : "+v"(lz));
+#pragma unroll
+                for (int s0 = 0; s0 < 8; s0 += 4) {
+                    f32x4 a[4][2], c[4][2];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            a[s][q] = gload<f32x4>(cm + 16 * (s0 + s) + 4 * q);
+                            c[s][q] = gload<f32x4>(ct + 16 * (s0 + s) + 4 * q);
+                        }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + lz + B_COMB + 16 * (s0 + s) + 8 * h + 4 * q);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[4 * q + j] = gelu_fast(a[s][q][j] + (c[s][q][j] + bq[j]));
+                        }
+                        split8_h<NP>(v, eh[s0 + s], el[s0 + s]);
+                    }
+                }
+            }
+            // ---- panels S_a (buffer 0), S_b (buffer 1): S = W_cex0[:, 128:] . emb + b -------------------------------------------------
+            f32x16 S[6];
+            {
+                int lz = 0;
+                fetch(L::SB, L::SB_N, 1);
+                asm volatile("" : "+v"(lz));
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) {
+                    acc_from_bias(S[nb], bl + lz + B_CEX0 + 32 * nb, h);
+                    mma_t<8, NP>(S[nb], &wl[0][0] + lz, nb, eh, el, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                lds_dma_wait();
+                __syncthreads();
+                fetch(L::P2, L::P2_N, 0);
+                asm volatile("" : "+v"(lz));
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) {
+                    acc_from_bias(S[3 + nb], bl + lz + B_CEX0 + 96 + 32 * nb, h);
+                    mma_t<8, NP>(S[3 + nb], &wl[1][0] + lz, nb, eh, el, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                lds_dma_wait();
+                __syncthreads();
+            }
+            float* sst = stash + (size_t)blk * (6 * 16 * 64);
+            if (last) {
+                // park S for the guiding-point pass (lane-linear 16-byte pieces: 1 KiB per instruction)
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {S[nb][4 * q], S[nb][4 * q + 1], S[nb][4 * q + 2], S[nb][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(sst + ((size_t)(nb * 4 + q) * 64 + lane) * 4) = v;
+                    }
+            }
+            // ---- denoiser on the mutated x + sampler update -----------------------------------------------------------------------
+            {
+                const bool more = rd + 1 < rend;
+                const int nxt_off = last ? L::P2 : L::SA;
+                const int nxt_n = last ? L::P2_N : L::SA_N;
+                (void)more;
+                pass(zt, S, nxt_off, nxt_n);
+            }
+            wave_sync();
+#pragma unroll 1
+            for (int i = lane; i < 96; i += 64) {
+                const float x0 = res[i];
+                if (last && live) out_x0[g0 + i] = x0;
+                if (mode != MODE_FORWARD) {
+                    const int tb = (int)t[(size_t)step * B + b];
+                    const float xm = zt[i], nz = tb != 0 ? 1.0f : 0.0f;
+                    const float nv = noise ? noise[(size_t)step * B * kPoints * 3 + g0 + i] : 0.0f;
+                    float smp;
+                    if (mode == MODE_P_SAMPLE) {
+                        const float mean = __fadd_rn(__fmul_rn(sc.coef1[tb], x0), __fmul_rn(sc.coef2[tb], xm));
+                        const float sig = expf(__fmul_rn(0.5f, sc.logvar[tb]));
+                        smp = __fadd_rn(mean, __fmul_rn(__fmul_rn(nz, sig), nv));
+                    } else {
+                        const float ab = sc.acp[tb], abp = sc.acp_prev[tb];
+                        const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(sc.sr_acp[tb], xm), x0), sc.srm1_acp[tb]);
+                        const float sigma = eta * sqrtf(__fdiv_rn(1.0f - abp, 1.0f - ab)) * sqrtf(1.0f - __fdiv_rn(ab, abp));
+                        const float mp = __fadd_rn(__fmul_rn(x0, sqrtf(abp)), __fmul_rn(sqrtf(1.0f - abp - sigma * sigma), eps));
+                        smp = __fadd_rn(mp, __fmul_rn(__fmul_rn(nz, sigma), nv));
+                    }
+                    xs[i] = smp;
+                    if (last && live) (chain ? x : out_sample)[g0 + i] = smp;
+                }
+            }
+            wave_sync();
+            // ---- denoiser on the guiding points (saved_guiding_points, Q12): defined by the last forward ----------------------------
+            if (last) {
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = gload<f32x4>(sst + ((size_t)(nb * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) S[nb][4 * q + j] = v[j];
+                    }
+                const bool more = rd + 1 < rend;
+                pass(gt, S, L::SA, more ? L::SA_N : 0);
+                wave_sync();
+#pragma unroll 1
+                for (int i = lane; i < 96; i += 64)
+                    if (live) out_guiding[g0 + i] = res[i];
+                wave_sync();
+            }
+        }
+    }
+}
+
+void launch_denoise_r(int np, const DenseH& blob, const Lin& pwt, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int ctime_per_sample,
+                      float* x, const int64_t* t, const float* mask, const float* pcd, const float* w, const float* o12, const float* hm,
+                      const float* ctext, const float* ctime, const float* noise, float* stash, float* out_x0, float* out_guiding,
+                      float* out_sample, int num_cus, hipStream_t st) {
+    const int rounds = (B * (kPoints / 32) + NW - 1) / NW;
+    const int grid = rounds < num_cus ? rounds : num_cus;
+    if (np == 2)
+        hipLaunchKernelGGL(denoise_r_kernel<2>, dim3(grid), dim3(NT), 0, st, blob.w, blob.b, pwt, sc, mode, eta, B, nsteps, ctime_per_sample, x, t, mask, pcd,
+                           w, o12, hm, ctext, ctime, noise, stash, out_x0, out_guiding, out_sample);
+    else
+        hipLaunchKernelGGL(denoise_r_kernel<1>, dim3(grid), dim3(NT), 0, st, blob.w, blob.b, pwt, sc, mode, eta, B, nsteps, ctime_per_sample, x, t, mask, pcd,
+                           w, o12, hm, ctext, ctime, noise, stash, out_x0, out_guiding, out_sample);
+}
+
+}  // namespace lsdm

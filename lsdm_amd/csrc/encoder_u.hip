@@ -488,6 +488,185 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// sa_x_kernel: the WIDE level (sa4: 256 -> 256 -> 512 on ReLU(U_j - V_i)) with the contraction split across a PAIR of waves.
+//
+// sa_h_kernel keeps a 64-row tile in LDS and every work-group streams all 768 KB of layer-2/3 fragments from L2 for those
+// 64 rows: 3.5 GB per step at B = 64 -- the L2, not the matrix pipe, sets its pace.  Registers cannot hold a 256-wide operand
+// for two chained layers (128 + 128 VGPRs per 32 rows), so here TWO waves share a centroid's 32 rows: wave (rb, kh) carries
+// channels 128 kh .. 128 kh + 127 of the layer operand (64 VGPRs) and contracts every channel block over ITS half of K; the
+// partial 32 x 32 block goes to the wave that owns the block through a 4 KB LDS slot, and the owner finishes it one panel step
+// later (sum, bias, ReLU, hi/lo split into its own K-half of the next layer; for the last layer max over the 32 rows) -- next to
+// the MFMAs of the following panel.  A work-group = 4 centroids x 2 halves = 128 rows per pass over the weights: 24 panels of
+// 32 KB (one channel block x all of K; the two halves read disjoint k-steps of it), staged global -> registers -> LDS two panel
+// steps ahead, one barrier per panel (it also orders the exchange slots).  Weight traffic 6 KB per row instead of 12 KB.
+// blob: build_chain_blob({conv1 256 x 256, conv2 512 x 256}, identity first map): [nb][s = 0..15][plane][lane][8]; biases [256|512].
+template <int NP>
+__global__ __launch_bounds__(512, 2) void sa_x_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                       const int* __restrict__ cent_idx, const int* __restrict__ ball,
+                                                       long long total_centroids, const __bf16* __restrict__ blob_w,
+                                                       const float* __restrict__ blob_b, float* __restrict__ out) {
+    constexpr int C1 = 256, C2 = 256, C3 = 512, NSRC = 64, S = 16, NW = 8, NT = NW * 64;
+    constexpr int KSH = C1 / 32;                              // k-steps of one K-half
+    constexpr int NB2 = C2 / 32, NB3 = C3 / 32, NPANEL = NB2 + NB3;
+    constexpr int FP = 2 * KSH * NP;                          // fragments (1 KiB) per panel
+    constexpr int PIECES = FP * 64 / NT;
+    static_assert(C1 == C2 && NPANEL % 2 == 0 && (FP * 64) % NT == 0, "panel split");
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FP * 512];
+    __shared__ __attribute__((aligned(16))) float exch[2][4][16 * 64];
+    __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), rb = wave & 3, kh = wave >> 2;
+    for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
+    const int p = lane & 31, h = lane >> 5;
+
+    bf16x8 stage[2][PIECES];
+    auto fetch = [&](int q) {
+        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FP * 512);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) stage[q & 1][i] = gload<bf16x8>(src + (size_t)(tid + i * NT) * 8);
+    };
+    auto commit = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) *reinterpret_cast<bf16x8*>(&wl[q & 1][(size_t)(tid + i * NT) * 8]) = stage[q & 1][i];
+    };
+    fetch(0);
+    commit(0);
+    fetch(1);
+    __syncthreads();
+
+    const long long rounds = total_centroids / 4;
+    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
+    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
+    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    f32x16 acc[2];                    // panel q accumulates in acc[q & 1]; the owner finishes it during panel q + 1
+    long long cent_prev = -1;         // centroid whose last block (panel NPANEL - 1) is still to be finished
+    bf16x8 xh[KSH], xl[KSH], zh[KSH], zl[KSH];
+
+    // the owner's part of panel `Q` (Q < NB2: layer 2 -> fragments of z; else layer 3 -> max over the rows -> out)
+    auto exch_write = [&](int par, const f32x16& a) {
+        float* dst = &exch[par][rb][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst + (i * 64 + lane) * 4) = f32x4{a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+    };
+    auto exch_add = [&](int par, f32x16& a) {
+        const float* src = &exch[par][rb][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[4 * i + j] += v[j];
+        }
+    };
+
+#define SAX_FINISH(Q, CENT)                                                                                                  \
+    {                                                                                                                        \
+        constexpr int own_ = (Q) < NB2 ? (Q) / (NB2 / 2) : ((Q) - NB2) & 1;                                                  \
+        if (kh == own_) {                                                                                                    \
+            exch_add((Q) & 1, acc[(Q) & 1]);                                                                                 \
+            if constexpr ((Q) < NB2) {                                                                                       \
+                constexpr int nbl_ = (Q) % (NB2 / 2);                                                                        \
+                _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                           \
+                    float v[8];                                                                                              \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = reluf(acc[(Q) & 1][8 * s2 + j]);                    \
+                    split8u<NP>(v, zh[2 * nbl_ + s2], zl[2 * nbl_ + s2]);                                                    \
+                }                                                                                                            \
+            } else {                                                                                                         \
+                float m = acc[(Q) & 1][0];                                                                                   \
+                _Pragma("unroll") for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[(Q) & 1][r]);                                \
+                m = fmaxf(m, __shfl_xor(m, 32));                                                                             \
+                if (lane < 32) out[(size_t)(CENT) * C3 + ((Q) - NB2) * 32 + lane] = reluf(m + bl[C2 + ((Q) - NB2) * 32 + lane]); \
+            }                                                                                                                \
+        }                                                                                                                    \
+    }
+    // panel step Q: request panel Q + 2; this wave's half of the contraction; finish the previous panel if owned; hand the
+    // partial to the owner if not; publish panel Q + 1
+#define SAX_STEP(Q)                                                                                                          \
+    {                                                                                                                        \
+        fetch(((Q) + 2) % NPANEL);                                                                                           \
+        const __bf16* W = &wl[(Q) & 1][0] + (size_t)kh * KSH * NP * 512;                                                     \
+        constexpr int own_ = (Q) < NB2 ? (Q) / (NB2 / 2) : ((Q) - NB2) & 1;                                                  \
+        if ((Q) < NB2 && kh == own_) {                                                                                       \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                               \
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 32 * (Q) + 8 * q4 + 4 * h);                            \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(Q) & 1][4 * q4 + j] = bq[j];                              \
+            }                                                                                                                \
+        } else {                                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[(Q) & 1][r] = 0.0f;                                           \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < KSH; ++s) {                                                                    \
+            const bf16x8 wh = wfrag_lds_u<NP>(W, KSH, 0, s, 0, lane);                                                        \
+            const bf16x8 wlo = wfrag_lds_u<NP>(W, KSH, 0, s, 1, lane);                                                       \
+            if constexpr ((Q) < NB2) {                                                                                       \
+                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc[(Q) & 1], 0, 0, 0);                    \
+                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh[s], acc[(Q) & 1], 0, 0, 0);                   \
+                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc[(Q) & 1], 0, 0, 0);                    \
+            } else {                                                                                                         \
+                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], wh, acc[(Q) & 1], 0, 0, 0);                    \
+                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wlo, acc[(Q) & 1], 0, 0, 0);                   \
+                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wh, acc[(Q) & 1], 0, 0, 0);                    \
+            }                                                                                                                \
+            if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                                    \
+        if (kh != own_) exch_write((Q) & 1, acc[(Q) & 1]);                                                                   \
+        commit(((Q) + 1) % NPANEL);                                                                                          \
+        __syncthreads();                                                                                                     \
+    }
+    for (long long rd = rbeg; rd < rend; ++rd) {
+        const long long cent = rd * 4 + rb;
+        const long long c = cent / S;
+        {
+            const int idx = ball[cent * kNSample + p];
+            const int ci = cent_idx[cent];
+            const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 128 * kh + 8 * h;
+            const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 128 * kh + 8 * h;
+            f32x4 u0[KSH], u1[KSH], v0[KSH], v1[KSH];
+#pragma unroll
+            for (int s = 0; s < KSH; ++s) {
+                u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
+                v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
+            }
+#pragma unroll
+            for (int s = 0; s < KSH; ++s) {
+                const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
+                                    reluf(u1[s][0] - v1[s][0]), reluf(u1[s][1] - v1[s][1]), reluf(u1[s][2] - v1[s][2]), reluf(u1[s][3] - v1[s][3])};
+                split8u<NP>(t, xh[s], xl[s]);
+            }
+        }
+        // panel 0 of this round next to the finish of the previous round's last panel
+        SAX_STEP(0)
+        if (cent_prev >= 0) SAX_FINISH(NPANEL - 1, cent_prev)
+        SAX_STEP(1) SAX_FINISH(0, cent)
+        SAX_STEP(2) SAX_FINISH(1, cent)
+        SAX_STEP(3) SAX_FINISH(2, cent)
+        SAX_STEP(4) SAX_FINISH(3, cent)
+        SAX_STEP(5) SAX_FINISH(4, cent)
+        SAX_STEP(6) SAX_FINISH(5, cent)
+        SAX_STEP(7) SAX_FINISH(6, cent)
+        SAX_FINISH(7, cent)            // (layer boundary: the last fragments of z before the first panel of layer 3)
+        SAX_STEP(8)
+        SAX_STEP(9) SAX_FINISH(8, cent)
+        SAX_STEP(10) SAX_FINISH(9, cent)
+        SAX_STEP(11) SAX_FINISH(10, cent)
+        SAX_STEP(12) SAX_FINISH(11, cent)
+        SAX_STEP(13) SAX_FINISH(12, cent)
+        SAX_STEP(14) SAX_FINISH(13, cent)
+        SAX_STEP(15) SAX_FINISH(14, cent)
+        SAX_STEP(16) SAX_FINISH(15, cent)
+        SAX_STEP(17) SAX_FINISH(16, cent)
+        SAX_STEP(18) SAX_FINISH(17, cent)
+        SAX_STEP(19) SAX_FINISH(18, cent)
+        SAX_STEP(20) SAX_FINISH(19, cent)
+        SAX_STEP(21) SAX_FINISH(20, cent)
+        SAX_STEP(22) SAX_FINISH(21, cent)
+        SAX_STEP(23) SAX_FINISH(22, cent)
+        cent_prev = cent;
+    }
+    if (cent_prev >= 0) SAX_FINISH(NPANEL - 1, cent_prev)
+#undef SAX_STEP
+#undef SAX_FINISH
+}
+
+// ---------------------------------------------------------------------------------------------
 // FP stage with the interpolated operand PRE-MULTIPLIED at the coarse level (fp2, fp3).  The first FP layer is linear in
 // [p1 || sum_j w_j p2_j] (pointnet2_utils.py:299-312), so with W = [Wa | Wb]:  W x [...] + b = Wa x p1 + sum_j w_j (Wb x p2_j) + b.
 // Y = p2 x Wb^T is evaluated once per COARSE point (lin_u_kernel<.., XYZ = false>, S = N/4 rows); here the three Y rows of a
@@ -637,7 +816,9 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
 
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
-    if (level == 1) {
+    if (level == 3) {
+        hipLaunchKernelGGL((sa_x_kernel<2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
+    } else if (level == 1) {
         const long long tot = (long long)nc * 256;
         hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out);
     } else if (level == 2) {

@@ -142,11 +142,20 @@ void launch_nn_dist(const float* A, int na, const float* B, int nb, int batch, f
 // denoise_bf.hip
 // ctext (B,1024,128) fp32: the text half of combine_extraction's pre-activation, once per call (h2x: text half of the
 // second up-sampling activation, one row per sample)
-void launch_ctext(int np, const DenoiseHParams& P, int B, const void* h2x, float* ctext, hipStream_t st);
+// time_half: the same product for the TIMESTEP half, one row of h2 per step (multi-step calls, all chains at the same timestep):
+// (rows,1024,128) fp32 consumed by denoise_h_kernel through `ctime`
+void launch_ctext(int np, const DenoiseHParams& P, int rows, const void* h2x, float* ctext, bool time_half, hipStream_t st);
 // nsteps consecutive steps in one launch (t / noise hold nsteps rows; out_sample == NULL in a sampling mode: the final sample goes
 // to x).  h2t rows: one per (step, sample) when h2t_per_sample, one per step otherwise (all chains at the same timestep)
 void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int h2t_per_sample, float* x, const int64_t* t,
                       const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
-                      const float* ctext, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
+                      const float* ctext, const float* ctime, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
+
+// denoise_reg.hip: the same step as launch_denoise_h with the per-point denoiser register-chained (blob: api.hip::build_denoise_reg_blob);
+// ctime: (rows,1024,128) from launch_ctext(time_half), row = step (ctime_per_sample = 0) or step * B + sample; stash: B * 32 tiles of 24 KB
+void launch_denoise_r(int np, const DenseH& blob, const Lin& pwt, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int ctime_per_sample,
+                      float* x, const int64_t* t, const float* mask, const float* pcd, const float* w, const float* o12, const float* hm,
+                      const float* ctext, const float* ctime, const float* noise, float* stash, float* out_x0, float* out_guiding,
+                      float* out_sample, int num_cus, hipStream_t st);
 
 }  // namespace lsdm
