@@ -54,6 +54,7 @@ struct lsdm_ctx {
     DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
     DenseH fp1_s{}, fp2_s{};     // fp1 + head / fp2 as register-chained blobs (encoder_reg.hip::fp_s_kernel, fp_ps_kernel)
     int fp2_reg = getenv("LSDM_FP2_REG") ? atoi(getenv("LSDM_FP2_REG")) : 0;   // A/B switch (measured: 317 us vs 287 us for fp_pre_kernel)
+    int sa4_x = getenv("LSDM_SA4_X") ? atoi(getenv("LSDM_SA4_X")) : 2;         // A/B switch: sa4 on 0 sa_h (LDS-tiled), 1 sa_x (K-split wave pairs), 2 sa_w (one wave per SIMD, 512 registers)
     int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
     DenseH den_r{};              // the per-point denoiser as a register-chained blob (denoise_reg.hip)
     int den_reg = getenv("LSDM_DEN_REG") ? atoi(getenv("LSDM_DEN_REG")) : 1;   // A/B switch: 0 = the LDS-tiled denoise_h_kernel
@@ -587,7 +588,8 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
             launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-            launch_sa_h_pre(nc, c->sa_U[1], c->sa_V[1], f.idx[3], lvl_xyz[4], f.ball[3], c->sa_h[3], c->feat[3], st);
+            if (c->sa4_x) launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
+            else launch_sa_h_pre(nc, c->sa_U[1], c->sa_V[1], f.idx[3], lvl_xyz[4], f.ball[3], c->sa_h[3], c->feat[3], st);
         } else if (l < c->sa_reg)
             launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
         else
@@ -962,6 +964,13 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                 c->sa_uw[1].b = upload(c, B4.data(), B4.size());
                 c->sa_wx[1] = upload(c, wx.data(), wx.size());
                 ok = c->sa_uw[1].w && c->sa_uw[1].b && c->sa_wx[1];
+                // the same two layers as a fragment blob for the K-split wave-pair kernel (encoder_u.hip::sa_x_kernel, A/B)
+                const std::string p4 = "pcd_backbone.sa4";
+                std::vector<ChainLayer> layers = {{p4 + ".mlp_convs.1.weight", p4 + ".mlp_convs.1.bias", p4 + ".mlp_bns.1", 256, 256},
+                                                  {p4 + ".mlp_convs.2.weight", p4 + ".mlp_convs.2.bias", p4 + ".mlp_bns.2", 512, 256}};
+                std::vector<int> ident(256);
+                for (int k = 0; k < 256; ++k) ident[k] = k;
+                ok = ok && build_chain_blob(c, layers, ident, np, &c->sa_ub[1]);
             }
         }
     }

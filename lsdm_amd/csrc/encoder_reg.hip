@@ -337,6 +337,34 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
     }
 }
 
+// Measurement hooks of tools/ubench/chain_bench.hip (never defined in the library build): drop one cost at a time from fp_s_kernel
+//   LSDM_X_NOLDS  weight fragments come from a register instead of LDS      LSDM_X_NOMFMA  no matrix instructions
+//   LSDM_X_NOEPI  no ReLU + hi/lo split between the layers                  LSDM_X_NOBAR   no barrier / panel wait per layer
+#ifdef LSDM_X_NOLDS
+#define XWFRAG(W, KS, NBI, s, pl, lane) xfrag_const
+#else
+#define XWFRAG(W, KS, NBI, s, pl, lane) wfrag_lds<NP>(W, KS, NBI, s, pl, lane)
+#endif
+#ifdef LSDM_X_NOMFMA
+#define XMFMA(a, b, c) xfake_mfma(a, b, c)
+__device__ __forceinline__ f32x16 xfake_mfma(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+}
+#else
+#define XMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+#ifdef LSDM_X_NOBAR
+#define XBARRIER
+#else
+#define XBARRIER lds_dma_wait(); __syncthreads();
+#endif
+#ifdef LSDM_X_NOEPI
+#define XSPLIT(v, oh, ol) { oh[0] = (__bf16)v[0]; ol[0] = (__bf16)v[7]; }
+#else
+#define XSPLIT(v, oh, ol) split8<NP>(v, oh, ol)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // fp1 + head as a register-chained stack (bf16x3): interpolation of the three nearest level-1 rows (pointnet2_utils.py:286-297)
 // -> 3 x (conv 128 -> 128 + BN + ReLU) -> conv1 + bn1 + ReLU -> conv2 (128 -> 3)   (pointnet2.py:72-80).
@@ -350,29 +378,38 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
 // the gather latency of every round).  conv2's padded block stays resident.  Weight traffic per point: 1 KB instead of 5 KB.
 // blob: four layers [nb][s][plane][lane][8] (layer 1 in channel order, later layers in accumulator order) + conv2 zero-padded
 // to 32 channels; biases [4 x 128 | 32].
-template <int NW, int NP>
+template <int NW, int NP, int PH = 1>
 __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, long long total_points,
                                                         const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
                                                         float* __restrict__ out, int dbg) {
     constexpr int C = 128, NT = NW * 64, KS = C / 16, NB = C / 32, F = KS * NP;
-    constexpr int NL = 4, FL = NB * F;                       // fragments (1 KiB) per layer panel
-    static_assert(FL % NW == 0, "panel split");
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FL * 512];
-    __shared__ __attribute__((aligned(16))) __bf16 w5[F * 512];
+    constexpr int NL = 4, FL = NB * F;                       // fragments (1 KiB) per layer
+    constexpr int FPN = FL / PH, NBP = NB / PH;              // PH panels per layer: fragments / channel blocks per panel
+    static_assert(FPN % NW == 0 && NB % PH == 0 && (NL * PH) % 2 == 0, "panel split");
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FPN * 512];
+    // conv2's padded block: resident in LDS, or (PH > 1: two work-groups share a CU's LDS) read from global memory through the L1
+    __shared__ __attribute__((aligned(16))) __bf16 w5[PH == 1 ? F * 512 : 8];
     __shared__ __attribute__((aligned(16))) float bl[NL * C + 32];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    for (int e = tid; e < F * 64; e += NT) *reinterpret_cast<bf16x8*>(w5 + (size_t)e * 8) = gload<bf16x8>(blob_w + (size_t)NL * FL * 512 + (size_t)e * 8);
+    if constexpr (PH == 1)
+        for (int e = tid; e < F * 64; e += NT) *reinterpret_cast<bf16x8*>(w5 + (size_t)e * 8) = gload<bf16x8>(blob_w + (size_t)NL * FL * 512 + (size_t)e * 8);
+    const __bf16* w5g = blob_w + (size_t)NL * FL * 512;
     for (int e = tid; e < NL * C + 32; e += NT) bl[e] = blob_b[e];
     const int p = lane & 31, h = lane >> 5;
+#ifdef LSDM_X_NOLDS
+    bf16x8 xfrag_const = gload<bf16x8>(blob_w + lane * 8);
+    asm volatile("" : "+v"(xfrag_const));
+#endif
 
-    // layer L's panel -> LDS buffer L & 1: each wave copies FL / NW fragments, a fragment = one 1 KiB wave-wide LDS-DMA
-    auto fetch = [&](int L) {
-        const __bf16* src = opaque_ptr(blob_w + (size_t)L * FL * 512);   // (round-invariant: keep the copy inside the loop)
+    // panel q (PH per layer, channel-block major) -> LDS buffer q & 1: each wave copies FPN / NW fragments, a fragment = one 1 KiB
+    // wave-wide LDS-DMA
+    auto fetch = [&](int q) {
+        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FPN * 512);   // (round-invariant: keep the copy inside the loop)
 #pragma unroll
-        for (int i = 0; i < FL / NW; ++i) {
+        for (int i = 0; i < FPN / NW; ++i) {
             const int fr = wave + i * NW;
-            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[L & 1][(size_t)fr * 512])));
+            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
         }
     };
     fetch(0);
@@ -434,7 +471,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
         }
         // one channel block of a layer: accumulators start from the bias, MFMAs against the resident panel, ReLU + split into the
         // next layer's two k-step fragments
-#define FP_BLOCK(L, NBI, XH, XL, OH, OL)                                                                                     \
+#define FP_BLOCK(L, NBI, XH, XL, OH, OL)   /* channel block NBI of layer L, read from the panel that holds it */                                                                                     \
     {                                                                                                                        \
         f32x16 acc;                                                                                                          \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                      \
@@ -442,40 +479,47 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
             _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[4 * q + j] = bq[j];                                            \
         }                                                                                                                    \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                     \
-            const bf16x8 wh = wfrag_lds<NP>(W, KS, (NBI), s, 0, lane);                                                       \
+            const bf16x8 wh = XWFRAG(W, KS, (NBI) % NBP, s, 0, lane);                                                              \
             if constexpr (NP == 2) {                                                                                         \
-                const bf16x8 wlo = wfrag_lds<NP>(W, KS, (NBI), s, 1, lane);                                                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, XL[s], acc, 0, 0, 0);                                      \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, XH[s], acc, 0, 0, 0);                                     \
+                const bf16x8 wlo = XWFRAG(W, KS, (NBI) % NBP, s, 1, lane);                                                         \
+                acc = XMFMA(wh, XL[s], acc);                                                                                 \
+                acc = XMFMA(wlo, XH[s], acc);                                                                                \
             }                                                                                                                \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, XH[s], acc, 0, 0, 0);                                          \
+            acc = XMFMA(wh, XH[s], acc);                                                                                     \
             if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                                    \
         _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                                   \
             float v[8];                                                                                                      \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);                                     \
-            split8<NP>(v, OH[2 * (NBI) + s2], OL[2 * (NBI) + s2]);                                                           \
+            XSPLIT(v, OH[2 * (NBI) + s2], OL[2 * (NBI) + s2]);                                                               \
         }                                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
     }
         // a layer: start the copy of the next layer's panel (its buffer was last read one barrier ago), four channel blocks from
         // this layer's panel, then wait for the own copies and the barrier that publishes the panel
-#define FP_LAYER(L, XH, XL, OH, OL)                                                                                          \
+#define FP_PANEL(L, H, XH, XL, OH, OL, BODY)                                                                                 \
     {                                                                                                                        \
-        fetch(((L) + 1) % NL);                                                                                               \
-        const __bf16* W = &wl[(L) & 1][0];                                                                                   \
+        fetch(((L) * PH + (H) + 1) % (NL * PH));                                                                             \
+        const __bf16* W = &wl[((L) * PH + (H)) & 1][0];                                                                      \
         int lz = 0;                                                                                                          \
         asm volatile("" : "+v"(lz));                                                                                         \
         W += lz;                                                                                                             \
-        FP_BLOCK(L, 0, XH, XL, OH, OL) FP_BLOCK(L, 1, XH, XL, OH, OL) FP_BLOCK(L, 2, XH, XL, OH, OL) FP_BLOCK(L, 3, XH, XL, OH, OL) \
-        lds_dma_wait();                                                                                                      \
-        __syncthreads();                                                                                                     \
+        BODY                                                                                                                 \
+        XBARRIER                                                                                                             \
+    }
+#define FP_LAYER(L, XH, XL, OH, OL)                                                                                          \
+    if constexpr (PH == 1) {                                                                                                 \
+        FP_PANEL(L, 0, XH, XL, OH, OL, FP_BLOCK(L, 0, XH, XL, OH, OL) FP_BLOCK(L, 1, XH, XL, OH, OL) FP_BLOCK(L, 2, XH, XL, OH, OL) FP_BLOCK(L, 3, XH, XL, OH, OL)) \
+    } else {                                                                                                                 \
+        FP_PANEL(L, 0, XH, XL, OH, OL, FP_BLOCK(L, 0, XH, XL, OH, OL) FP_BLOCK(L, 1, XH, XL, OH, OL))                        \
+        FP_PANEL(L, 1, XH, XL, OH, OL, FP_BLOCK(L, 2, XH, XL, OH, OL) FP_BLOCK(L, 3, XH, XL, OH, OL))                        \
     }
         FP_LAYER(0, yh, yl, zh, zl)
         FP_LAYER(1, zh, zl, yh, yl)
         FP_LAYER(2, yh, yl, zh, zl)
         FP_LAYER(3, zh, zl, yh, yl)
 #undef FP_LAYER
+#undef FP_PANEL
 #undef FP_BLOCK
         // ---- conv2 (128 -> 3, rows zero-padded to one 32-channel block), direct orientation D[point][channel] -------------------
         {
@@ -486,9 +530,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 wh = wfrag_lds<NP>(w5 + lz, KS, 0, s, 0, lane);
+                const bf16x8 wh = PH == 1 ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 0, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP) * 64 + lane) * 8);
                 if constexpr (NP == 2) {
-                    const bf16x8 wlo = wfrag_lds<NP>(w5 + lz, KS, 0, s, 1, lane);
+                    const bf16x8 wlo = PH == 1 ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 1, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP + 1) * 64 + lane) * 8);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], wh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], wlo, acc, 0, 0, 0);
                 }
@@ -670,7 +714,11 @@ void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* n
                  hipStream_t st) {
     static const int dbg = getenv("LSDM_DBG_GATHER") ? atoi(getenv("LSDM_DBG_GATHER")) : 0;
     const long long tot = (long long)nc * 1024;
-    hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
+    // LSDM_FP1_WG=4: two independent 4-wave work-groups per CU on half-layer panels (A/B: their phases drift apart, the weights are
+    // streamed twice)
+    static const int wg4 = getenv("LSDM_FP1_WG") ? atoi(getenv("LSDM_FP1_WG")) == 4 : 0;
+    if (wg4) hipLaunchKernelGGL((fp_s_kernel<4, 2, 2>), dim3(512), dim3(256), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
+    else hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
 }
 
 void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,

@@ -256,12 +256,14 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
     constexpr int F2 = KS2 * NP, F3 = KS3 * NP;
     constexpr int W2E = NB2 * F2 * 512;
-    static_assert(NB3 % 2 == 0, "panel count must be even (double-buffer parity is compile-time)");
-    constexpr int PIECES = (F3 * 64 + NT - 1) / NT;
+    constexpr int PB = 2;                                     // channel blocks per layer-3 panel (32 KB): 4 barriers per round
+    constexpr int NPANEL = NB3 / PB, FP = PB * F3;            // fragments (1 KiB) per panel
+    static_assert(NB3 % PB == 0 && NPANEL % 2 == 0, "panel count must be even (double-buffer parity is compile-time)");
+    static_assert(FP % NW == 0, "panel split over the waves");
     __shared__ __attribute__((aligned(16))) __bf16 w2[W2E];
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][F3 * 512];
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FP * 512];
     __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     for (int e = tid; e < W2E / 8; e += NT) *reinterpret_cast<bf16x8*>(w2 + (size_t)e * 8) = *reinterpret_cast<const bf16x8*>(blob_w + (size_t)e * 8);
     for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
     const float* b2 = bl;
@@ -269,28 +271,18 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
     const int p = lane & 31, h = lane >> 5;
     const __bf16* w3g = blob_w + W2E;
 
-    // Layer-3 panels are requested TWO panel steps ahead (a step is 24 MFMAs per wave, ~1.5k cycles with two waves per SIMD;
-    // the loaded L2 latency is more than that): panel r travels through register set r % 2 into LDS buffer r % 2.
-    bf16x8 stage[2][PIECES];
+    // Layer-3 panel q -> LDS buffer q & 1 by LDS-DMA (no staging registers), requested one panel step ahead: a step is 48 MFMAs
+    // per wave (~3k cycles with two waves per SIMD), the copy is 4 KiB per wave
     auto fetch = [&](int q) {
-        const __bf16* src = w3g + (size_t)q * F3 * 512;
-        src = opaque_ptr(src);   // keeps the (round-invariant) panel fetches inside the persistent loop, as global loads
+        const __bf16* src = opaque_ptr(w3g + (size_t)q * FP * 512);   // (round-invariant: keep the copy inside the loop)
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int e = tid + i * NT;
-            if ((F3 * 64) % NT == 0 || e < F3 * 64) stage[q & 1][i] = gload<bf16x8>(src + (size_t)e * 8);
-        }
-    };
-    auto commit = [&](int q) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int e = tid + i * NT;
-            if ((F3 * 64) % NT == 0 || e < F3 * 64) *reinterpret_cast<bf16x8*>(&wl[q & 1][(size_t)e * 8]) = stage[q & 1][i];
+        for (int i = 0; i < FP / NW; ++i) {
+            const int fr = wave + i * NW;
+            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
         }
     };
     fetch(0);
-    commit(0);
-    fetch(1);
+    lds_dma_wait();
     __syncthreads();
 
     const long long rounds = (total_centroids + NW - 1) / NW;
@@ -359,20 +351,25 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- layer 3 streamed: one 16 KB panel per 32-channel block, direct orientation, max over the 32 neighbours
-#define PANEL_BEGIN(Q) { fetch(((Q) + 2) % NB3); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz));
-#define PANEL_END(Q) commit(((Q) + 1) % NB3); __syncthreads(); }
+        // ---- layer 3 streamed: one 32 KB panel per pair of 32-channel blocks, direct orientation, max over the 32 neighbours
+#define PANEL_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
+#define PANEL_END(Q) lds_dma_wait(); __syncthreads(); }
 #pragma unroll
-        for (int nb = 0; nb < NB3; ++nb) {
-            PANEL_BEGIN(nb)
-            f32x16 acc;
-            mma_panel_u<KS3, NP, false>(acc, W, zh, zl, lane);
-            float m = acc[0];
+        for (int q = 0; q < NPANEL; ++q) {
+            PANEL_BEGIN(q)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (live && lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[lz + nb * 32 + lane]);
-            PANEL_END(nb)
+            for (int u = 0; u < PB; ++u) {
+                const int nb = q * PB + u;
+                f32x16 acc;
+                mma_panel_u<KS3, NP, false>(acc, W + (size_t)u * F3 * 512, zh, zl, lane);
+                float m = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (live && lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[lz + nb * 32 + lane]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            PANEL_END(q)
         }
 #undef PANEL_BEGIN
 #undef PANEL_END
@@ -667,6 +664,160 @@ __global__ __launch_bounds__(512, 2) void sa_x_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// sa_w_kernel: the WIDE level (sa4) with ONE wave per SIMD and the whole register file behind it.
+//
+// A wave owns a centroid's 32 rows and carries BOTH 256-wide operands of the chained layers in registers (x: 128, z: 128 -- with one
+// wave per SIMD the 512-entry register file of gfx950 belongs to it; the matrix instructions read their operands from either half).
+// No exchange between waves, no K split: 4 centroids = 128 rows per pass over the weights (as sa_x), twelve panels of 64 KB (two
+// channel blocks x all of K) by LDS-DMA, one barrier per panel.  The two channel blocks of a panel are two INDEPENDENT accumulator
+// chains, issued alternately -- a single dependent chain leaves the matrix pipe idle a quarter of the time at one wave per SIMD
+// (tools/ubench/mfma_clock: 1.59 vs 2.08 PFLOP/s).
+// blob: as sa_x_kernel (build_chain_blob, [nb][s = 0..15][plane][lane][8]); biases [256 | 512].
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
+    const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
+    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out) {
+    constexpr int C1 = 256, C2 = 256, C3 = 512, NSRC = 64, S = 16, NW = 4, NT = NW * 64;
+    constexpr int KS = C1 / 16;
+    constexpr int NB2 = C2 / 32, NB3 = C3 / 32, PB = 2, NPANEL = (NB2 + NB3) / PB;
+    constexpr int FB = KS * NP, FP = PB * FB;                 // fragments (1 KiB) per channel block / per panel
+    static_assert(C1 == C2 && NPANEL % 2 == 0 && FP % NW == 0, "panel split");
+    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FP * 512];
+    __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
+    const int p = lane & 31, h = lane >> 5;
+    auto fetch = [&](int q) {
+        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FP * 512);
+#pragma unroll
+        for (int i = 0; i < FP / NW; ++i) {
+            const int fr = wave + i * NW;
+            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
+        }
+    };
+    fetch(0);
+    lds_dma_wait();
+    __syncthreads();
+
+    const long long rounds = total_centroids / NW;
+    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
+    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
+    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    // The neighbour / centroid indices of a round are requested one round ahead and its 32 U rows (the gather: 128 registers per
+    // lane) at the start of the previous round's layer 3, when x is dead -- with one wave per SIMD nothing else would hide that latency.
+    int idx_n = 0, ci_n = 0, ci_c = 0;
+    f32x4 un0[KS], un1[KS];
+    auto request_u = [&](long long cc) {
+        const float* urow = U + ((size_t)cc * NSRC + idx_n) * C1 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { un0[s] = load4f(urow + 16 * s); un1[s] = load4f(urow + 16 * s + 4); }
+    };
+    if (rbeg < rend) {
+        const long long ce = rbeg * NW + wave;
+        idx_n = ball[ce * kNSample + p];
+        ci_n = cent_idx[ce];
+        request_u(ce / S);
+    }
+    for (long long rd = rbeg; rd < rend; ++rd) {
+        const long long cent = rd * NW + wave;
+        const long long c = cent / S;
+        bf16x8 xh[KS], xl[KS], zh[KS], zl[KS];
+        ci_c = ci_n;
+        {
+            const float* vrow = V + ((size_t)c * NSRC + ci_c) * C1 + 8 * h;
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += 8) {
+                f32x4 v0[8], v1[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { v0[s] = load4f(vrow + 16 * (s0 + s)); v1[s] = load4f(vrow + 16 * (s0 + s) + 4); }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const f32x4 u0 = un0[s0 + s], u1 = un1[s0 + s];
+                    const float t[8] = {reluf(u0[0] - v0[s][0]), reluf(u0[1] - v0[s][1]), reluf(u0[2] - v0[s][2]), reluf(u0[3] - v0[s][3]),
+                                        reluf(u1[0] - v1[s][0]), reluf(u1[1] - v1[s][1]), reluf(u1[2] - v1[s][2]), reluf(u1[3] - v1[s][3])};
+                    split8u<NP>(t, xh[s0 + s], xl[s0 + s]);
+                }
+            }
+            if (rd + 1 < rend) { const long long ce = (rd + 1) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
+        }
+#define SAW_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
+#define SAW_END(Q) lds_dma_wait(); __syncthreads(); }
+        // ---- layer 2 (transposed): two channel blocks per panel as two interleaved accumulator chains
+#pragma unroll
+        for (int q = 0; q < NB2 / PB; ++q) {
+            SAW_BEGIN(q)
+            f32x16 a0, a1;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + lz + 32 * (2 * q) + 8 * qq + 4 * h);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + lz + 32 * (2 * q + 1) + 8 * qq + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a0[4 * qq + j] = b0[j]; a1[4 * qq + j] = b1[j]; }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 w0h = wfrag_lds_u<NP>(W, KS, 0, s, 0, lane), w1h = wfrag_lds_u<NP>(W, KS, 1, s, 0, lane);
+                if constexpr (NP == 2) {
+                    const bf16x8 w0l = wfrag_lds_u<NP>(W, KS, 0, s, 1, lane), w1l = wfrag_lds_u<NP>(W, KS, 1, s, 1, lane);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, xl[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xl[s], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, xh[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l, xh[s], a1, 0, 0, 0);
+                }
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, xh[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xh[s], a1, 0, 0, 0);
+                if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8], w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] = reluf(a0[8 * s2 + j]); w[j] = reluf(a1[8 * s2 + j]); }
+                split8u<NP>(v, zh[4 * q + s2], zl[4 * q + s2]);
+                split8u<NP>(w, zh[4 * q + 2 + s2], zl[4 * q + 2 + s2]);
+            }
+            SAW_END(q)
+        }
+        // ---- layer 3 (direct orientation): max over the 32 rows
+        if (rd + 1 < rend) request_u(((rd + 1) * NW + wave) / S);
+#pragma unroll
+        for (int q = 0; q < NB3 / PB; ++q) {
+            SAW_BEGIN(NB2 / PB + q)
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 w0h = wfrag_lds_u<NP>(W, KS, 0, s, 0, lane), w1h = wfrag_lds_u<NP>(W, KS, 1, s, 0, lane);
+                if constexpr (NP == 2) {
+                    const bf16x8 w0l = wfrag_lds_u<NP>(W, KS, 0, s, 1, lane), w1l = wfrag_lds_u<NP>(W, KS, 1, s, 1, lane);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], w0h, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], w1h, a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w0l, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w1l, a1, 0, 0, 0);
+                }
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w0h, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w1h, a1, 0, 0, 0);
+                if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            float m0 = a0[0], m1 = a1[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, a0[r]); m1 = fmaxf(m1, a1[r]); }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32));
+            if (lane < 32) {
+                out[(size_t)cent * C3 + (2 * q) * 32 + lane] = reluf(m0 + bl[lz + C2 + (2 * q) * 32 + lane]);
+                out[(size_t)cent * C3 + (2 * q + 1) * 32 + lane] = reluf(m1 + bl[lz + C2 + (2 * q + 1) * 32 + lane]);
+            }
+            SAW_END(NB2 / PB + q)
+        }
+#undef SAW_BEGIN
+#undef SAW_END
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // FP stage with the interpolated operand PRE-MULTIPLIED at the coarse level (fp2, fp3).  The first FP layer is linear in
 // [p1 || sum_j w_j p2_j] (pointnet2_utils.py:299-312), so with W = [Wa | Wb]:  W x [...] + b = Wa x p1 + sum_j w_j (Wb x p2_j) + b.
 // Y = p2 x Wb^T is evaluated once per COARSE point (lin_u_kernel<.., XYZ = false>, S = N/4 rows); here the three Y rows of a
@@ -817,7 +968,9 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
     if (level == 3) {
-        hipLaunchKernelGGL((sa_x_kernel<2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
+        static const int w = getenv("LSDM_SA4_X") ? atoi(getenv("LSDM_SA4_X")) : 2;   // 1 = sa_x (K-split wave pairs), 2 = sa_w (one wave per SIMD)
+        if (w == 2) hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
+        else hipLaunchKernelGGL((sa_x_kernel<2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;
         hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out);

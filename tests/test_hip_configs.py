@@ -188,25 +188,35 @@ def test_config3_b64_bulk_calls_bit_equal_to_single_steps(b64, precision):
 
 
 # ======================================================================================= configs[0]: the CLI on the HIP path
-def test_config1_cli_on_hip_backend_vs_oracle_backend(tmp_path):
+def test_config1_cli_on_hip_backend_vs_oracle_backend(tmp_path, golden):
     """python -m run.test_sdm --synthetic 4 --use_ddim --timestep_respacing ddim50 with the DEFAULT backend (HipBackend),
-    against the same CLI with the oracle injected: predictions / guiding points <= 1e-3, results.txt in the reference's
-    format (run/test_sdm.py:211,227-231) with matching figures."""
+    against the same CLI driven by the oracle (recorded by oracle/make_cli_fixture.py into g10_cli_ddim50: 200 oracle
+    forwards, ten minutes of CPU time on the GPU box otherwise; LSDM_FULL_CONFIG0=1 re-runs the oracle CLI live instead):
+    predictions / guiding points <= 1e-3, results.txt in the reference's format (run/test_sdm.py:211,227-231) with matching figures."""
     import run.test_sdm as cli
-    from test_host_logic import OracleBackend
     argv = lambda root, out, dev: [str(root), "--synthetic", "4", "--device", dev, "--use_ddim", "--timestep_respacing", "ddim50",
                                    "--output_dir", str(out), "--fix_ori", "--test_on_valid_set", "--model_name", "sdm"]
     assert cli.main(argv(tmp_path / "d_hip", tmp_path / "hip", "cuda:0")) == 0
-    assert cli.main(argv(tmp_path / "d_ref", tmp_path / "ref", "cpu"), backend_factory=OracleBackend) == 0
+    if os.environ.get("LSDM_FULL_CONFIG0") == "1":
+        from test_host_logic import OracleBackend
+        assert cli.main(argv(tmp_path / "d_ref", tmp_path / "ref", "cpu"), backend_factory=OracleBackend) == 0
+        ref = {sub: np.stack([np.load(tmp_path / "ref" / sub / f) for f in sorted(os.listdir(tmp_path / "ref" / sub))])
+               for sub in ("predictions", "guiding_points")}
+        ref_files = {sub: sorted(os.listdir(tmp_path / "ref" / sub)) for sub in ref}
+        lr = open(tmp_path / "ref" / "results.txt").read().splitlines()
+    else:
+        g = golden("g10_cli_ddim50")
+        ref = {sub: g[sub] for sub in ("predictions", "guiding_points")}
+        ref_files = {sub: [str(f) for f in g[sub + "_files"]] for sub in ref}
+        lr = str(g["results_txt"]).splitlines()
     for sub in ("predictions", "guiding_points"):
         files = sorted(os.listdir(tmp_path / "hip" / sub))
-        assert files == sorted(os.listdir(tmp_path / "ref" / sub)) and len(files) == 4
-        for f in files:
-            a, b = np.load(tmp_path / "hip" / sub / f), np.load(tmp_path / "ref" / sub / f)
+        assert files == ref_files[sub] and len(files) == 4
+        for i, f in enumerate(files):
+            a, b = np.load(tmp_path / "hip" / sub / f), ref[sub][i]
             assert a.shape == (1024, 3) and a.dtype == np.float32
             assert np.abs(a - b).max() <= 1e-3, (sub, f, np.abs(a - b).max())
     lh = open(tmp_path / "hip" / "results.txt").read().splitlines()
-    lr = open(tmp_path / "ref" / "results.txt").read().splitlines()
     assert len(lh) == len(lr) == 4 + 5
     assert all(re.fullmatch(r"Chamfer distance for seq Scene\d\d_\d{5}_01: \d+\.\d{4}", l) for l in lh[:4])
     for a, b, prefix in zip(lh[4:], lr[4:], ("Final Chamfer distance: ", "Final EMD: ", "Final F1 score: ", "Category accuracy: ",
