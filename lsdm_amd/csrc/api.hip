@@ -54,6 +54,8 @@ struct lsdm_ctx {
     DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
     DenseH fp1_s{}, fp2_s{};     // fp1 + head / fp2 as register-chained blobs (encoder_reg.hip::fp_s_kernel, fp_ps_kernel)
     int fp2_reg = getenv("LSDM_FP2_REG") ? atoi(getenv("LSDM_FP2_REG")) : 0;   // A/B switch (measured: 317 us vs 287 us for fp_pre_kernel)
+    int fuse_y = getenv("LSDM_FUSE_Y") ? atoi(getenv("LSDM_FUSE_Y")) : 1;      // A/B switch: fp2's Y as an extra layer of the fp3 launch
+    bool keep_taps = true;       // stage outputs that only feed a fused consumer (fp3) are still stored: off inside multi-step calls
     int sa4_x = getenv("LSDM_SA4_X") ? atoi(getenv("LSDM_SA4_X")) : 2;         // A/B switch: sa4 on 0 sa_h (LDS-tiled), 1 sa_x (K-split wave pairs), 2 sa_w (one wave per SIMD, 512 registers)
     int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
     DenseH den_r{};              // the per-point denoiser as a register-chained blob (denoise_reg.hip)
@@ -599,8 +601,11 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     prof_mark(c, K_FP4, st);
     launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
     prof_mark(c, K_FP3, st);
+    // fp3 also writes fp2's pre-multiplied interpolation operand (one more layer on its rows) when fp2 takes that form
+    const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y && !c->fp2_reg;
     if (np == 2 && c->fp_pre >= 2)
-        launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, st);
+        launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, false,
+                      c->fp_y[1], fuse_y ? c->fp_ybuf[1] : nullptr, c->keep_taps, st);
     else
         launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
     prof_mark(c, K_FP2, st);
@@ -612,7 +617,8 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
             launch_fp_y(nc * 256, c->fpo3, c->fp_y[1], c->fp_ybuf[1], st);
             launch_fp_ps(nc, p1, remap, c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp2_s.w, c->fp2_s.b, c->fpo2, st);
         } else {
-            launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, st);
+            launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
+                          DenseH{nullptr, nullptr}, nullptr, true, st);
         }
     } else
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
@@ -1206,6 +1212,8 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         return fail(c, LSDM_ERR_ARG, "lsdm_sample_steps: NULL tensor");
     DeviceGuard guard(c);
     if (!guard.ok) return LSDM_ERR_HIP;
+    // a multi-step call: stage outputs that feed only a fused consumer are not stored
+    struct TapsOff { lsdm_ctx* c; explicit TapsOff(lsdm_ctx* c_) : c(c_) { c->keep_taps = false; } ~TapsOff() { c->keep_taps = true; } } taps_off(c);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* cur = x;
     float* nxt = c->xs;

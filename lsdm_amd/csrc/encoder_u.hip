@@ -676,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void sa_x_kernel(const float* __restrict__ 
 template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
-    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out) {
+    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out, int dbg) {
     constexpr int C1 = 256, C2 = 256, C3 = 512, NSRC = 64, S = 16, NW = 4, NT = NW * 64;
     constexpr int KS = C1 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32, PB = 2, NPANEL = (NB2 + NB3) / PB;
@@ -741,8 +741,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if (rd + 1 < rend) { const long long ce = (rd + 1) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
         }
-#define SAW_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
-#define SAW_END(Q) lds_dma_wait(); __syncthreads(); }
+#define SAW_BEGIN(Q) { if (!(dbg & 1)) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
+#define SAW_END(Q) lds_dma_wait(); if (!(dbg & 2)) __syncthreads(); }
         // ---- layer 2 (transposed): two channel blocks per panel as two interleaved accumulator chains
 #pragma unroll
         for (int q = 0; q < NB2 / PB; ++q) {
@@ -755,11 +755,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { a0[4 * qq + j] = b0[j]; a1[4 * qq + j] = b1[j]; }
             }
+            // (requesting the fragments of k-step s + 1 in front of the MFMAs of k-step s was measured: no gain, 359 vs 352 us)
+            bf16x8 f0h = wfrag_lds_u<NP>(W, KS, 0, 0, 0, lane), f1h = wfrag_lds_u<NP>(W, KS, 1, 0, 0, lane);
+            bf16x8 f0l = wfrag_lds_u<NP>(W, KS, 0, 0, NP - 1, lane), f1l = wfrag_lds_u<NP>(W, KS, 1, 0, NP - 1, lane);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 w0h = wfrag_lds_u<NP>(W, KS, 0, s, 0, lane), w1h = wfrag_lds_u<NP>(W, KS, 1, s, 0, lane);
+                const bf16x8 w0h = f0h, w1h = f1h, w0l = f0l, w1l = f1l;
+                if (s + 1 < KS) {
+                    f0h = wfrag_lds_u<NP>(W, KS, 0, s + 1, 0, lane); f1h = wfrag_lds_u<NP>(W, KS, 1, s + 1, 0, lane);
+                    f0l = wfrag_lds_u<NP>(W, KS, 0, s + 1, NP - 1, lane); f1l = wfrag_lds_u<NP>(W, KS, 1, s + 1, NP - 1, lane);
+                }
+
                 if constexpr (NP == 2) {
-                    const bf16x8 w0l = wfrag_lds_u<NP>(W, KS, 0, s, 1, lane), w1l = wfrag_lds_u<NP>(W, KS, 1, s, 1, lane);
                     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, xl[s], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xl[s], a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, xh[s], a0, 0, 0, 0);
@@ -787,11 +794,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x16 a0, a1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+            bf16x8 f0h = wfrag_lds_u<NP>(W, KS, 0, 0, 0, lane), f1h = wfrag_lds_u<NP>(W, KS, 1, 0, 0, lane);
+            bf16x8 f0l = wfrag_lds_u<NP>(W, KS, 0, 0, NP - 1, lane), f1l = wfrag_lds_u<NP>(W, KS, 1, 0, NP - 1, lane);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 w0h = wfrag_lds_u<NP>(W, KS, 0, s, 0, lane), w1h = wfrag_lds_u<NP>(W, KS, 1, s, 0, lane);
+                const bf16x8 w0h = f0h, w1h = f1h, w0l = f0l, w1l = f1l;
+                if (s + 1 < KS) {
+                    f0h = wfrag_lds_u<NP>(W, KS, 0, s + 1, 0, lane); f1h = wfrag_lds_u<NP>(W, KS, 1, s + 1, 0, lane);
+                    f0l = wfrag_lds_u<NP>(W, KS, 0, s + 1, NP - 1, lane); f1l = wfrag_lds_u<NP>(W, KS, 1, s + 1, NP - 1, lane);
+                }
+
                 if constexpr (NP == 2) {
-                    const bf16x8 w0l = wfrag_lds_u<NP>(W, KS, 0, s, 1, lane), w1l = wfrag_lds_u<NP>(W, KS, 1, s, 1, lane);
                     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], w0h, a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], w1h, a1, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w0l, a0, 0, 0, 0);
@@ -824,15 +837,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // fine point are gathered and interpolated cooperatively (coalesced 16-byte pieces, fp32, no bf16 split) into an LDS tile
 // from which every wave initialises its accumulators; the matrix pipe then only contracts over the D1 columns of p1.
 // One LDS region is reused in sequence: interpolated tile (fp32) -> p1 operand tile -> layer-1 activations.
-template <int D1, int C1, int C2>
+// FUSE: the stage's output feeds ONLY the next finer stage's interpolation (fp3 -> fp2), whose first layer is pre-multiplied at THIS
+// level: ynext = out x Wb_next^T is one more layer on the rows that are already on chip -- no separate row-wise GEMM launch, no
+// re-read of `out` (which is then stored only when keep_out: the parity taps of the stage entry points).
+template <int D1, int C1, int C2, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                         const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out) {
     constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
     constexpr int LDT = C1 + 4;                              // fp32 tile row (floats): 16-byte aligned, rows 4 banks apart
-    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
-    constexpr int BYTES = imax(imax(TM * LDT * 4, NP * PX * 2), NP * PB * 2);
+    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB, LDC = ldh(C2), PC = TM * LDC;
+    constexpr int BYTES = imax(imax(imax(TM * LDT * 4, NP * PX * 2), NP * PB * 2), FUSE ? NP * PC * 2 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char region[BYTES];
     float* tile = reinterpret_cast<float*>(region);
     __bf16* bufX = reinterpret_cast<__bf16*>(region);
@@ -924,20 +940,68 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
     __syncthreads();
     using T2 = SplitH<NW, TM, C2>;
     const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
+    if constexpr (!FUSE) {
 #pragma unroll 1
-    for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
-        f32x16 a2[T2::RB];
-        acc_zero_h(a2);
-        const int col = cb * 32 + (lane & 31);
-        const float bv = l2.b[col];
-        mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
+        for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
+            f32x16 a2[T2::RB];
+            acc_zero_h(a2);
+            const int col = cb * 32 + (lane & 31);
+            const float bv = l2.b[col];
+            mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
 #pragma unroll
-        for (int rb = 0; rb < T2::RB; ++rb)
+            for (int rb = 0; rb < T2::RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lane);
-                out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lane);
+                    out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv);
+                }
+        }
+    } else {
+        // layer 2 transposed, every block of the wave kept in accumulators until all waves are done with bufB; its ReLU output
+        // becomes the operand tile of the extra layer in the same region
+        static_assert(!FUSE || (T2::RB == 2 && T2::WPC == 1), "split");
+        constexpr int NCB2 = T2::CB / T2::CSTEP;
+        __bf16* bufC = reinterpret_cast<__bf16*>(region);
+        f32x16 a2[NCB2][2];
+#pragma unroll
+        for (int q = 0; q < NCB2; ++q) {
+            f32x4 bv2[4];
+            load_bias_h(bv2, l2.b, cb2 + q * T2::CSTEP, lane);
+            acc_bias_h(a2[q], bv2);
+            mma_kloop_h<2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NCB2; ++q) {
+            const int cb = cb2 + q * T2::CSTEP;
+            if (keep_out) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const f32x4 v = {reluf(a2[q][rb][4 * qd]), reluf(a2[q][rb][4 * qd + 1]), reluf(a2[q][rb][4 * qd + 2]), reluf(a2[q][rb][4 * qd + 3])};
+                        *reinterpret_cast<f32x4*>(out + ((size_t)c * N + n0 + rb * 32 + p) * C2 + cb * 32 + 8 * qd + 4 * h) = v;
+                    }
             }
+            store_lds_b_h<ACT_RELU, 2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
+        }
+        __syncthreads();
+        using T3 = SplitH<NW, TM, 256>;
+        const int cb3 = wave % T3::CSTEP, rg3 = wave / T3::CSTEP;
+#pragma unroll 1
+        for (int cb = cb3; cb < T3::CB; cb += T3::CSTEP) {
+            f32x16 a3[T3::RB];
+            acc_zero_h(a3);
+            const int col = cb * 32 + (lane & 31);
+            mma_kloop_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane);
+#pragma unroll
+            for (int rb = 0; rb < T3::RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (rg3 * T3::RB + rb) * 32 + acc_row(r, lane);
+                    ynext[((size_t)c * N + n0 + row) * 256 + col] = a3[rb][r];
+                }
+        }
     }
 }
 
@@ -947,14 +1011,23 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
     hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
 }
 
+// y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):
+// fuse fp2's Y = out x wb_next^T into this launch; `out` itself is then stored only when keep_out.
 void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
-                   const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st) {
+                   const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
+                   bool keep_out, hipStream_t st) {
     const int S = which == 2 ? 256 : 64;
-    launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
+    if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
+    const DenseH none{nullptr, nullptr};
     if (which == 2)
-        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out);
+        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
+                           none, nullptr, 1);
+    else if (ynext)
+        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
+                           out, wb_next, ynext, keep_out ? 1 : 0);
     else
-        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out);
+        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out,
+                           none, nullptr, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -969,7 +1042,8 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
     if (level == 3) {
         static const int w = getenv("LSDM_SA4_X") ? atoi(getenv("LSDM_SA4_X")) : 2;   // 1 = sa_x (K-split wave pairs), 2 = sa_w (one wave per SIMD)
-        if (w == 2) hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
+        static const int dbg = getenv("LSDM_DBG_SAW") ? atoi(getenv("LSDM_DBG_SAW")) : 0;   // timing experiments: 1 no panel copy, 2 no barrier
+        if (w == 2) hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg);
         else hipLaunchKernelGGL((sa_x_kernel<2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;

@@ -116,8 +116,11 @@ void launch_sa_u(int level, int num_clouds, const float* U, const float* V, cons
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
 // p1_remap (optional): row i of a cloud's points1 is points1[p1_remap[i]]
+// y_ready: ybuf was written by the coarser stage's fused extra layer; wb_next / ynext (which = 3, optional): this launch also writes
+// fp2's pre-multiplied operand ynext = out x wb_next^T, and stores `out` itself only when keep_out (parity taps)
 void launch_fp_pre(int which, int num_clouds, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
-                   const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, hipStream_t st);
+                   const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
+                   bool keep_out, hipStream_t st);
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
