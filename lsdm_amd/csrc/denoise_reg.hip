@@ -10,10 +10,11 @@
 //   * Here a WAVE owns 32 points of one chain and carries their activations through the whole stack in registers (the
 //     accumulator -> operand identity of encoder_reg.hip: in the transposed product D[channel][point] the accumulators 8 s2 .. 8 s2 + 7
 //     of channel block nb ARE the lane's k-slots of k-step 2 nb + s2 of the next layer; the host packs the weight fragments in that
-//     k order).  Weights go through LDS as PANELS of <= 48 KB shared by the 8 waves of the work-group (256 points per panel
-//     pass), double-buffered, copied global -> LDS by the LDS-DMA path while the waves work on the previous panel; one barrier
-//     per panel.  Per step: [S_a S_b | pose2 | cex0_a cex0_b | cex2_a cex2_b | fin0]; pose_final.2 (3 rows zero-padded to one
-//     channel block) stays resident.
+//     k order).  Weights go through LDS as PANELS of <= 32 KB shared by the 8 waves of the work-group (256 points per panel
+//     pass) in a ring of four slots, copied global -> LDS by the LDS-DMA path THREE panels ahead of their use (a panel step is
+//     only ~1 us of matrix work at one 32-point block per wave: with the copy one step ahead every barrier also waited for the
+//     L2 latency -- 62 -> 45 us per step); one barrier per panel.  Per step: [S x3 | pose2 | cex0 x3 | cex2 x4 | fin0];
+//     pose_final.2 (3 rows zero-padded to one channel block) stays resident.
 //   * The timestep half of combine_extraction's pre-activation comes from ctext_kernel(kb0 = 0) (`ctime`; one tile per step when
 //     all chains share the timestep, one per (step, chain) otherwise), the text half from `ctext`: emb = GELU(ctime + ctext + b) is
 //     formed straight into operand fragments.  S = W_cex0[:, 128:] . emb + b is shared by the two denoiser passes of a step's last
@@ -44,13 +45,16 @@ struct RL {   // fragment (1 KiB = 512 bf16) offsets of the blob, see api.hip::b
     static constexpr int OFF_F0 = OFF_C2 + C2_NB * C2_KS * NP;
     static constexpr int OFF_F2 = OFF_F0 + F0_NB * F0_KS * NP;
     static constexpr int TOTAL = OFF_F2 + F2_KS * NP;
-    static constexpr int PANEL = 24 * NP;         // largest panel
-    // panels of a step: (offset, fragments)
-    static constexpr int SA = OFF_S, SA_N = 24 * NP, SB = OFF_S + 24 * NP, SB_N = 24 * NP;
-    static constexpr int P2 = OFF_P2, P2_N = 16 * NP;
-    static constexpr int C0A = OFF_C0, C0B = OFF_C0 + 24 * NP, C0_N = 24 * NP;
-    static constexpr int C2A = OFF_C2, C2B = OFF_C2 + 24 * NP, C2_N = 24 * NP;
-    static constexpr int F0 = OFF_F0, F0_N = 16 * NP;
+    // Panels (<= 32 KB) of a step, in the order they are consumed:
+    //   0..2  S blocks {0,1} {2,3} {4,5} | 3 pose2 | 4..6 cex0 blocks {0,1} {2,3} {4,5} | 7..10 cex2 blocks 0..3 | 11 fin0
+    // the guiding-point pass of a step's last forward repeats 3..11
+    static constexpr int NPAN = 12, FIRST_PASS = 3;
+    static constexpr int PANEL = 16 * NP;              // largest panel (fragments)
+    static constexpr int MIN_PER_WAVE = 12 * NP / 8;   // LDS-DMA instructions EVERY wave issues for the smallest panel
+    __device__ static int poff(int id) {
+        return id < 3 ? OFF_S + id * 16 * NP : id == 3 ? OFF_P2 : id < 7 ? OFF_C0 + (id - 4) * 16 * NP : id < 11 ? OFF_C2 + (id - 7) * 12 * NP : OFF_F0;
+    }
+    __device__ static int pn(int id) { return (id >= 7 && id < 11) ? 12 * NP : 16 * NP; }
 };
 // bias block (floats), same order as the host builds it
 constexpr int B_CEX0 = 0, B_POSE2 = 192, B_CEX2 = 320, B_FIN0 = 448, B_COMB = 512, B_POSE0 = 640, B_FIN2 = 896, B_TOTAL = 900;
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                                                        float* __restrict__ out_x0, float* __restrict__ out_guiding,
                                                        float* __restrict__ out_sample) {
     using L = RL<NP>;
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][L::PANEL * 512];
+    constexpr int NSLOT = 4;                                   // panel ring: the panel consumed now + three in flight
+    __shared__ __attribute__((aligned(16))) __bf16 wl[NSLOT][L::PANEL * 512];
     __shared__ __attribute__((aligned(16))) __bf16 wf2[L::F2_KS * NP * 512];
     __shared__ __attribute__((aligned(16))) float bl[B_TOTAL + 4];
     __shared__ float fsm[NW][4 * 96 + 32];
@@ -138,22 +143,51 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
     float* res = xs + 96;             // denoiser output
     float* oterm = res + 96;          // W15[c, 3:15] . o[b, o', :]   (27 values)
 
-    // panel `off` (fragment index in the blob, `n` fragments) -> LDS buffer `buf`: each wave copies n / NW fragments
-    auto fetch = [&](int off, int n, int buf) {
-        const __bf16* src = opaque_ptr(blob_w) + (size_t)off * 512;
-        for (int i = wave; i < n; i += NW)
-            lds_dma16(src + (size_t)i * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[buf][(size_t)i * 512])));
-    };
-    fetch(L::SA, L::SA_N, 0);
-    lds_dma_wait();
-    __syncthreads();
-
     const int total = B * (kPoints / 32);                       // 32-point blocks
     const int rounds = (total + NW - 1) / NW;
     const int rchunk = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
     const int rbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
     const int rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
     const bool chain = out_sample == nullptr && mode != MODE_FORWARD;
+
+    // ---- weight panels: the consumer counts panels (pc, slot = pc % NSLOT); the producer cursor walks the same sequence -- steps
+    // 0 .. nsteps-1 of every round, panels 0 .. 11 of a step, 3 .. 11 again after the last step -- three panels ahead.  All of it
+    // is wave-uniform scalar state.
+    int pc = 0;                                                         // panels consumed
+    int q_id = 0, q_step = 0, q_round = rbeg, q_pass2 = 0, q_cnt = 0;   // producer cursor; q_cnt = panels requested
+    auto request_next = [&]() {
+        if (q_round >= rend) return;
+        const __bf16* src = opaque_ptr(blob_w) + (size_t)L::poff(q_id) * 512;
+        const int n = L::pn(q_id);
+        __bf16* dst = &wl[q_cnt % NSLOT][0];
+        for (int i = wave; i < n; i += NW)
+            lds_dma16(src + (size_t)i * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(dst + (size_t)i * 512)));
+        ++q_cnt;
+        if (q_id < L::NPAN - 1) { ++q_id; return; }
+        if (!q_pass2 && q_step == nsteps - 1) { q_pass2 = 1; q_id = L::FIRST_PASS; return; }
+        q_pass2 = 0; q_id = 0;
+        if (++q_step >= nsteps) { q_step = 0; ++q_round; }
+    };
+    // the panel consumed now (the request for the one three ahead goes into the slot the previous barrier released)
+    auto panel_begin = [&]() -> const __bf16* {
+        request_next();
+        int lz = 0;
+        asm volatile("" : "+v"(lz));      // opaque zero: the (step-invariant) LDS reads stay inside the loops
+        return &wl[pc % NSLOT][0] + lz;
+    };
+    // the NEXT panel must have landed: everything but the copies of the two panels behind it may still be in flight (loads return
+    // in order; other loads issued since only make the wait stricter); at the tail of the sequence wait for everything
+    auto panel_end = [&]() {
+        if (q_cnt - pc >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L::MIN_PER_WAVE) : "memory");
+        else lds_dma_wait();
+        __syncthreads();
+        ++pc;
+    };
+    request_next();
+    request_next();
+    request_next();
+    lds_dma_wait();
+    __syncthreads();
 
     for (int rd = rbeg; rd < rend; ++rd) {
         const int blk_raw = rd * NW + wave;
@@ -188,107 +222,88 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
         }
         wave_sync();
 
-        // one denoiser pass on the (32, 3) tile zsrc (LDS) -> res; consumes S in place.  nxt_*: the panel to prefetch during fin0
-        auto pass = [&](const float* zsrc, f32x16 (&S)[6], int nxt_off, int nxt_n) {
-            int lz = 0;
+        // one denoiser pass on the (32, 3) tile zsrc (LDS) -> res; consumes S in place (panels 3 .. 11)
+        auto pass = [&](const float* zsrc, f32x16 (&S)[6]) {
             // pose_embedding.0: 3 -> 64 sigmoid (K = 3: VALU) straight into the K = 64 operand: k-slot (s, h, j) = channel 16 s + 8 h + j
             bf16x8 ah[4], al[4];
             {
+                int lz = 0;
+                asm volatile("" : "+v"(lz));
                 const float z0 = zsrc[p * 3], z1 = zsrc[p * 3 + 1], z2 = zsrc[p * 3 + 2];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const f32x4 wb = *reinterpret_cast<const f32x4*>(bl + B_POSE0 + 4 * (16 * s + 8 * h + j));
+                        const f32x4 wb = *reinterpret_cast<const f32x4*>(bl + lz + B_POSE0 + 4 * (16 * s + 8 * h + j));
                         v[j] = sigmoid_fast(fmaf(z2, wb[2], fmaf(z1, wb[1], z0 * wb[0])) + wb[3]);
                     }
                     split8_h<NP>(v, ah[s], al[s]);
                 }
             }
-            // ---- panel pose2 (buffer 0): 64 -> 128 sigmoid ---------------------------------------------------------------------
+            // ---- panel 3: pose2 64 -> 128 sigmoid ------------------------------------------------------------------------------
             bf16x8 ph[8], pl[8];
-            fetch(L::C0A, L::C0_N, 1);
-            asm volatile("" : "+v"(lz));
+            {
+                const __bf16* W = panel_begin();
+                const float* bz = bl + (W - &wl[pc % NSLOT][0]);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    f32x16 acc;
+                    acc_from_bias(acc, bz + B_POSE2 + 32 * nb, h);
+                    mma_t<4, NP>(acc, W, nb, ah, al, lane);
+                    act_split<ACT_SIGMOID, NP>(acc, ph[2 * nb], pl[2 * nb], ph[2 * nb + 1], pl[2 * nb + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                panel_end();
+            }
+            // ---- panels 4..6: cex0 [pose || emb] 256 -> 192 sigmoid; the emb half is S ------------------------------------------------
+            bf16x8 ch[12], cl[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const __bf16* W = panel_begin();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int nb = 2 * q + u;
+                    mma_t<8, NP>(S[nb], W, u, ph, pl, lane);
+                    act_split<ACT_SIGMOID, NP>(S[nb], ch[2 * nb], cl[2 * nb], ch[2 * nb + 1], cl[2 * nb + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                panel_end();
+            }
+            // ---- panels 7..10: cex2 192 -> 128 sigmoid -----------------------------------------------------------------------------
+            bf16x8 dh[8], dl[8];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
+                const __bf16* W = panel_begin();
+                const float* bz = bl + (W - &wl[pc % NSLOT][0]);
                 f32x16 acc;
-                acc_from_bias(acc, bl + lz + B_POSE2 + 32 * nb, h);
-                mma_t<4, NP>(acc, &wl[0][0] + lz, nb, ah, al, lane);
-                act_split<ACT_SIGMOID, NP>(acc, ph[2 * nb], pl[2 * nb], ph[2 * nb + 1], pl[2 * nb + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            lds_dma_wait();
-            __syncthreads();
-            // ---- panels cex0_a (buffer 1), cex0_b (buffer 0): [pose || emb] 256 -> 192 sigmoid; the emb half is S -------------------
-            bf16x8 ch[12], cl[12];
-            fetch(L::C0B, L::C0_N, 0);
-            asm volatile("" : "+v"(lz));
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
-                mma_t<8, NP>(S[nb], &wl[1][0] + lz, nb, ph, pl, lane);
-                act_split<ACT_SIGMOID, NP>(S[nb], ch[2 * nb], cl[2 * nb], ch[2 * nb + 1], cl[2 * nb + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            lds_dma_wait();
-            __syncthreads();
-            fetch(L::C2A, L::C2_N, 1);
-            asm volatile("" : "+v"(lz));
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
-                mma_t<8, NP>(S[3 + nb], &wl[0][0] + lz, nb, ph, pl, lane);
-                act_split<ACT_SIGMOID, NP>(S[3 + nb], ch[6 + 2 * nb], cl[6 + 2 * nb], ch[7 + 2 * nb], cl[7 + 2 * nb]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            lds_dma_wait();
-            __syncthreads();
-            // ---- panels cex2_a (buffer 1), cex2_b (buffer 0): 192 -> 128 sigmoid -----------------------------------------------------
-            bf16x8 dh[8], dl[8];
-            fetch(L::C2B, L::C2_N, 0);
-            asm volatile("" : "+v"(lz));
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 acc;
-                acc_from_bias(acc, bl + lz + B_CEX2 + 32 * nb, h);
-                mma_t<12, NP>(acc, &wl[1][0] + lz, nb, ch, cl, lane);
+                acc_from_bias(acc, bz + B_CEX2 + 32 * nb, h);
+                mma_t<12, NP>(acc, W, 0, ch, cl, lane);
                 act_split<ACT_SIGMOID, NP>(acc, dh[2 * nb], dl[2 * nb], dh[2 * nb + 1], dl[2 * nb + 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                panel_end();
             }
-            lds_dma_wait();
-            __syncthreads();
-            fetch(L::F0, L::F0_N, 1);
-            asm volatile("" : "+v"(lz));
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 acc;
-                acc_from_bias(acc, bl + lz + B_CEX2 + 64 + 32 * nb, h);
-                mma_t<12, NP>(acc, &wl[0][0] + lz, nb, ch, cl, lane);
-                act_split<ACT_SIGMOID, NP>(acc, dh[4 + 2 * nb], dl[4 + 2 * nb], dh[5 + 2 * nb], dl[5 + 2 * nb]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            lds_dma_wait();
-            __syncthreads();
-            // ---- panel fin0 (buffer 1): 128 -> 64 GELU; then pose_final.2 (resident): 64 -> 3 GELU, direct orientation ---------------
+            // ---- panel 11: fin0 128 -> 64 GELU; then pose_final.2 (resident): 64 -> 3 GELU, direct orientation ---------------------
             bf16x8 fh[4], fl[4];
-            if (nxt_n > 0) fetch(nxt_off, nxt_n, 0);
-            asm volatile("" : "+v"(lz));
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 acc;
-                acc_from_bias(acc, bl + lz + B_FIN0 + 32 * nb, h);
-                mma_t<8, NP>(acc, &wl[1][0] + lz, nb, dh, dl, lane);
-                act_split<ACT_GELU, NP>(acc, fh[2 * nb], fl[2 * nb], fh[2 * nb + 1], fl[2 * nb + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             {
+                const __bf16* W = panel_begin();
+                const int lzi = (int)(W - &wl[pc % NSLOT][0]);
+                const float* bz = bl + lzi;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    f32x16 acc;
+                    acc_from_bias(acc, bz + B_FIN0 + 32 * nb, h);
+                    mma_t<8, NP>(acc, W, nb, dh, dl, lane);
+                    act_split<ACT_GELU, NP>(acc, fh[2 * nb], fl[2 * nb], fh[2 * nb + 1], fl[2 * nb + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const bf16x8 wh = wfrag<NP>(wf2 + lz, 4, 0, s, 0, lane);
+                    const bf16x8 wh = wfrag<NP>(wf2 + lzi, 4, 0, s, 0, lane);
                     if constexpr (NP == 2) {
-                        const bf16x8 wlo = wfrag<NP>(wf2 + lz, 4, 0, s, 1, lane);
+                        const bf16x8 wlo = wfrag<NP>(wf2 + lzi, 4, 0, s, 1, lane);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s], wh, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s], wlo, acc, 0, 0, 0);
                     }
@@ -296,13 +311,12 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                 }
                 const int c = lane & 31;
                 if (c < 3) {
-                    const float bv = bl[lz + B_FIN2 + c];
+                    const float bv = bz[B_FIN2 + c];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) res[acc_row(r, lane) * 3 + c] = gelu_fast(acc[r] + bv);
                 }
+                panel_end();
             }
-            lds_dma_wait();
-            __syncthreads();
         };
 
 #pragma unroll 1
@@ -346,30 +360,20 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                     }
                 }
             }
-            // ---- panels S_a (buffer 0), S_b (buffer 1): S = W_cex0[:, 128:] . emb + b -------------------------------------------------
+            // ---- panels 0..2: S = W_cex0[:, 128:] . emb + b -----------------------------------------------------------------------
             f32x16 S[6];
-            {
-                int lz = 0;
-                fetch(L::SB, L::SB_N, 1);
-                asm volatile("" : "+v"(lz));
 #pragma unroll
-                for (int nb = 0; nb < 3; ++nb) {
-                    acc_from_bias(S[nb], bl + lz + B_CEX0 + 32 * nb, h);
-                    mma_t<8, NP>(S[nb], &wl[0][0] + lz, nb, eh, el, lane);
+            for (int q = 0; q < 3; ++q) {
+                const __bf16* W = panel_begin();
+                const float* bz = bl + (W - &wl[pc % NSLOT][0]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int nb = 2 * q + u;
+                    acc_from_bias(S[nb], bz + B_CEX0 + 32 * nb, h);
+                    mma_t<8, NP>(S[nb], W, u, eh, el, lane);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                lds_dma_wait();
-                __syncthreads();
-                fetch(L::P2, L::P2_N, 0);
-                asm volatile("" : "+v"(lz));
-#pragma unroll
-                for (int nb = 0; nb < 3; ++nb) {
-                    acc_from_bias(S[3 + nb], bl + lz + B_CEX0 + 96 + 32 * nb, h);
-                    mma_t<8, NP>(S[3 + nb], &wl[1][0] + lz, nb, eh, el, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                lds_dma_wait();
-                __syncthreads();
+                panel_end();
             }
             float* sst = stash + (size_t)blk * (6 * 16 * 64);
             if (last) {
@@ -383,13 +387,7 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                     }
             }
             // ---- denoiser on the mutated x + sampler update -----------------------------------------------------------------------
-            {
-                const bool more = rd + 1 < rend;
-                const int nxt_off = last ? L::P2 : L::SA;
-                const int nxt_n = last ? L::P2_N : L::SA_N;
-                (void)more;
-                pass(zt, S, nxt_off, nxt_n);
-            }
+            pass(zt, S);
             wave_sync();
 #pragma unroll 1
             for (int i = lane; i < 96; i += 64) {
@@ -426,8 +424,7 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
 #pragma unroll
                         for (int j = 0; j < 4; ++j) S[nb][4 * q + j] = v[j];
                     }
-                const bool more = rd + 1 < rend;
-                pass(gt, S, L::SA, more ? L::SA_N : 0);
+                pass(gt, S);
                 wave_sync();
 #pragma unroll 1
                 for (int i = lane; i < 96; i += 64)
