@@ -1254,7 +1254,12 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
             const lsdm_ctx::FrontSet f = c->fset_steps(j, B);
-            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, out_guiding, nxt, st, inv, c->shared_t());
+            // saved_guiding_points is defined by the LAST forward of the call (Q12): the loop-invariant schedule runs the denoiser's
+            // guiding-point pass only there (every other step's result would be overwritten unseen); the strict schedule keeps the
+            // reference's literal work and runs it every step
+            const bool skip_guiding = inv && c->den_reg && c->prec != LSDM_PREC_F32 && k != K - 1;
+            run_back(c, f, mode, eta, B, cur, f.tbuf, mask, given_objs, noise + (size_t)k * xn, out_x0, skip_guiding ? nullptr : out_guiding, nxt, st, inv,
+                     c->shared_t());
             rc = check_launch(c, "sample step");
             if (rc) return rc;
             float* tmp = cur; cur = nxt; nxt = tmp;
@@ -1306,7 +1311,8 @@ int lsdm_sample_steps_hoisted(lsdm_ctx* c, int mode, float eta, int B, int t_fir
         }
         if (c->prec != LSDM_PREC_F32) {
             // the whole group in one launch: a tile's x stays on chip between its steps (denoise_bf.hip)
-            run_denoise(c, c->fs0, mode, eta, B, cur, c->fs0.tbuf, mask, noise + (size_t)k0 * xn, out_x0, out_guiding, nullptr, st, g, true);
+            run_denoise(c, c->fs0, mode, eta, B, cur, c->fs0.tbuf, mask, noise + (size_t)k0 * xn, out_x0,
+                        (c->den_reg && k0 + g < K) ? nullptr : out_guiding, nullptr, st, g, true);
             rc = check_launch(c, "hoisted sample steps");
             if (rc) return rc;
             continue;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             lds_dma16(src + (size_t)i * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(dst + (size_t)i * 512)));
         ++q_cnt;
         if (q_id < L::NPAN - 1) { ++q_id; return; }
-        if (!q_pass2 && q_step == nsteps - 1) { q_pass2 = 1; q_id = L::FIRST_PASS; return; }
+        if (!q_pass2 && q_step == nsteps - 1 && out_guiding != nullptr) { q_pass2 = 1; q_id = L::FIRST_PASS; return; }
         q_pass2 = 0; q_id = 0;
         if (++q_step >= nsteps) { q_step = 0; ++q_round; }
     };
@@ -376,7 +376,8 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                 panel_end();
             }
             float* sst = stash + (size_t)blk * (6 * 16 * 64);
-            if (last) {
+            const bool guide = last && out_guiding != nullptr;   // out_guiding == NULL: a later forward of the call defines the guiding points
+            if (guide) {
                 // park S for the guiding-point pass (lane-linear 16-byte pieces: 1 KiB per instruction)
 #pragma unroll
                 for (int nb = 0; nb < 6; ++nb)
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             }
             wave_sync();
             // ---- denoiser on the guiding points (saved_guiding_points, Q12): defined by the last forward ----------------------------
-            if (last) {
+            if (guide) {
 #pragma unroll
                 for (int nb = 0; nb < 6; ++nb)
 #pragma unroll
