@@ -599,12 +599,14 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     }
     const Lin head2{c->head[1].w, c->head[1].b};
     prof_mark(c, K_FP4, st);
-    launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
-    prof_mark(c, K_FP3, st);
-    // fp3 also writes fp2's pre-multiplied interpolation operand (one more layer on its rows) when fp2 takes that form
+    // fp4 / fp3 also write the next finer stage's pre-multiplied interpolation operand (one more layer on their rows) when that stage
+    // takes the pre-multiplied form
     const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y && !c->fp2_reg;
+    if (fuse_y) launch_fp4_y(nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], c->fp_y[0], c->fpo4, c->fp_ybuf[0], c->keep_taps, st);
+    else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
+    prof_mark(c, K_FP3, st);
     if (np == 2 && c->fp_pre >= 2)
-        launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, false,
+        launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, fuse_y,
                       c->fp_y[1], fuse_y ? c->fp_ybuf[1] : nullptr, c->keep_taps, st);
     else
         launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);

@@ -226,11 +226,15 @@ extern "C" int lsdm_debug_phase_counters(unsigned long long* out, int reset) {
 // ---------------------------------------------------------------------------------------------
 // FP stage: [points1 || sum_j w_j * points2[idx_j]] -> conv+BN+ReLU stack; K streamed through LDS in chunks of KC.
 // HEAD adds conv1+bn1+ReLU (128->128) and conv2 (128->3, fp32 VALU) and writes fp32.
-template <int D1, int D2, int C1, int C2, int C3, bool HEAD, int TM, int KC, int NW, int NP, int WPS = 1>
+// FUSEY (two-layer form): the stage's output feeds only the next finer stage's interpolation, whose first layer is pre-multiplied at
+// this level (encoder_u.hip::fp_pre_kernel): ynext = out x l3^T (no bias, no activation) is one more layer on the rows already on
+// chip; `out` itself is then stored only when keep_out (parity taps).
+template <int D1, int D2, int C1, int C2, int C3, bool HEAD, int TM, int KC, int NW, int NP, int WPS = 1, bool FUSEY = false>
 __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT<NP>::type* __restrict__ points1,
                                                         const typename FeatT<NP>::type* __restrict__ points2,
                                                         const int* __restrict__ nn_idx, const float* __restrict__ nn_w, int N, int S,
-                                                        DenseH l1, DenseH l2, DenseH l3, DenseH h1, Lin h2, DenseH h2m, void* __restrict__ out_v) {
+                                                        DenseH l1, DenseH l2, DenseH l3, DenseH h1, Lin h2, DenseH h2m, void* __restrict__ out_v,
+                                                        float* __restrict__ ynext = nullptr, int keep_out = 1) {
     typedef typename FeatT<NP>::type feat_t;
     constexpr int NT = NW * 64;
     constexpr int K0 = D1 + D2;
@@ -323,7 +327,59 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
     for (int q = 0; q < NCB; ++q) store_lds_b_h<ACT_RELU, TS::RB, NP>(acc[q], rg * TS::RB, cb0 + q * TS::CSTEP, bufB, LDB, PB, lane);
     __syncthreads();
 
-    if constexpr (!HEAD) {
+    if constexpr (!HEAD && FUSEY) {
+        // layer 2 transposed, all blocks of the wave kept in accumulators until every wave is done with bufB; its ReLU output becomes
+        // the operand tile of the extra layer in the same region
+        static_assert(!FUSEY || (NP == 2 && C2 == 256), "fused Y: bf16x3, 256-wide stage output");
+        float* out = static_cast<float*>(out_v);
+        using T2 = SplitH<NW, TM, C2>;
+        static_assert(!FUSEY || (T2::RB == 2 && T2::WPC == 1), "split");
+        constexpr int NCB2 = T2::CB / T2::CSTEP;
+        constexpr int LDC = ldh(C2), PC = TM * LDC;
+        static_assert(!FUSEY || NP * PC <= SMEM, "operand tile of the extra layer fits the region");
+        const int cb2 = wave % T2::CSTEP, p = lane & 31, h = lane >> 5;
+        f32x16 a2[NCB2][2];
+#pragma unroll
+        for (int q = 0; q < NCB2; ++q) {
+            f32x4 bv2[4];
+            load_bias_h(bv2, l2.b, cb2 + q * T2::CSTEP, lane);
+            acc_bias_h(a2[q], bv2);
+            mma_kloop_h<2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
+        }
+        __syncthreads();
+        __bf16* bufC = smem;
+#pragma unroll
+        for (int q = 0; q < NCB2; ++q) {
+            const int cb = cb2 + q * T2::CSTEP;
+            if (keep_out) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const f32x4 v = {reluf(a2[q][rb][4 * qd]), reluf(a2[q][rb][4 * qd + 1]), reluf(a2[q][rb][4 * qd + 2]), reluf(a2[q][rb][4 * qd + 3])};
+                        *reinterpret_cast<f32x4*>(out + ((size_t)c * N + n0 + rb * 32 + p) * C2 + cb * 32 + 8 * qd + 4 * h) = v;
+                    }
+            }
+            store_lds_b_h<ACT_RELU, 2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
+        }
+        __syncthreads();
+        using T3 = SplitH<NW, TM, 256>;
+        const int cb3 = wave % T3::CSTEP, rg3 = wave / T3::CSTEP;
+#pragma unroll 1
+        for (int cb = cb3; cb < T3::CB; cb += T3::CSTEP) {
+            f32x16 a3[T3::RB];
+            acc_zero_h(a3);
+            const int col = cb * 32 + (lane & 31);
+            mma_kloop_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane);
+#pragma unroll
+            for (int rb = 0; rb < T3::RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (rg3 * T3::RB + rb) * 32 + acc_row(r, lane);
+                    ynext[((size_t)c * N + n0 + row) * 256 + col] = a3[rb][r];
+                }
+        }
+    } else if constexpr (!HEAD) {
         // last layer, direct orientation: 32 consecutive channels per half-wave -> global
         feat_t* out = static_cast<feat_t*>(out_v);
         using T2 = SplitH<NW, TM, C2>;
@@ -408,6 +464,15 @@ static void launch_fp_h_t(int which, int nc, const void* points1, const void* po
         case 1: hipLaunchKernelGGL((fp_h_kernel<0, 128, 128, 128, 128, true, 64, 128, 4, NP>), dim3(1024 / 64 * nc), dim3(256), 0, st, p1, p2,
                                    nn_idx, nn_w, 1024, 1024, l[0], l[1], l[2], head1[0], head2, head1[1], out); break;
     }
+}
+
+// fp4 (bf16x3) that also writes fp3's pre-multiplied interpolation operand ynext = out x wb^T; out is stored only when keep_out
+void launch_fp4_y(int nc, const float* points1, const float* points2, const int* nn_idx, const float* nn_w, const DenseH* l, DenseH wb,
+                  float* out, float* ynext, bool keep_out, hipStream_t st) {
+    const DenseH none{nullptr, nullptr};
+    const Lin nol{nullptr, nullptr};
+    hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, 2, 1, true>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, points2, nn_idx, nn_w,
+                       64, 16, l[0], l[1], wb, none, nol, none, out, ynext, keep_out ? 1 : 0);
 }
 
 // sa4 with the first layer split across the grouping (encoder_u.hip): U, V of the level-3 points, cent = FPS indices of level 4

@@ -846,7 +846,10 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
                                                         float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out) {
     constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
-    constexpr int LDT = C1 + 4;                              // fp32 tile row (floats): 16-byte aligned, rows 4 banks apart
+    // fp32 tile row (floats): 68 quads, and the quad index of an access is XORed with (row / 4) & 3 -- the 16-lane phases of both the
+    // interpolation stores (rows r .. r+3 x four consecutive quads) and the accumulator loads (16 consecutive rows x one quad) then
+    // cover 16 distinct bank quads (with the plain C1 + 4 rows the stores were 4-way conflicted: 26 % of the LDS cycles)
+    constexpr int LDT = C1 + 16;
     constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB, LDC = ldh(C2), PC = TM * LDC;
     constexpr int BYTES = imax(imax(imax(TM * LDT * 4, NP * PX * 2), NP * PB * 2), FUSE ? NP * PC * 2 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char region[BYTES];
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(a[k][j], w0), __fmul_rn(b[k][j], w1)), __fmul_rn(d[k][j], w2));
-                *reinterpret_cast<f32x4*>(tile + row * LDT + ch) = v;
+                *reinterpret_cast<f32x4*>(tile + row * LDT + (ch ^ (((row >> 2) & 3) << 2))) = v;
             }
         }
     }
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ (((p >> 2) & 3) << 2)));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = t[j];
             }

@@ -154,6 +154,9 @@ void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int 
                       const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
                       const float* ctext, const float* ctime, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
 
+// encoder_bf.hip: fp4 with fp3's pre-multiplied interpolation operand as an extra layer (bf16x3)
+void launch_fp4_y(int nc, const float* points1, const float* points2, const int* nn_idx, const float* nn_w, const DenseH* l, DenseH wb,
+                  float* out, float* ynext, bool keep_out, hipStream_t st);
 // denoise_reg.hip: the same step as launch_denoise_h with the per-point denoiser register-chained (blob: api.hip::build_denoise_reg_blob);
 // ctime: (rows,1024,128) from launch_ctext(time_half), row = step (ctime_per_sample = 0) or step * B + sample; stash: B * 32 tiles of 24 KB
 void launch_denoise_r(int np, const DenseH& blob, const Lin& pwt, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int ctime_per_sample,
