@@ -333,18 +333,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
         static_assert(!FUSEY || (NP == 2 && C2 == 256), "fused Y: bf16x3, 256-wide stage output");
         float* out = static_cast<float*>(out_v);
         using T2 = SplitH<NW, TM, C2>;
-        static_assert(!FUSEY || (T2::RB == 2 && T2::WPC == 1), "split");
+        static_assert(!FUSEY || T2::WPC == 1, "split");
+        constexpr int RB2 = T2::RB;
         constexpr int NCB2 = T2::CB / T2::CSTEP;
         constexpr int LDC = ldh(C2), PC = TM * LDC;
         static_assert(!FUSEY || NP * PC <= SMEM, "operand tile of the extra layer fits the region");
         const int cb2 = wave % T2::CSTEP, p = lane & 31, h = lane >> 5;
-        f32x16 a2[NCB2][2];
+        f32x16 a2[NCB2][RB2];
 #pragma unroll
         for (int q = 0; q < NCB2; ++q) {
             f32x4 bv2[4];
             load_bias_h(bv2, l2.b, cb2 + q * T2::CSTEP, lane);
             acc_bias_h(a2[q], bv2);
-            mma_kloop_h<2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
+            mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
         }
         __syncthreads();
         __bf16* bufC = smem;
@@ -353,14 +354,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
             const int cb = cb2 + q * T2::CSTEP;
             if (keep_out) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RB2; ++rb)
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         const f32x4 v = {reluf(a2[q][rb][4 * qd]), reluf(a2[q][rb][4 * qd + 1]), reluf(a2[q][rb][4 * qd + 2]), reluf(a2[q][rb][4 * qd + 3])};
                         *reinterpret_cast<f32x4*>(out + ((size_t)c * N + n0 + rb * 32 + p) * C2 + cb * 32 + 8 * qd + 4 * h) = v;
                     }
             }
-            store_lds_b_h<ACT_RELU, 2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
+            store_lds_b_h<ACT_RELU, RB2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
         }
         __syncthreads();
         using T3 = SplitH<NW, TM, 256>;
@@ -471,6 +472,8 @@ void launch_fp4_y(int nc, const float* points1, const float* points2, const int*
                   float* out, float* ynext, bool keep_out, hipStream_t st) {
     const DenseH none{nullptr, nullptr};
     const Lin nol{nullptr, nullptr};
+    // (32-row tiles -- 1152 work-groups instead of 576 on 512 resident slots -- were measured slower, 130 vs 111 us: every tile streams
+    // the stage's 1.3 MB of fragments from L2, and that stream, not the second half-empty round, sets the pace)
     hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, 2, 1, true>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, points2, nn_idx, nn_w,
                        64, 16, l[0], l[1], wb, none, nol, none, out, ynext, keep_out ? 1 : 0);
 }
