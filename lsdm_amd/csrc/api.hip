@@ -63,8 +63,9 @@ struct lsdm_ctx {
     float* s_stash = nullptr;    // denoise_r_kernel: S of the last step, parked between its two denoiser passes
     // first FP layer split at the concat boundary (encoder_u.hip): columns of points1 (+ bias) / of the interpolated points2;
     // index 0: fp3, 1: fp2
-    DenseH fp_a[2], fp_y[2];
-    float* fp_ybuf[2] = {};
+    DenseH fp_a[3], fp_y[3];     // first FP layer split at the concat boundary: [0] fp3, [1] fp2, [2] fp4
+    float* fp_ybuf[3] = {};
+    int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
     int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
     const float* sa_wx[3] = {};
     float *sa_U[3] = {}, *sa_V[3] = {};
@@ -602,7 +603,12 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     // fp4 / fp3 also write the next finer stage's pre-multiplied interpolation operand (one more layer on their rows) when that stage
     // takes the pre-multiplied form
     const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y && !c->fp2_reg;
-    if (fuse_y) launch_fp4_y(nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], c->fp_y[0], c->fpo4, c->fp_ybuf[0], c->keep_taps, st);
+    if (fuse_y && c->fp4_pre)
+        // fp4 in the pre-multiplied form too: Y4 = feat4 x Wb^T on the 16 coarse points of a cloud, the matrix pipe then contracts over the
+        // 256 columns of points1 only (K = 256 instead of 768: a third of the fragments every 64-row tile streams from L2)
+        launch_fp_pre(4, nc, c->feat[2], nullptr, c->feat[3], c->fp_y[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], c->fpo4, false,
+                      c->fp_y[0], c->fp_ybuf[0], c->keep_taps, st);
+    else if (fuse_y) launch_fp4_y(nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], c->fp_y[0], c->fpo4, c->fp_ybuf[0], c->keep_taps, st);
     else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
     prof_mark(c, K_FP3, st);
     if (np == 2 && c->fp_pre >= 2)
@@ -937,20 +943,20 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
             }
             // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
             {
-                const char* pre[2] = {"pcd_backbone.fp3", "pcd_backbone.fp2"};
-                const int d1[2] = {128, 64};
-                for (int i = 0; i < 2 && ok; ++i) {
-                    const int K = d1[i] + 256;
+                const char* pre[3] = {"pcd_backbone.fp3", "pcd_backbone.fp2", "pcd_backbone.fp4"};
+                const int d1[3] = {128, 64, 256}, d2[3] = {256, 256, 512};
+                for (int i = 0; i < 3 && ok; ++i) {
+                    const int K = d1[i] + d2[i];
                     std::vector<float> Wf, Bf;
                     ok = fold_dense(c, std::string(pre[i]) + ".mlp_convs.0.weight", std::string(pre[i]) + ".mlp_convs.0.bias",
                                     std::string(pre[i]) + ".mlp_bns.0", 256, K, Wf, Bf);
                     if (!ok) break;
-                    std::vector<float> wa((size_t)256 * d1[i]), wb((size_t)256 * 256);
+                    std::vector<float> wa((size_t)256 * d1[i]), wb((size_t)256 * d2[i]);
                     for (int n = 0; n < 256; ++n) {
                         for (int k = 0; k < d1[i]; ++k) wa[(size_t)n * d1[i] + k] = Wf[(size_t)n * K + k];
-                        for (int k = 0; k < 256; ++k) wb[(size_t)n * 256 + k] = Wf[(size_t)n * K + d1[i] + k];
+                        for (int k = 0; k < d2[i]; ++k) wb[(size_t)n * d2[i] + k] = Wf[(size_t)n * K + d1[i] + k];
                     }
-                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], np, {}), pb = pack_weight_h(wb, 256, 256, np, {});
+                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], np, {}), pb = pack_weight_h(wb, 256, d2[i], np, {});
                     c->fp_a[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pa.data()), pa.size() / 2));
                     c->fp_a[i].b = upload(c, Bf.data(), Bf.size());
                     c->fp_y[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pb.data()), pb.size() / 2));
@@ -1172,7 +1178,7 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->sa_V[0] = ws_alloc<float>(c, "sa3_v", nc * 256 * 128)) && (c->sa_U[1] = ws_alloc<float>(c, "sa4_u", nc * 64 * 256)) &&
          (c->sa_V[1] = ws_alloc<float>(c, "sa4_v", nc * 64 * 256)) && (c->sa_U[2] = ws_alloc<float>(c, "sa2_u", nc * 1024 * 64)) &&
          (c->sa_V[2] = ws_alloc<float>(c, "sa2_v", nc * 1024 * 64)) && (c->fp_ybuf[1] = ws_alloc<float>(c, "fp2_y", nc * 256 * 256)) &&
-         (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256)) &&
+         (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256)) && (c->fp_ybuf[2] = ws_alloc<float>(c, "fp4_y", nc * 16 * 256)) &&
          (c->h2x = ws_alloc<float>(c, "h2x", (size_t)B * 128 * 512)) && (c->ctext = ws_alloc<float>(c, "ctext", (size_t)B * kN * 128)) &&
          (c->ct_time = ws_alloc<float>(c, "ct_time", (size_t)(B > lsdm_ctx::kGroup ? B : lsdm_ctx::kGroup) * kN * 128)) &&
          (c->s_stash = ws_alloc<float>(c, "s_stash", (size_t)B * (kN / 32) * 6 * 16 * 64));

@@ -1019,9 +1019,16 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
 void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
                    bool keep_out, hipStream_t st) {
-    const int S = which == 2 ? 256 : 64;
-    if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
+    const int S = which == 2 ? 256 : (which == 3 ? 64 : 16);
     const DenseH none{nullptr, nullptr};
+    if (which == 4) {
+        // fp4: 64 fine <- 16 coarse points per cloud, D1 = 256, the coarse features are 512 wide
+        hipLaunchKernelGGL((lin_u_kernel<512, 256, false>), dim3((nc * 16 + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, nc * 16, wb, nullptr, ybuf, nullptr);
+        hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16, l1a, l2,
+                           out, wb_next, ynext, keep_out ? 1 : 0);
+        return;
+    }
+    if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
     if (which == 2)
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
                            none, nullptr, 1);
