@@ -840,12 +840,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // FUSE: the stage's output feeds ONLY the next finer stage's interpolation (fp3 -> fp2), whose first layer is pre-multiplied at THIS
 // level: ynext = out x Wb_next^T is one more layer on the rows that are already on chip -- no separate row-wise GEMM launch, no
 // re-read of `out` (which is then stored only when keep_out: the parity taps of the stage entry points).
-template <int D1, int C1, int C2, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
+// TM_ x NW_: 64 rows x 4 waves, two work-groups per CU; or 128 rows x 8 waves, one per CU (half the weight stream per row).
+template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4>
+__global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                         const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
                                                         float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out) {
-    constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
+    constexpr int TM = TM_, NW = NW_, NP = 2, NT = NW * 64;
+    static_assert(NT == 4 * TM, "four threads per fine point in the interpolation phase");
     // fp32 tile row (floats): 68 quads, and the quad index of an access is XORed with (row / 4) & 3 -- the 16-lane phases of both the
     // interpolation stores (rows r .. r+3 x four consecutive quads) and the accumulator loads (16 consecutive rows x one quad) then
     // cover 16 distinct bank quads (with the plain C1 + 4 rows the stores were 4-way conflicted: 26 % of the LDS cycles)
@@ -909,13 +911,14 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
     // ---- phase B: accumulators start from the interpolated rows (transposed product: lane owns channels 8q + 4h + j of point p)
     using TS = SplitH<NW, TM, C1>;
     constexpr int NCB = TS::CB / TS::CSTEP;
-    static_assert(TS::RB == 2 && TS::WPC == 1, "split");
+    static_assert(TS::WPC == 1, "split");
+    constexpr int RB1 = TS::RB;
     const int cb0 = wave % TS::CSTEP;
-    f32x16 acc[NCB][2];
+    f32x16 acc[NCB][RB1];
 #pragma unroll
     for (int q = 0; q < NCB; ++q)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < RB1; ++rb)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ (((p >> 2) & 3) << 2)));
@@ -935,11 +938,11 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) mma_kloop_h<2, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
+    for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
     __syncthreads();
     // ---- phase D: layer-1 epilogue -> bufB, layer 2 (direct orientation) -> global -----------------------------------------------
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, 2, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
+    for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
     __syncthreads();
     using T2 = SplitH<NW, TM, C2>;
     const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
@@ -962,16 +965,16 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
     } else {
         // layer 2 transposed, every block of the wave kept in accumulators until all waves are done with bufB; its ReLU output
         // becomes the operand tile of the extra layer in the same region
-        static_assert(!FUSE || (T2::RB == 2 && T2::WPC == 1), "split");
-        constexpr int NCB2 = T2::CB / T2::CSTEP;
+        static_assert(!FUSE || T2::WPC == 1, "split");
+        constexpr int NCB2 = T2::CB / T2::CSTEP, RB2 = T2::RB;
         __bf16* bufC = reinterpret_cast<__bf16*>(region);
-        f32x16 a2[NCB2][2];
+        f32x16 a2[NCB2][RB2];
 #pragma unroll
         for (int q = 0; q < NCB2; ++q) {
             f32x4 bv2[4];
             load_bias_h(bv2, l2.b, cb2 + q * T2::CSTEP, lane);
             acc_bias_h(a2[q], bv2);
-            mma_kloop_h<2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
+            mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
         }
         __syncthreads();
 #pragma unroll
@@ -979,14 +982,14 @@ __global__ __launch_bounds__(256, 2) void fp_pre_kernel(const float* __restrict_
             const int cb = cb2 + q * T2::CSTEP;
             if (keep_out) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RB2; ++rb)
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         const f32x4 v = {reluf(a2[q][rb][4 * qd]), reluf(a2[q][rb][4 * qd + 1]), reluf(a2[q][rb][4 * qd + 2]), reluf(a2[q][rb][4 * qd + 3])};
                         *reinterpret_cast<f32x4*>(out + ((size_t)c * N + n0 + rb * 32 + p) * C2 + cb * 32 + 8 * qd + 4 * h) = v;
                     }
             }
-            store_lds_b_h<ACT_RELU, 2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
+            store_lds_b_h<ACT_RELU, RB2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
         }
         __syncthreads();
         using T3 = SplitH<NW, TM, 256>;
@@ -1032,9 +1035,15 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
     if (which == 2)
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
                            none, nullptr, 1);
-    else if (ynext)
-        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
-                           out, wb_next, ynext, keep_out ? 1 : 0);
+    else if (ynext) {
+        // LSDM_FP3_TM=128: 128-row tiles, one 8-wave work-group per CU (half the weight stream per row; measured slower, 175 vs 156 us:
+        // two independent work-groups per CU cover each other's gather and barrier phases)
+        static const int big = getenv("LSDM_FP3_TM") ? atoi(getenv("LSDM_FP3_TM")) == 128 : 0;
+        if (big) hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 128, 8>), dim3(256 / 128 * nc), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w,
+                                    256, 64, l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0);
+        else hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
+                                out, wb_next, ynext, keep_out ? 1 : 0);
+    }
     else
         hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out,
                            none, nullptr, 1);
