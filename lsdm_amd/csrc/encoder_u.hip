@@ -250,7 +250,7 @@ template <int C1, int C2, int C3, int NW, int NP>
 __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                          const int* __restrict__ cent_idx, const int* __restrict__ ball, int NSRC, int S,
                                                          long long total_centroids, const __bf16* __restrict__ blob_w,
-                                                         const float* __restrict__ blob_b, float* __restrict__ out) {
+                                                         const float* __restrict__ blob_b, float* __restrict__ out, int dbg) {
     constexpr int NT = NW * 64;
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
         const bool live = cent < total_centroids;
         if (!live) cent = total_centroids - 1;
         const long long c = cent / S;
+        if (dbg) { idx_n = wave; ci_n = 0; }      // timing experiment: every lane of a wave gathers the same row
         const float* urow = U + ((size_t)c * NSRC + idx_n) * C1 + 8 * h;
         const float* vrow = V + ((size_t)c * NSRC + ci_n) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
@@ -1072,7 +1073,10 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
         // LSDM_SA3_V1=1: the older kernel that streams both layers (A/B switch for measurements)
         static const bool v1 = getenv("LSDM_SA3_V1") && atoi(getenv("LSDM_SA3_V1")) != 0;
         if (v1) hipLaunchKernelGGL((sa_u_kernel<128, 128, 256, 4, 2>), dim3(512), dim3(256), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
-        else hipLaunchKernelGGL((sa_u2_kernel<128, 128, 256, 8, 2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
+        else {
+            static const int dbg = getenv("LSDM_DBG_SA3") ? atoi(getenv("LSDM_DBG_SA3")) : 0;
+            hipLaunchKernelGGL((sa_u2_kernel<128, 128, 256, 8, 2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out, dbg);
+        }
     }
 }
 
