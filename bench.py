@@ -42,15 +42,15 @@ GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
 # A profiled STAGE (the reference function it replaces) can be two launches in the bf16x3 mode; the rocprofv3 summary lists
 # them separately (profiles/r01_*_kernel_stats.md), the HIP-event interval of the stage covers both.
 STAGE_KERNELS_BF16X3 = {
-    "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64>",
+    "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64> (once per call in the loop-invariant schedule)",
     "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128>",
     "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_u2_kernel<128,128,256>",
-    "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_h_kernel<256,256,256,512,...,PRE>",
-    "fp_kernel<fp4>": "fp_h_kernel<256,512,256,256>",
-    "fp_kernel<fp3>": "lin_u_kernel<256,256,false> (Y per level-3 point) + fp_pre_kernel<128,256,256>",
-    "fp_kernel<fp2>": "lin_u_kernel<256,256,false> (Y per level-2 point) + fp_pre_kernel<64,256,128>",
+    "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_w_kernel",
+    "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y)",
+    "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
+    "fp_kernel<fp2>": "fp_pre_kernel<64,256,128>",
     "fp_kernel<fp1+head>": "fp_s_kernel<8,2>",
-    "denoise_kernel": "denoise_h_kernel",
+    "denoise_kernel": "denoise_r_kernel (guiding-point pass on the call's last forward only in the loop-invariant schedule)",
 }
 GFLOP_PER_SAMPLE_STEP_HOISTED = 0.740   # the x/t-dependent part only
 

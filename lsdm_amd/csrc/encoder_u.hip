@@ -890,16 +890,19 @@ __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(cons
         const float* r2 = yb + (size_t)nn_idx[o + 2] * C1;
         const float w0 = nn_w[o + 0], w1 = nn_w[o + 1], w2 = nn_w[o + 2];
         constexpr int PIECES = C1 / 16;                      // per thread
+        // GB pieces x 3 rows in flight per batch: the phase is a chain of L2 round trips, so fewer, larger batches (registers
+        // permitting: 12 GB VGPRs) shorten it
+        constexpr int GB = PIECES >= 8 ? 8 : 4;
 #pragma unroll 1
-        for (int k0 = 0; k0 < PIECES; k0 += 4) {
-            f32x4 a[4], b[4], d[4];
+        for (int k0 = 0; k0 < PIECES; k0 += GB) {
+            f32x4 a[GB], b[GB], d[GB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < GB; ++k) {
                 const int ch = 4 * (sub + 4 * (k0 + k));
                 a[k] = load4f(r0 + ch); b[k] = load4f(r1 + ch); d[k] = load4f(r2 + ch);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < GB; ++k) {
                 const int ch = 4 * (sub + 4 * (k0 + k));
                 f32x4 v;
 #pragma unroll

@@ -11,43 +11,42 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SA = {"3": "sa_kernel<3,32,32,64>", "64": "sa_kernel<64,64,64,128>", "128": "sa_kernel<128,128,128,256>", "256": "sa_kernel<256,256,256,512>"}
-FP = {("256", "512"): "fp_kernel<fp4>", ("128", "256"): "fp_kernel<fp3>", ("64", "256"): "fp_kernel<fp2>", ("0", "128"): "fp_kernel<fp1+head>"}
-
-
-def bench_name(k):
-    m = re.search(r"sa_(?:[hrsu]_)?kernel<(\d+),", k)
-    if m:
-        return SA.get(m.group(1))
-    m = re.search(r"fp_(?:h_)?kernel<(\d+), (\d+),", k)
-    if m:
-        return FP.get((m.group(1), m.group(2)))
-    m = re.search(r"fp_pre_kernel<(\d+),", k)
-    if m:
-        return {"64": "fp_kernel<fp2>", "128": "fp_kernel<fp3>"}.get(m.group(1))
-    if "fps_chain" in k:
-        return "fps_chain_kernel"
-    for n in ("fps_chain_kernel", "posa_kernel", "cond_kernel", "scene_attn_kernel"):
-        if n in k:
-            return n
-    if "denoise" in k:
-        return "denoise_kernel"
-    if "upsample12" in k:
-        return "upsample12_kernel"
-    return None
-
+# bench stage -> the launches it consists of in the bf16x3 schedule (substring match on the rocprof kernel name); a stage's traffic
+# is the SUM over its launches (both are inside the HIP-event interval bench.py reports for the stage)
+STAGES = {
+    "sa_kernel<3,32,32,64>": ["sa_r_kernel<3, 32, 32, 64", "sa_h_kernel<3, 32, 32, 64", "sa_kernel<3, 32, 32, 64"],
+    "sa_kernel<64,64,64,128>": ["sa_ur_kernel<64, 64, 128", "sa_r_kernel<64, 64, 64, 128", "sa_h_kernel<64, 64, 64, 128"],
+    "sa_kernel<128,128,128,256>": ["lin_u_kernel<128, 128, true>", "sa_u2_kernel<128, 128, 256", "sa_u_kernel<128, 128, 256", "sa_s_kernel<128",
+                                   "sa_h_kernel<128, 128, 128, 256"],
+    "sa_kernel<256,256,256,512>": ["lin_u_kernel<256, 256, true>", "sa_w_kernel", "sa_x_kernel", "sa_h_kernel<256, 256, 256, 512"],
+    "fp_kernel<fp4>": ["lin_u_kernel<512, 256, false>", "fp_pre_kernel<256, 256, 256", "fp_h_kernel<256, 512"],
+    "fp_kernel<fp3>": ["fp_pre_kernel<128, 256, 256", "fp_h_kernel<128, 256"],
+    "fp_kernel<fp2>": ["fp_pre_kernel<64, 256, 128", "fp_ps_kernel", "fp_h_kernel<64, 256"],
+    "fp_kernel<fp1+head>": ["fp_s_kernel", "fp_h_kernel<0, 128"],
+    "fps_chain_kernel": ["fps_chain"],
+    "denoise_kernel": ["denoise_r_kernel", "denoise_h_kernel", "denoise_kernel"],
+    "upsample12_kernel": ["upsample12"],
+    "cond_kernel": ["cond_kernel"],
+    "scene_attn_kernel": ["scene_attn_kernel"],
+    "posa_kernel": ["posa_stage_kernel", "posa_kernel"],
+}
 
 out = {}
 for arg in sys.argv[1:]:
     prec, path = arg.split("=")
     d = json.load(open(path))
     out[prec] = {}
-    for k, cs in d.items():
-        n = bench_name(k)
-        if not n or "FETCH_SIZE" not in cs:
-            continue
-        f = cs["FETCH_SIZE"]["mean_per_launch"] * 1024.0
-        w = cs.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0) * 1024.0
-        out[prec][n] = {"fetch_bytes": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "unit": "bytes per launch (B=64)"}
+    for stage, pats in STAGES.items():
+        f = w = 0.0
+        parts = []
+        for k, cs in d.items():
+            if "FETCH_SIZE" not in cs or not any(pt in k for pt in pats):
+                continue
+            f += cs["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+            w += cs.get("WRITE_SIZE", {}).get("mean_per_launch", 0.0) * 1024.0
+            parts.append(k.replace("void ", "").split("(")[0][:60])
+        if parts:
+            out[prec][stage] = {"fetch_bytes": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "unit": "bytes per launch (B=64)", "launches": parts}
+    out[prec]["_source"] = os.path.basename(path)
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
-print(json.dumps(out, indent=1)[:1500])
+print(json.dumps(out, indent=1)[:1800])
