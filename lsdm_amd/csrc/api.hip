@@ -602,7 +602,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     prof_mark(c, K_FP4, st);
     // fp4 / fp3 also write the next finer stage's pre-multiplied interpolation operand (one more layer on their rows) when that stage
     // takes the pre-multiplied form
-    const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y && !c->fp2_reg;
+    const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y;
     if (fuse_y && c->fp4_pre)
         // fp4 in the pre-multiplied form too: Y4 = feat4 x Wb^T on the 16 coarse points of a cloud, the matrix pipe then contracts over the
         // 256 columns of points1 only (K = 256 instead of 768: a third of the fragments every 64-row tile streams from L2)
@@ -622,7 +622,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         const float* p1 = src ? static_cast<const float*>(c->inv_F1) : c->feat[0];
         const int* remap = src ? f.idx[0] : nullptr;
         if (c->fp2_reg) {
-            launch_fp_y(nc * 256, c->fpo3, c->fp_y[1], c->fp_ybuf[1], st);
+            if (!fuse_y) launch_fp_y(nc * 256, c->fpo3, c->fp_y[1], c->fp_ybuf[1], st);
             launch_fp_ps(nc, p1, remap, c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp2_s.w, c->fp2_s.b, c->fpo2, st);
         } else {
             launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,

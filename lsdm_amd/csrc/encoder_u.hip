@@ -885,9 +885,10 @@ __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(cons
     {
         const int row = tid >> 2, sub = tid & 3;
         const size_t o = ((size_t)c * N + n0 + row) * 3;
-        const float* r0 = yb + (size_t)nn_idx[o + 0] * C1;
-        const float* r1 = yb + (size_t)nn_idx[o + 1] * C1;
-        const float* r2 = yb + (size_t)nn_idx[o + 2] * C1;
+        const int dbg = keep_out >> 1;                       // timing experiments (LSDM_DBG_FP2): 1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs
+        const float* r0 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 0]) * C1;
+        const float* r1 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 1]) * C1;
+        const float* r2 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 2]) * C1;
         const float w0 = nn_w[o + 0], w1 = nn_w[o + 1], w2 = nn_w[o + 2];
         constexpr int PIECES = C1 / 16;                      // per thread
         // GB pieces x 3 rows in flight per batch: the phase is a chain of L2 round trips, so fewer, larger batches (registers
@@ -942,7 +943,8 @@ __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(cons
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
+    for (int q = 0; q < NCB; ++q)
+        if (!((keep_out >> 1) & 8)) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
     __syncthreads();
     // ---- phase D: layer-1 epilogue -> bufB, layer 2 (direct orientation) -> global -----------------------------------------------
 #pragma unroll
@@ -957,7 +959,8 @@ __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(cons
             acc_zero_h(a2);
             const int col = cb * 32 + (lane & 31);
             const float bv = l2.b[col];
-            mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
+            if (!((keep_out >> 1) & 4)) mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
+            if (((keep_out >> 1) & 2) && a2[0][0] != 12345.0f) continue;
 #pragma unroll
             for (int rb = 0; rb < T2::RB; ++rb)
 #pragma unroll
@@ -1036,9 +1039,11 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
         return;
     }
     if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
-    if (which == 2)
+    if (which == 2) {
+        static const int dbg = getenv("LSDM_DBG_FP2") ? atoi(getenv("LSDM_DBG_FP2")) : 0;
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
-                           none, nullptr, 1);
+                           none, nullptr, 1 | (dbg << 1));
+    }
     else if (ynext) {
         // LSDM_FP3_TM=128: 128-row tiles, one 8-wave work-group per CU (half the weight stream per row; measured slower, 175 vs 156 us:
         // two independent work-groups per CU cover each other's gather and barrier phases)
