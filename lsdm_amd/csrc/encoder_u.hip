@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
         const bool live = cent < total_centroids;
         if (!live) cent = total_centroids - 1;
         const long long c = cent / S;
-        if (dbg) { idx_n = wave; ci_n = 0; }      // timing experiment: every lane of a wave gathers the same row
+        if (dbg & 1) { idx_n = wave; ci_n = 0; }      // timing experiment: every lane of a wave gathers the same row
         const float* urow = U + ((size_t)c * NSRC + idx_n) * C1 + 8 * h;
         const float* vrow = V + ((size_t)c * NSRC + ci_n) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- layer 3 streamed: one 32 KB panel per pair of 32-channel blocks, direct orientation, max over the 32 neighbours
-#define PANEL_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
-#define PANEL_END(Q) lds_dma_wait(); __syncthreads(); }
+#define PANEL_BEGIN(Q) { if (!(dbg & 2)) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
+#define PANEL_END(Q) lds_dma_wait(); if (!(dbg & 4)) __syncthreads(); }
 #pragma unroll
         for (int q = 0; q < NPANEL; ++q) {
             PANEL_BEGIN(q)
