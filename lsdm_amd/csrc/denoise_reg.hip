@@ -12,8 +12,9 @@
 //     of channel block nb ARE the lane's k-slots of k-step 2 nb + s2 of the next layer; the host packs the weight fragments in that
 //     k order).  Weights go through LDS as PANELS of <= 32 KB shared by the 8 waves of the work-group (256 points per panel
 //     pass) in a ring of four slots, copied global -> LDS by the LDS-DMA path THREE panels ahead of their use (a panel step is
-//     only ~1 us of matrix work at one 32-point block per wave: with the copy one step ahead every barrier also waited for the
-//     L2 latency -- 62 -> 45 us per step); one barrier per panel.  Per step: [S x3 | pose2 | cex0 x3 | cex2 x4 | fin0];
+//     only ~1 us of matrix work at one 32-point block per wave; measured against two 48 KB buffers filled one step ahead the
+//     ring changes nothing -- 61 us per hoisted step either way: the stage is bound by its activations' VALU work, see
+//     DESIGN.md); one barrier per panel.  Per step: [S x3 | pose2 | cex0 x3 | cex2 x4 | fin0];
 //     pose_final.2 (3 rows zero-padded to one channel block) stays resident.
 //   * The timestep half of combine_extraction's pre-activation comes from ctext_kernel(kb0 = 0) (`ctime`; one tile per step when
 //     all chains share the timestep, one per (step, chain) otherwise), the text half from `ctext`: emb = GELU(ctime + ctext + b) is
