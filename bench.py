@@ -44,7 +44,7 @@ GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
 STAGE_KERNELS_BF16X3 = {
     "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64> (once per call in the loop-invariant schedule)",
     "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128>",
-    "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_u2_kernel<128,128,256>",
+    "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_p_kernel<128,128,256,12> (epilogues software-pipelined against the next block's MFMAs)",
     "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_w_kernel",
     "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y)",
     "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
@@ -189,6 +189,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if torch.cuda.device_count() < a.gpus:
+        sys.exit("bench.py: --gpus %d but only %d visible device(s) -- refusing to run ranks on shared GPUs" % (a.gpus, torch.cuda.device_count()))
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (python -m torch.distributed.run "
                  "--nproc-per-node %d bench.py --gpus %d ...) or run `python bench.py --gpus %d` directly" % (a.gpus, world, a.gpus, a.gpus, a.gpus))
@@ -229,7 +231,7 @@ def main():
     t0 = time.perf_counter()
     r.run(T - 1 - W, W, K, invariant=inv)
     ev[0].record()
-    gathered = gather_samples(r.x, dist)          # the path's only collective (RCCL all-gather over xGMI)
+    gathered = gather_samples(r.x, dist, agree=False)   # the path's only collective (RCCL all-gather over xGMI); sizes agreed in the warm-up
     ev[1].record()
     torch.cuda.synchronize()
     if dist:
@@ -239,11 +241,14 @@ def main():
     prof = r.ctx.profile_end()
     allgather_us = ev[0].elapsed_time(ev[1]) * 1e3 if dist else 0.0
     log("timed region %.3f s" % dt)
+    per_rank_dt = [dt]
     if dist:
         assert dist.get_world_size() == a.gpus
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_dt = [float(v) for v in every.cpu()]
+        dt = max(per_rank_dt)                     # the job's time is its slowest rank's
     assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
     x_final = r.x.clone()
 
@@ -279,16 +284,21 @@ def main():
     # The same K steps again (same inputs, same RNG draws, from the same x): once through the headline entry point WITHOUT the
     # HIP-event instrumentation of the timed region, once through the OTHER entry point; the three final samples must be
     # bit-identical (the invariant mode only moves FPS-order-independent work out of the loop).
-    def rerun(invariant):
+    def rerun(invariant, repeats=5):
         xi = x_start.clone()
         r.run(T - 1 - W, W, K, x=xi, invariant=invariant)      # warm
-        xi.copy_(x_start)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        r.run(T - 1 - W, W, K, x=xi, invariant=invariant)
-        torch.cuda.synchronize()
-        d = time.perf_counter() - t1
-        return {"value": K / d, "ms_per_step": d / K * 1e3, "steps": K, "dtype": a.precision,
+        ds = []
+        for _ in range(repeats):
+            xi.copy_(x_start)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r.run(T - 1 - W, W, K, x=xi, invariant=invariant)
+            torch.cuda.synchronize()
+            ds.append(time.perf_counter() - t1)
+        ds.sort()
+        d = ds[len(ds) // 2]
+        return {"value": K / d, "ms_per_step": d / K * 1e3, "steps": K, "dtype": a.precision, "repeats": repeats,
+                "value_is": "median of %d repeats of the same %d-step call" % (repeats, K), "value_min": K / ds[-1], "value_max": K / ds[0],
                 "final_sample_bit_identical_to_timed_region": bool(torch.equal(xi, x_final))}
     # INTEGRATION.md path B: one model.forward (lsdm_step, mode 0) per call -- conditioning, POSA branch and PointNet++ evaluated
     # every call, nothing amortised over steps
@@ -307,7 +317,9 @@ def main():
                 "entry_point": "SceneDiffusionModel.forward -> lsdm_step(mode 0), B=%d, host-drawn FPS starts uploaded per call" % B}
     fwd = forward_only()
     uninstrumented = rerun(inv)
-    uninstrumented["note"] = "the timed region repeated without lsdm_profile_begin (no HIP events between the launches)"
+    uninstrumented["note"] = ("the timed region repeated 5x without lsdm_profile_begin (no HIP events between the launches): median with "
+                              "min / max -- the box-to-box and run-to-run spread to hold `value` against")
+    res_spread = {"value_median": uninstrumented["value"], "value_min": uninstrumented["value_min"], "value_max": uninstrumented["value_max"]}
     other = rerun(not inv)
     other["entry_point"] = "lsdm_sample_steps" if inv else "lsdm_sample_steps_invariant"
     other["note"] = ("every stage recomputed every step (the reference's literal schedule of work)" if inv else
@@ -351,7 +363,10 @@ def main():
                    "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
                    "global_batch": B * world, "chains_per_gpu": B,
                    "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
+        "schedule": "loop-invariant (level-1 encoder work once per %d-step call, inside the timed call; bit-identical to strict)" % K if inv
+                    else "strict (every stage every step)",
         "rccl_ranks": world, "per_rank_seeds": [shard_seed(a.seed, q) for q in range(world)], "allgather_us": allgather_us,
+        "per_rank_ms_per_step": [round(v / K * 1e3, 4) for v in per_rank_dt],
         "roofline": {"bound": "mfma", "kernel": dom["name"],
                      "launches_of_the_stage": STAGE_KERNELS_BF16X3.get(dom["name"], dom["name"]) if a.precision == "bf16x3" else dom["name"],
                      "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
@@ -370,6 +385,7 @@ def main():
         res["hoisted_conditioning"] = hoisted
     res["forward_only"] = fwd
     res["uninstrumented"] = uninstrumented
+    res["repeat_spread"] = res_spread
     res["strict_recompute" if inv else "invariant_motion"] = other
     del r
     torch.cuda.empty_cache()

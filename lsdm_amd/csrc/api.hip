@@ -52,11 +52,9 @@ struct lsdm_ctx {
     // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
     // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
     DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
-    DenseH fp1_s{}, fp2_s{};     // fp1 + head / fp2 as register-chained blobs (encoder_reg.hip::fp_s_kernel, fp_ps_kernel)
-    int fp2_reg = getenv("LSDM_FP2_REG") ? atoi(getenv("LSDM_FP2_REG")) : 0;   // A/B switch (measured: 317 us vs 287 us for fp_pre_kernel)
+    DenseH fp1_s{};              // fp1 + head as a register-chained blob (encoder_reg.hip::fp_s_kernel)
     int fuse_y = getenv("LSDM_FUSE_Y") ? atoi(getenv("LSDM_FUSE_Y")) : 1;      // A/B switch: fp2's Y as an extra layer of the fp3 launch
     bool keep_taps = true;       // stage outputs that only feed a fused consumer (fp3) are still stored: off inside multi-step calls
-    int sa4_x = getenv("LSDM_SA4_X") ? atoi(getenv("LSDM_SA4_X")) : 2;         // A/B switch: sa4 on 0 sa_h (LDS-tiled), 1 sa_x (K-split wave pairs), 2 sa_w (one wave per SIMD, 512 registers)
     int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
     DenseH den_r{};              // the per-point denoiser as a register-chained blob (denoise_reg.hip)
     int den_reg = getenv("LSDM_DEN_REG") ? atoi(getenv("LSDM_DEN_REG")) : 1;   // A/B switch: 0 = the LDS-tiled denoise_h_kernel
@@ -359,41 +357,6 @@ bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const 
     return out->w && out->b;
 }
 
-// Fragment blob of encoder_reg.hip::fp_ps_kernel (fp2 on the pre-multiplied interpolation operand): per panel nb = 0..7
-//   [Wa = conv0[:, 0:64] block nb: 4 k-steps x np planes][conv1 columns of block nb: 4 channel blocks x 2 k-steps x np planes]
-// with the fragment element order of build_chain_blob (first layer: k-slot (s, h, j) = input channel 16 s + 8 h + j; second
-// layer: the accumulator order of the first layer's transposed product); biases [conv0 (256) | conv1 (128)], BatchNorm folded.
-bool build_fp2_blob(lsdm_ctx* c, int np, DenseH* out) {
-    const std::string pre = "pcd_backbone.fp2";
-    std::vector<float> W0, B0, W1, B1;
-    if (!fold_dense(c, pre + ".mlp_convs.0.weight", pre + ".mlp_convs.0.bias", pre + ".mlp_bns.0", 256, 320, W0, B0) ||
-        !fold_dense(c, pre + ".mlp_convs.1.weight", pre + ".mlp_convs.1.bias", pre + ".mlp_bns.1", 128, 256, W1, B1))
-        return false;
-    std::vector<uint16_t> blob;
-    auto frag = [&](const std::vector<float>& W, int K, int nb, int s, int pl, bool first) {
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-                const int n = nb * 32 + (lane & 31), h = lane >> 5;
-                const int k = first ? 16 * s + 8 * h + j : 32 * (s / 2) + 8 * (2 * (s % 2) + j / 4) + 4 * h + j % 4;
-                const float v = W[(size_t)n * K + k];
-                const uint16_t hi = f2bf(v);
-                blob.push_back(pl == 0 ? hi : f2bf(v - bf2f(hi)));
-            }
-    };
-    for (int nb1 = 0; nb1 < 8; ++nb1) {
-        for (int s = 0; s < 4; ++s)
-            for (int pl = 0; pl < np; ++pl) frag(W0, 320, nb1, s, pl, true);
-        for (int nb2 = 0; nb2 < 4; ++nb2)
-            for (int s2 = 0; s2 < 2; ++s2)
-                for (int pl = 0; pl < np; ++pl) frag(W1, 256, nb2, 2 * nb1 + s2, pl, false);
-    }
-    std::vector<float> biases = B0;
-    biases.insert(biases.end(), B1.begin(), B1.end());
-    out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
-    out->b = upload(c, biases.data(), biases.size());
-    return out->w && out->b;
-}
-
 // Fragment blob of denoise_reg.hip::denoise_r_kernel, fragments [nb][k-step s][plane][lane][8] per layer, layers back to back:
 //   S  = combination_extraction.0[:, 128:256] (6 x 8), pose_embedding.2 (4 x 4)           -- k-slot (s, h, j) = column 16 s + 8 h + j
 //   combination_extraction.0[:, 0:128] (6 x 8), combination_extraction.2 (4 x 12), pose_final.0 (2 x 8), pose_final.2 zero-padded
@@ -591,8 +554,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
             launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-            if (c->sa4_x) launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
-            else launch_sa_h_pre(nc, c->sa_U[1], c->sa_V[1], f.idx[3], lvl_xyz[4], f.ball[3], c->sa_h[3], c->feat[3], st);
+            launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
         } else if (l < c->sa_reg)
             launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
         else
@@ -621,13 +583,8 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         const bool src = skip_sa1 && inv_in_source_order(c);   // level-1 features in source order, read through f.idx[0]
         const float* p1 = src ? static_cast<const float*>(c->inv_F1) : c->feat[0];
         const int* remap = src ? f.idx[0] : nullptr;
-        if (c->fp2_reg) {
-            if (!fuse_y) launch_fp_y(nc * 256, c->fpo3, c->fp_y[1], c->fp_ybuf[1], st);
-            launch_fp_ps(nc, p1, remap, c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp2_s.w, c->fp2_s.b, c->fpo2, st);
-        } else {
-            launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
-                          DenseH{nullptr, nullptr}, nullptr, true, st);
-        }
+        launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
+                      DenseH{nullptr, nullptr}, nullptr, true, st);
     } else
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_mark(c, K_FP1, st);
@@ -939,7 +896,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                                                   {pb + ".conv2.weight", pb + ".conv2.bias", "", 3, 128, 32}};
                 std::vector<int> ident(128);
                 for (int k = 0; k < 128; ++k) ident[k] = k;
-                ok = build_chain_blob(c, layers, ident, np, &c->fp1_s) && build_fp2_blob(c, np, &c->fp2_s);
+                ok = build_chain_blob(c, layers, ident, np, &c->fp1_s);
             }
             // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
             {

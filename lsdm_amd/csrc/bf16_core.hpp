@@ -54,7 +54,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // hi / lo split of a PAIR of fp32 values: hi = bf16(v) (one v_cvt_pk_bf16_f32 for both), lo = bf16(v - hi) with v - hi formed by
 // v_dot2c_f32_bf16 straight from the packed hi pair (hi x (-1, 0) + v: exact, the difference is representable) -- no unpacking
-// of hi back to fp32: 3 VALU instructions per pair of values less than the convert / shift / subtract form.
+// of hi back to fp32: 3 VALU instructions per pair of values less than the convert / shift / subtract form.  (v_dot2c executes on
+// the matrix pipe's side -- profiles/r03_ubench_mfma_fill.txt: 4 of them per MFMA gap cost 47 ticks against 26 for plain VALU --
+// but the plain-VALU form measured no faster in any kernel, block-placed or software-pipelined: sa3 326 vs 323 us, sa2 305 vs 303.)
 template <int NP>
 __device__ __forceinline__ void split2(float v0, float v1, bf16x2& hi, bf16x2& lo) {
     hi[0] = (__bf16)v0; hi[1] = (__bf16)v1;

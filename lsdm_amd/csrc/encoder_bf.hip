@@ -478,13 +478,6 @@ void launch_fp4_y(int nc, const float* points1, const float* points2, const int*
                        64, 16, l[0], l[1], wb, none, nol, none, out, ynext, keep_out ? 1 : 0);
 }
 
-// sa4 with the first layer split across the grouping (encoder_u.hip): U, V of the level-3 points, cent = FPS indices of level 4
-void launch_sa_h_pre(int nc, const float* U, const float* V, const int* cent, const float* new_xyz, const int* ball, const DenseH* l,
-                     float* out, hipStream_t st) {
-    hipLaunchKernelGGL((sa_h_kernel<256, 256, 256, 512, 64, 8, 2, 1, true>), dim3(16 / 2 * nc), dim3(512), 0, st, nullptr, U, new_xyz, ball, 64, 16,
-                       l[0], l[1], l[2], out, V, cent);
-}
-
 void launch_sa_h(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const DenseH* l, void* out, hipStream_t st) {
     if (np == 2) launch_sa_h_t<2>(level, nc, src_xyz, src_feat, new_xyz, ball, l, out, st);

@@ -548,177 +548,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// fp2 as a register-chained stack (bf16x3) on top of the pre-multiplied interpolation operand (encoder_u.hip: the first FP layer
-// is linear in [p1 || sum_j w_j p2_j], Y = p2 x Wb^T per COARSE point):
-//     z = ReLU(Wa x p1 + sum_j w_j Y[nn_j] + b)   (64 -> 256),     out = ReLU(W2 x z + b2)   (256 -> 128)
-// A wave owns 32 fine points: p1 as four k-step fragments; the accumulators of a 32-channel block of z START from the three
-// interpolated Y pieces of the lane's own channels (16-byte gathers, requested one block ahead); the block's two k-step
-// fragments of z go straight into the four accumulators of the second layer (split-K: out += W2[:, 32 nb .. 32 nb + 31] z_nb),
-// so z never exists as a whole -- 64 accumulator registers instead of 128 operand registers.  Weights: eight 24 KB panels per
-// round of 32 NW points ([Wa block nb | W2 columns of block nb]), requested two panel steps ahead, one barrier per panel.
-// p1_remap (optional): row i of a cloud's points1 is points1[p1_remap[i]] (loop-invariant schedule).
-// blob (api.hip::build_fp2_blob): per panel nb [Wa: 4 k-steps x NP x 1 KiB][W2: 4 channel blocks x 2 k-steps x NP x 1 KiB];
-// biases [256 | 128].
-template <int NW, int NP>
-__global__ __launch_bounds__(NW * 64, 2) void fp_ps_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
-                                                            const float* __restrict__ y, const int* __restrict__ nn_idx,
-                                                            const float* __restrict__ nn_w, int N, int S, long long total_points,
-                                                            const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
-                                                            float* __restrict__ out, int dbg) {
-    constexpr int D1 = 64, C1 = 256, C2 = 128, NT = NW * 64;
-    constexpr int KS1 = D1 / 16, NB1 = C1 / 32, NB2 = C2 / 32;
-    constexpr int FA = KS1 * NP, FB = NB2 * 2 * NP, FP = FA + FB;   // fragments (1 KiB) per panel
-    constexpr int NPANEL = NB1;
-    constexpr int PIECES = FP * 64 / NT;
-    static_assert((FP * 64) % NT == 0 && NPANEL % 2 == 0, "panel split");
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FP * 512];
-    __shared__ __attribute__((aligned(16))) float bl[C1 + C2];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int e = tid; e < C1 + C2; e += NT) bl[e] = blob_b[e];
-    const int p = lane & 31, h = lane >> 5;
-
-    bf16x8 stage[2][PIECES];
-    auto fetch = [&](int q) {
-        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FP * 512);
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) stage[q & 1][i] = gload<bf16x8>(src + (size_t)(tid + i * NT) * 8);
-    };
-    auto commit = [&](int q) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) *reinterpret_cast<bf16x8*>(&wl[q & 1][(size_t)(tid + i * NT) * 8]) = stage[q & 1][i];
-    };
-    fetch(0);
-    commit(0);
-    fetch(1);
-    __syncthreads();
-
-    const long long rounds = total_points / (32 * NW);
-    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
-    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
-    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
-    int ni[3] = {0, 0, 0}, prow = 0;
-    float nw[3] = {0.0f, 0.0f, 0.0f};
-    auto request = [&](long long rd) {
-        const long long pt = rd * (32 * NW) + wave * 32 + p;
-        const size_t o = (size_t)pt * 3;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { ni[j] = nn_idx[o + j]; nw[j] = nn_w[o + j]; }
-        if (dbg == 1) { ni[0] = ni[1] = ni[2] = (int)(pt % S); }
-        if (dbg == 2) { ni[0] = ni[1] = ni[2] = (int)(wave * 4); }
-        prow = p1_remap ? p1_remap[pt] : (int)(pt % N);
-    };
-    if (rbeg < rend) request(rbeg);
-    for (long long rd = rbeg; rd < rend; ++rd) {
-        const long long pt0 = rd * (32 * NW) + wave * 32;
-        const long long c = pt0 / N;
-        const float* yb = y + (size_t)c * S * C1 + 4 * h;
-        const float* r0 = yb + (size_t)ni[0] * C1;
-        const float* r1 = yb + (size_t)ni[1] * C1;
-        const float* r2 = yb + (size_t)ni[2] * C1;
-        const float w0 = nw[0], w1 = nw[1], w2 = nw[2];
-        const float* prow_p = points1 + ((size_t)c * N + prow) * D1 + 8 * h;
-        // the three Y pieces of channel block nb for this lane's accumulator quads (channels 32 nb + 8 q + 4 h .. + 3), row by row
-        f32x4 ya[4], yb4[4], yd[4];
-        auto yload = [&](int nb) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ya[q] = load4f(r0 + 32 * nb + 8 * q);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) yb4[q] = load4f(r1 + 32 * nb + 8 * q);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) yd[q] = load4f(r2 + 32 * nb + 8 * q);
-        };
-        bf16x8 xh[KS1], xl[KS1];
-        {
-            f32x4 g0[KS1], g1[KS1];
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) { g0[s] = load4f(prow_p + 16 * s); g1[s] = load4f(prow_p + 16 * s + 4); }
-            yload(0);
-            if (rd + 1 < rend) request(rd + 1);
-#pragma unroll
-            for (int s = 0; s < KS1; ++s) {
-                const float v[8] = {g0[s][0], g0[s][1], g0[s][2], g0[s][3], g1[s][0], g1[s][1], g1[s][2], g1[s][3]};
-                split8<NP>(v, xh[s], xl[s]);
-            }
-        }
-        f32x16 acc2[NB2];
-#pragma unroll
-        for (int nb2 = 0; nb2 < NB2; ++nb2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[nb2][r] = 0.0f;
-#define FPP_PANEL(Q)                                                                                                         \
-    {                                                                                                                        \
-        fetch(((Q) + 2) % NPANEL);                                                                                           \
-        const __bf16* W = &wl[(Q) & 1][0];                                                                                   \
-        int lz = 0;                                                                                                          \
-        asm volatile("" : "+v"(lz));                                                                                         \
-        f32x16 acc;                                                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                      \
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + lz + 32 * (Q) + 8 * q + 4 * h);                            \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
-                acc[4 * q + j] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(ya[q][j], w0), __fmul_rn(yb4[q][j], w1)), __fmul_rn(yd[q][j], w2)), bq[j]); \
-        }                                                                                                                    \
-        if ((Q) + 1 < NB1) yload((Q) + 1);                                                                                   \
-        _Pragma("unroll") for (int s = 0; s < KS1; ++s) {                                                                    \
-            const bf16x8 wh = wfrag_lds<NP>(W, KS1, 0, s, 0, lane);                                                          \
-            if constexpr (NP == 2) {                                                                                         \
-                const bf16x8 wlo = wfrag_lds<NP>(W, KS1, 0, s, 1, lane);                                                     \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc, 0, 0, 0);                                      \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh[s], acc, 0, 0, 0);                                     \
-            }                                                                                                                \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc, 0, 0, 0);                                          \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        bf16x8 zh[2], zl[2];                                                                                                 \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                                   \
-            float v[8];                                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);                                     \
-            split8<NP>(v, zh[s2], zl[s2]);                                                                                   \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        _Pragma("unroll") for (int nb2 = 0; nb2 < NB2; ++nb2) {                                                              \
-            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                               \
-                const bf16x8 wh = wfrag_lds<NP>(W + FA * 512, 2, nb2, s2, 0, lane);                                          \
-                if constexpr (NP == 2) {                                                                                     \
-                    const bf16x8 wlo = wfrag_lds<NP>(W + FA * 512, 2, nb2, s2, 1, lane);                                     \
-                    acc2[nb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s2], wh, acc2[nb2], 0, 0, 0);                     \
-                    acc2[nb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s2], wlo, acc2[nb2], 0, 0, 0);                    \
-                }                                                                                                            \
-                acc2[nb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s2], wh, acc2[nb2], 0, 0, 0);                         \
-            }                                                                                                                \
-            __builtin_amdgcn_sched_barrier(0);                                                                               \
-        }                                                                                                                    \
-        commit(((Q) + 1) % NPANEL);                                                                                          \
-        __syncthreads();                                                                                                     \
-    }
-        FPP_PANEL(0) FPP_PANEL(1) FPP_PANEL(2) FPP_PANEL(3) FPP_PANEL(4) FPP_PANEL(5) FPP_PANEL(6) FPP_PANEL(7)
-#undef FPP_PANEL
-        // ---- second-layer epilogue: D[point][channel], 32 consecutive channels of a row per half-wave
-#pragma unroll
-        for (int nb2 = 0; nb2 < NB2; ++nb2) {
-            const float bv = bl[C1 + 32 * nb2 + p];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) out[(size_t)(pt0 + acc_row(r, lane)) * C2 + 32 * nb2 + p] = reluf(acc2[nb2][r] + bv);
-        }
-    }
-}
-
-void launch_fp_ps(int nc, const float* points1, const int* p1_remap, const float* y, const int* nn_idx, const float* nn_w,
-                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
-    static const int dbg = getenv("LSDM_DBG_GATHER") ? atoi(getenv("LSDM_DBG_GATHER")) : 0;
-    const long long tot = (long long)nc * 1024;
-    hipLaunchKernelGGL((fp_ps_kernel<8, 2>), dim3(256), dim3(512), 0, st, points1, p1_remap, y, nn_idx, nn_w, 1024, 256, tot, blob_w, blob_b, out, dbg);
-}
-
 void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
                  hipStream_t st) {
+    // timing experiment (compile-time only, `make TIMING=1`; results are wrong with it): 1 sequential rows, 2 one row per wave
+#ifdef LSDM_TIMING_EXPERIMENTS
     static const int dbg = getenv("LSDM_DBG_GATHER") ? atoi(getenv("LSDM_DBG_GATHER")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     const long long tot = (long long)nc * 1024;
-    // LSDM_FP1_WG=4: two independent 4-wave work-groups per CU on half-layer panels (A/B: their phases drift apart, the weights are
-    // streamed twice)
-    static const int wg4 = getenv("LSDM_FP1_WG") ? atoi(getenv("LSDM_FP1_WG")) == 4 : 0;
-    if (wg4) hipLaunchKernelGGL((fp_s_kernel<4, 2, 2>), dim3(512), dim3(256), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
-    else hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
+    hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
 }
 
 void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,

@@ -9,8 +9,9 @@
 // part of U and V in plain fp32 FMAs; results differ from the concat form at fp32 rounding level only.
 //
 //   lin_u_kernel : U = X x Wf^T + xyz x Wx^T + b,  V = xyz x Wx^T     (rows = source points of all clouds)
-//   sa_u_kernel  : register-chained two-layer stack on ReLU(U_j - V_i) + max over the 32 neighbours (sa3; cf. sa_s_kernel)
+//   sa_p_kernel (sa3) / sa_w_kernel (sa4) / sa_ur_kernel (sa2) : register-chained two-layer stack on ReLU(U_j - V_i) + max over the 32 neighbours
 #include <cstdlib>
+#include <utility>
 
 #include "bf16_core.hpp"
 #include "kernels.hpp"
@@ -130,175 +131,101 @@ __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// Register-chained stack (cf. encoder_reg.hip::sa_s_kernel) on ReLU(U_j - V_i): layer 2 (C1 -> C2) and layer 3 (C2 -> C3, max
-// over the 32 neighbours).  blob: [W2 frags: C2/32 x C1/16 x NP x 512][W3: C3/32 x C2/16 x NP x 512], biases [b2 | b3];
-// the k-slot (s, h, j) of layer 2 is channel 16 s + 8 h + j of U (identity order), layer 3 follows the accumulator order.
+// sa_p_kernel (sa3): register-chained stack (cf. encoder_reg.hip::sa_r_kernel) on ReLU(U_j - V_i): layer 2 (C1 -> C2) RESIDENT in LDS
+// (64 KB of fragments for the life of the persistent work-group), layer 3 (C2 -> C3, max over the 32 neighbours) streamed through two
+// 32 KB panels by LDS-DMA (0.5 KB of weights per point; streaming both layers was L2-bound in round 2), with the epilogues
+// SOFTWARE-PIPELINED against the next channel block's matrix instructions.
+// blob: [W2 frags: C2/32 x C1/16 x NP x 512][W3: C3/32 x C2/16 x NP x 512], biases [b2 | b3]; the k-slot (s, h, j) of layer 2 is
+// channel 16 s + 8 h + j of U (identity order), layer 3 follows the accumulator order.
+//
+// Round 2's form of this kernel (sa_u2_kernel: a block's MFMAs, then its epilogue) met a barrier four times per round, so the waves
+// of a SIMD ran in the same phase: all want the matrix pipe, then all run their ReLU + hi/lo split (or max-pool) epilogue while the
+// pipe idles -- nothing overlaps (tools/ubench/gen_mfma_fill.py, profiles/r03_ubench_mfma_fill.txt: 8 MFMAs followed by a block of
+// 40 VALU instructions cost 32.0 ticks per MFMA at two waves per SIMD, the same instructions interleaved 5 per MFMA 25.9 against
+// 24.8 for bare MFMAs).  Here a wave ping-pongs two accumulators: the epilogue of channel block n reads accumulator n & 1 while the 24 matrix instructions
+// of block n + 1 fill the other, and __builtin_amdgcn_sched_group_barrier pins the interleave (1 MFMA : 2 VALU in layer 2, 1 : 1 in
+// layer 3).  The cross-half max of the pooling uses v_permlane32_swap (VALU) instead of ds_bpermute, and both half-waves store
+// (same value, same address), so the pooled epilogue has no branch and no LDS round trip.  Twelve waves (three per SIMD) share a
+// panel pass.  Same-box A/B at B = 64 (gpurun_out/abv_*.log, round 3): sa_u2 355-360 us per launch incl. the 48 us U/V launch, this
+// kernel with 8 waves 342-345, with 12 waves 320-324; results bit-identical to sa_u2 (same products, same accumulation order).
+// max(m[l], m[l ^ 32]) in every lane: v_permlane32_swap exchanges the upper half of its first operand with the lower half of its
+// second, so after swapping two copies of m one holds m[l & 31] and the other m[(l & 31) + 32] in all lanes.  Written as asm: with
+// the builtin hipcc (ROCm 7.2) folds the max over the two results of one swap of a value with itself away.
+__device__ __forceinline__ float max_halves(float m) {
+    float a = m, b = m;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// scheduling pattern of one channel block of KS k-steps (3 MFMAs each) next to NV VALU instructions per MFMA: per k-step two LDS
+// fragment reads, then MFMA / VALU alternating; the first LEAD MFMAs run without VALU (the epilogue they cover reads the previous
+// block's accumulator, whose last MFMA is still in flight)
+template <int KS, int NV, int LEAD>
+__device__ __forceinline__ void sgb_block() {
+    static_for<KS>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+        static_for<3>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (3 * s + m >= LEAD) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        });
+    });
+}
+
 template <int C1, int C2, int C3, int NW, int NP>
-__global__ __launch_bounds__(NW * 64) void sa_u_kernel(const float* __restrict__ U, const float* __restrict__ V,
+__global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                         const int* __restrict__ cent_idx, const int* __restrict__ ball, int NSRC, int S,
                                                         long long total_centroids, const __bf16* __restrict__ blob_w,
                                                         const float* __restrict__ blob_b, float* __restrict__ out) {
-    constexpr int NT = NW * 64;
-    constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
-    constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
-    constexpr int F2 = KS2 * NP, F3 = KS3 * NP;
-    constexpr int FMAX = F2 > F3 ? F2 : F3;
-    constexpr int W2E = NB2 * F2 * 512;
-    constexpr int NPANEL = NB2 + NB3;
-    static_assert(NPANEL % 2 == 0, "panel count must be even (double-buffer parity is compile-time)");
-    constexpr int PIECES = (FMAX * 64 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FMAX * 512];
-    __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
-    const float* b2 = bl;
-    const float* b3 = bl + C2;
-    const int p = lane & 31, h = lane >> 5;
-
-    auto panel_off = [&](int q) -> int { return q < NB2 ? q * F2 * 512 : W2E + (q - NB2) * F3 * 512; };
-    auto panel_nf = [&](int q) -> int { return q < NB2 ? F2 : F3; };
-    bf16x8 stage[PIECES];
-    auto fetch = [&](int q) {
-        const __bf16* src = blob_w + panel_off(q);
-        src = opaque_ptr(src);   // keeps the (round-invariant) panel fetches inside the persistent loop, as global loads
-        const int n16 = panel_nf(q) * 64;
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int e = tid + i * NT;
-            if (e < n16) stage[i] = gload<bf16x8>(src + (size_t)e * 8);
-        }
-    };
-    auto commit = [&](int q) {
-        const int n16 = panel_nf(q) * 64;
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            const int e = tid + i * NT;
-            if (e < n16) *reinterpret_cast<bf16x8*>(&wl[q & 1][(size_t)e * 8]) = stage[i];
-        }
-    };
-    fetch(0);
-    commit(0);
-    __syncthreads();
-
-    const long long rounds = (total_centroids + NW - 1) / NW;
-    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
-    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
-    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
-    for (long long rd = rbeg; rd < rend; ++rd) {
-        long long cent = rd * NW + wave;
-        const bool live = cent < total_centroids;
-        if (!live) cent = total_centroids - 1;
-        const long long c = cent / S;
-        const int idx = ball[cent * kNSample + p];
-        // layer-2 operand fragments: ReLU(U_j - V_i), this lane's k-slots of step s = channels 16 s + 8 h .. + 7
-        const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
-        const float* vrow = V + ((size_t)c * NSRC + cent_idx[cent]) * C1 + 8 * h;
-        bf16x8 yh[KS2], yl[KS2];
-        {
-            f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
-#pragma unroll
-            for (int s = 0; s < KS2; ++s) {
-                u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
-                v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
-            }
-#pragma unroll
-            for (int s = 0; s < KS2; ++s) {
-                const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
-                                    reluf(u1[s][0] - v1[s][0]), reluf(u1[s][1] - v1[s][1]), reluf(u1[s][2] - v1[s][2]), reluf(u1[s][3] - v1[s][3])};
-                split8u<NP>(t, yh[s], yl[s]);
-            }
-        }
-        bf16x8 zh[KS3], zl[KS3];
-#define PANEL_BEGIN(Q) { fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz));
-#define PANEL_END(Q) commit(((Q) + 1) % NPANEL); __syncthreads(); }
-#pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) {
-            PANEL_BEGIN(nb)
-            f32x16 acc;
-            mma_panel_u<KS2, NP, true>(acc, W, yh, yl, lane);
-            relu_split_pair_u<NP>(acc, b2 + lz + 32 * nb, h, zh[2 * nb], zl[2 * nb], zh[2 * nb + 1], zl[2 * nb + 1]);
-            PANEL_END(nb)
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB3; ++nb) {
-            PANEL_BEGIN(NB2 + nb)
-            f32x16 acc;
-            mma_panel_u<KS3, NP, false>(acc, W, zh, zl, lane);
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (live && lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[nb * 32 + lane]);
-            PANEL_END(NB2 + nb)
-        }
-#undef PANEL_BEGIN
-#undef PANEL_END
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// sa_u2_kernel: the same stack with layer 2 RESIDENT in LDS and only layer 3 streamed.
-//
-// sa_u_kernel moves every weight panel of both layers from L2 into LDS once per round of NW = 4 centroids (192 KB per 128
-// points): at two work-groups per CU that is ~100 GB/s per CU, ~26 TB/s on the chip -- the L2 limit, not the matrix pipe, sets
-// its pace (38 % MFMA busy).  Here a work-group has 8 waves (one per centroid, 256 points per round), keeps the 64 KB of
-// layer-2 fragments in LDS for its whole life (no barrier inside layer 2: the waves drift apart and overlap their epilogues
-// with each other's MFMAs) and streams the 128 KB of layer 3 through two 16 KB buffers: 0.5 KB per point instead of 1.5 KB.
-// The bias of a transposed block initialises its accumulators (the ds_read lands in the accumulator registers: no zeroing,
-// no add in the epilogue).
-template <int C1, int C2, int C3, int NW, int NP>
-__global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                                         const int* __restrict__ cent_idx, const int* __restrict__ ball, int NSRC, int S,
-                                                         long long total_centroids, const __bf16* __restrict__ blob_w,
-                                                         const float* __restrict__ blob_b, float* __restrict__ out, int dbg) {
+    static_assert(NP == 2, "bf16x3 only");
     constexpr int NT = NW * 64;
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
     constexpr int F2 = KS2 * NP, F3 = KS3 * NP;
     constexpr int W2E = NB2 * F2 * 512;
-    constexpr int PB = 2;                                     // channel blocks per layer-3 panel (32 KB): 4 barriers per round
-    constexpr int NPANEL = NB3 / PB, FP = PB * F3;            // fragments (1 KiB) per panel
-    static_assert(NB3 % PB == 0 && NPANEL % 2 == 0, "panel count must be even (double-buffer parity is compile-time)");
-    static_assert(FP % NW == 0, "panel split over the waves");
+    constexpr int PB = 2;
+    constexpr int NPANEL = NB3 / PB, FP = PB * F3;
+    static_assert(NB3 % PB == 0 && NPANEL % 2 == 0 && NB2 % 2 == 0, "ping-pong parity is compile-time");
+    constexpr int NLD = NW > 8 ? 8 : NW;                      // waves that copy panels
+    static_assert(FP % NLD == 0, "panel split over the waves");
     __shared__ __attribute__((aligned(16))) __bf16 w2[W2E];
     __shared__ __attribute__((aligned(16))) __bf16 wl[2][FP * 512];
     __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     for (int e = tid; e < W2E / 8; e += NT) *reinterpret_cast<bf16x8*>(w2 + (size_t)e * 8) = *reinterpret_cast<const bf16x8*>(blob_w + (size_t)e * 8);
     for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
-    const float* b2 = bl;
-    const float* b3 = bl + C2;
     const int p = lane & 31, h = lane >> 5;
     const __bf16* w3g = blob_w + W2E;
-
-    // Layer-3 panel q -> LDS buffer q & 1 by LDS-DMA (no staging registers), requested one panel step ahead: a step is 48 MFMAs
-    // per wave (~3k cycles with two waves per SIMD), the copy is 4 KiB per wave
     auto fetch = [&](int q) {
-        const __bf16* src = opaque_ptr(w3g + (size_t)q * FP * 512);   // (round-invariant: keep the copy inside the loop)
+        const __bf16* src = opaque_ptr(w3g + (size_t)q * FP * 512);
+        if (wave < NLD) {
 #pragma unroll
-        for (int i = 0; i < FP / NW; ++i) {
-            const int fr = wave + i * NW;
-            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
+            for (int i = 0; i < FP / NLD; ++i) {
+                const int fr = wave + i * NLD;
+                lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
+            }
         }
     };
     fetch(0);
     lds_dma_wait();
     __syncthreads();
 
-    const long long rounds = (total_centroids + NW - 1) / NW;
-    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
-    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
-    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
-    // the neighbour / centroid indices of a round are requested during the previous round (first of two dependent latencies)
-    auto cent_of = [&](long long rd) { const long long ce = rd * NW + wave; return ce < total_centroids ? ce : total_centroids - 1; };
+    const int total = (int)total_centroids;
+    const int rounds = (total + NW - 1) / NW;
+    const int rchunk = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int rbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
+    const int rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    auto cent_of = [&](int rd) { const int ce = rd * NW + wave; return ce < total ? ce : total - 1; };
     int idx_n = 0, ci_n = 0;
-    if (rbeg < rend) { const long long ce = cent_of(rbeg); idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
-    for (long long rd = rbeg; rd < rend; ++rd) {
-        long long cent = rd * NW + wave;
-        const bool live = cent < total_centroids;
-        if (!live) cent = total_centroids - 1;
-        const long long c = cent / S;
-        if (dbg & 1) { idx_n = wave; ci_n = 0; }      // timing experiment: every lane of a wave gathers the same row
+    if (rbeg < rend) { const int ce = cent_of(rbeg); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
+    for (int rd = rbeg; rd < rend; ++rd) {
+        const int cent = cent_of(rd);        // (a wave past the end repeats the last centroid: same values, same addresses)
+        const int c = cent / S;
         const float* urow = U + ((size_t)c * NSRC + idx_n) * C1 + 8 * h;
         const float* vrow = V + ((size_t)c * NSRC + ci_n) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
@@ -309,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
                 u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
-            if (rd + 1 < rend) { const long long ce = cent_of(rd + 1); idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
+            if (rd + 1 < rend) { const int ce = cent_of(rd + 1); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
@@ -317,63 +244,100 @@ __global__ __launch_bounds__(NW * 64) void sa_u2_kernel(const float* __restrict_
                 split8u<NP>(t, yh[s], yl[s]);
             }
         }
-        // ---- layer 2 from the resident fragments: no barrier, accumulators start from the bias
         bf16x8 zh[KS3], zl[KS3];
-#pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) {
-            int lz = 0;
-            asm volatile("" : "+v"(lz));      // opaque zero: the (round-invariant) LDS reads stay inside the loop
-            const float* bq = b2 + lz + 32 * nb + 4 * h;
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bq + 8 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bv[j];
-            }
-            const __bf16* W = w2 + lz + (size_t)nb * F2 * 512;
-#pragma unroll
-            for (int s = 0; s < KS2; ++s) {
-                const bf16x8 wh = wfrag_lds_u<NP>(W, KS2, 0, s, 0, lane);
-                if constexpr (NP == 2) {
-                    const bf16x8 wlo = wfrag_lds_u<NP>(W, KS2, 0, s, 1, lane);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yl[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, yh[s], acc, 0, 0, 0);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, yh[s], acc, 0, 0, 0);
-                if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-            }
+        f32x16 acc[2];
+        int lz = 0;
+        asm volatile("" : "+v"(lz));          // opaque zero: the (round-invariant) LDS reads stay inside the loop
+        // weight fragments travel through a three-slot register ring, requested two k-steps ahead of their MFMAs (the LDS latency
+        // of a just-in-time read is exposed on every k-step otherwise: both waves of a SIMD run in lockstep between the barriers)
+        bf16x8 fh[3], fl[3];
+        auto frag = [&](const __bf16* W, int KS, int t, bf16x8& oh, bf16x8& ol) {      // flat step t of a stream of blocks of KS k-steps
+            oh = wfrag_lds_u<NP>(W, KS, 0, t, 0, lane);
+            ol = wfrag_lds_u<NP>(W, KS, 0, t, 1, lane);
+        };
+        auto l2_epi = [&](auto nb_, const f32x16& a) {
+            constexpr int nb = decltype(nb_)::value;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);
+                for (int j = 0; j < 8; ++j) v[j] = reluf(a[8 * s2 + j]);
                 split8u<NP>(v, zh[2 * nb + s2], zl[2 * nb + s2]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- layer 3 streamed: one 32 KB panel per pair of 32-channel blocks, direct orientation, max over the 32 neighbours
-#define PANEL_BEGIN(Q) { if (!(dbg & 2)) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
-#define PANEL_END(Q) lds_dma_wait(); if (!(dbg & 4)) __syncthreads(); }
+        };
+        // max over the 32 rows of block nb (ReLU(x + b) is monotone: pool first); both half-waves store the same values
+        auto l3_epi = [&](int nb, const f32x16& a) {
+            float m = a[0];
 #pragma unroll
-        for (int q = 0; q < NPANEL; ++q) {
-            PANEL_BEGIN(q)
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, a[r]);
+            m = max_halves(m);
+            out[(size_t)cent * C3 + nb * 32 + p] = reluf(m + bl[lz + C2 + nb * 32 + p]);
+        };
+        // ---- layer 2 (resident fragments): one stream of NB2 x KS2 k-steps; block nb accumulates in acc[nb & 1] while the
+        // epilogue of block nb - 1 reads the other accumulator
+        const __bf16* W2p = w2 + lz;
+        frag(W2p, KS2, 0, fh[0], fl[0]);
+        frag(W2p, KS2, 1, fh[1], fl[1]);
+        static_for<NB2>([&](auto nb_) {
+            constexpr int nb = decltype(nb_)::value;
+            f32x16& a = acc[nb & 1];
+            // (source order: the epilogue of the previous block first -- the pattern below moves this block's MFMAs up between its
+            // instructions wherever the data allows)
+            if constexpr (nb > 0) l2_epi(std::integral_constant<int, (nb > 0 ? nb - 1 : 0)>{}, acc[(nb - 1) & 1]);
+            const float* bq = bl + lz + 32 * nb + 4 * h;
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int nb = q * PB + u;
-                f32x16 acc;
-                mma_panel_u<KS3, NP, false>(acc, W + (size_t)u * F3 * 512, zh, zl, lane);
-                float m = acc[0];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bq + 8 * q);
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (live && lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[lz + nb * 32 + lane]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 4; ++j) a[4 * q + j] = bv[j];
             }
-            PANEL_END(q)
-        }
-#undef PANEL_BEGIN
-#undef PANEL_END
+            static_for<KS2>([&](auto s_) {
+                constexpr int s = decltype(s_)::value, t = nb * KS2 + s;
+                // (past the end of layer 2 the ring continues with the first k-steps of layer 3's panel 0, published a round ago)
+                if constexpr (t + 2 < NB2 * KS2) frag(W2p, KS2, t + 2, fh[(t + 2) % 3], fl[(t + 2) % 3]);
+                else frag(&wl[0][0] + lz, KS3, t + 2 - NB2 * KS2, fh[(t + 2) % 3], fl[(t + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0x47f);      // the fragment reads keep their place two k-steps ahead; everything else may move
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[t % 3], yl[s], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[t % 3], yh[s], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[t % 3], yh[s], a, 0, 0, 0);
+            });
+            if constexpr (nb > 0) sgb_block<KS2, 3, 2>();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- layer 3 (streamed panels of PB = 2 blocks): block j accumulates in acc[j & 1]; its pooled epilogue runs under block j + 1
+        static_for<NPANEL>([&](auto q_) {
+            constexpr int q = decltype(q_)::value;
+            fetch((q + 1) % NPANEL);
+            const __bf16* W = &wl[q & 1][0] + lz;
+            if constexpr (q > 0) {                        // a new panel: its first two k-steps can only be requested after the barrier
+                frag(W, KS3, 0, fh[0], fl[0]);
+                frag(W, KS3, 1, fh[1], fl[1]);
+            }
+            static_for<PB>([&](auto u_) {
+                constexpr int u = decltype(u_)::value, j = q * PB + u;
+                f32x16& a = acc[j & 1];
+                // the previous block's epilogue first (block 0 needs the last two k-steps of z that layer 2's last epilogue produces)
+                if constexpr (j == 0) l2_epi(std::integral_constant<int, NB2 - 1>{}, acc[(NB2 - 1) & 1]);
+                else l3_epi(j - 1, acc[(j - 1) & 1]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+                static_for<KS3>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value, t = u * KS3 + s;
+                    constexpr int base = q == 0 ? (NB2 * KS2) % 3 : 0;   // ring slot of the panel's step 0 (panel 0 continues layer 2's ring)
+                    if constexpr (t + 2 < PB * KS3) frag(W, KS3, t + 2, fh[(base + t + 2) % 3], fl[(base + t + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0x47f);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], fh[(base + t) % 3], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], fl[(base + t) % 3], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], fh[(base + t) % 3], a, 0, 0, 0);
+                });
+                if constexpr (j == 0) sgb_block<KS3, 3, 2>();
+                else sgb_block<KS3, 1, 2>();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            lds_dma_wait();
+            __syncthreads();
+        });
+        l3_epi(NB3 - 1, acc[(NB3 - 1) & 1]);
     }
 }
 
@@ -394,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     constexpr int W2E = NB2 * KS2 * NP * 512, W3E = NB3 * KS3 * NP * 512;
     __shared__ __attribute__((aligned(16))) __bf16 wl[W2E + W3E];
     __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     for (int e = tid; e < (W2E + W3E) / 8; e += NW * 64)
         *reinterpret_cast<bf16x8*>(wl + (size_t)e * 8) = *reinterpret_cast<const bf16x8*>(blob_w + (size_t)e * 8);
     for (int e = tid; e < C2 + C3; e += NW * 64) bl[e] = blob_b[e];
@@ -404,14 +368,23 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     const float* b2 = bl;
     const float* b3 = bl + C2;
     const int p = lane & 31, h = lane >> 5;
-    const long long chunk = ((total_centroids + gridDim.x - 1) / gridDim.x + NW - 1) / NW * NW;
-    const long long cbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk;
-    const long long cend = cbeg + chunk < total_centroids ? cbeg + chunk : total_centroids;
-    for (long long cent = cbeg + wave; cent < cend; cent += NW) {
-        const long long c = cent / S;
-        int idx = ball[cent * kNSample + p];
-        int ci = cent_idx[cent];
-        if (remap) { idx = remap[c * NSRC + idx]; ci = remap[c * NSRC + ci]; }
+    // 32-bit index arithmetic (a 64-bit division per centroid costs ~60 instructions); the neighbour / centroid indices of a
+    // centroid -- two dependent loads when they go through `remap` -- are requested one iteration ahead
+    const int total = (int)total_centroids;
+    const int chunk = ((total + (int)gridDim.x - 1) / (int)gridDim.x + NW - 1) / NW * NW;
+    const int cbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk;
+    const int cend = cbeg + chunk < total ? cbeg + chunk : total;
+    int idx_n = 0, ci_n = 0;
+    auto request = [&](int ce) {
+        const int cc = ce / S;
+        idx_n = ball[(size_t)ce * kNSample + p];
+        ci_n = cent_idx[ce];
+        if (remap) { idx_n = remap[(size_t)cc * NSRC + idx_n]; ci_n = remap[(size_t)cc * NSRC + ci_n]; }
+    };
+    if (cbeg + wave < cend) request(cbeg + wave);
+    for (int cent = cbeg + wave; cent < cend; cent += NW) {
+        const int c = cent / S;
+        const int idx = idx_n, ci = ci_n;
         const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
         const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
@@ -422,6 +395,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                 u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
+            if (cent + NW < cend) request(cent + NW);
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
@@ -478,190 +452,11 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
             float m = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (lane < 32) out[(size_t)cent * C3 + nb * 32 + lane] = reluf(m + b3[nb * 32 + lane]);
+            m = max_halves(m);      // both half-waves store the same values: no branch, no LDS round trip
+            out[(size_t)cent * C3 + nb * 32 + p] = reluf(m + b3[nb * 32 + p]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// sa_x_kernel: the WIDE level (sa4: 256 -> 256 -> 512 on ReLU(U_j - V_i)) with the contraction split across a PAIR of waves.
-//
-// sa_h_kernel keeps a 64-row tile in LDS and every work-group streams all 768 KB of layer-2/3 fragments from L2 for those
-// 64 rows: 3.5 GB per step at B = 64 -- the L2, not the matrix pipe, sets its pace.  Registers cannot hold a 256-wide operand
-// for two chained layers (128 + 128 VGPRs per 32 rows), so here TWO waves share a centroid's 32 rows: wave (rb, kh) carries
-// channels 128 kh .. 128 kh + 127 of the layer operand (64 VGPRs) and contracts every channel block over ITS half of K; the
-// partial 32 x 32 block goes to the wave that owns the block through a 4 KB LDS slot, and the owner finishes it one panel step
-// later (sum, bias, ReLU, hi/lo split into its own K-half of the next layer; for the last layer max over the 32 rows) -- next to
-// the MFMAs of the following panel.  A work-group = 4 centroids x 2 halves = 128 rows per pass over the weights: 24 panels of
-// 32 KB (one channel block x all of K; the two halves read disjoint k-steps of it), staged global -> registers -> LDS two panel
-// steps ahead, one barrier per panel (it also orders the exchange slots).  Weight traffic 6 KB per row instead of 12 KB.
-// blob: build_chain_blob({conv1 256 x 256, conv2 512 x 256}, identity first map): [nb][s = 0..15][plane][lane][8]; biases [256|512].
-template <int NP>
-__global__ __launch_bounds__(512, 2) void sa_x_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                                       const int* __restrict__ cent_idx, const int* __restrict__ ball,
-                                                       long long total_centroids, const __bf16* __restrict__ blob_w,
-                                                       const float* __restrict__ blob_b, float* __restrict__ out) {
-    constexpr int C1 = 256, C2 = 256, C3 = 512, NSRC = 64, S = 16, NW = 8, NT = NW * 64;
-    constexpr int KSH = C1 / 32;                              // k-steps of one K-half
-    constexpr int NB2 = C2 / 32, NB3 = C3 / 32, NPANEL = NB2 + NB3;
-    constexpr int FP = 2 * KSH * NP;                          // fragments (1 KiB) per panel
-    constexpr int PIECES = FP * 64 / NT;
-    static_assert(C1 == C2 && NPANEL % 2 == 0 && (FP * 64) % NT == 0, "panel split");
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FP * 512];
-    __shared__ __attribute__((aligned(16))) float exch[2][4][16 * 64];
-    __shared__ __attribute__((aligned(16))) float bl[C2 + C3];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), rb = wave & 3, kh = wave >> 2;
-    for (int e = tid; e < C2 + C3; e += NT) bl[e] = blob_b[e];
-    const int p = lane & 31, h = lane >> 5;
-
-    bf16x8 stage[2][PIECES];
-    auto fetch = [&](int q) {
-        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FP * 512);
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) stage[q & 1][i] = gload<bf16x8>(src + (size_t)(tid + i * NT) * 8);
-    };
-    auto commit = [&](int q) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) *reinterpret_cast<bf16x8*>(&wl[q & 1][(size_t)(tid + i * NT) * 8]) = stage[q & 1][i];
-    };
-    fetch(0);
-    commit(0);
-    fetch(1);
-    __syncthreads();
-
-    const long long rounds = total_centroids / 4;
-    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
-    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
-    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
-    f32x16 acc[2];                    // panel q accumulates in acc[q & 1]; the owner finishes it during panel q + 1
-    long long cent_prev = -1;         // centroid whose last block (panel NPANEL - 1) is still to be finished
-    bf16x8 xh[KSH], xl[KSH], zh[KSH], zl[KSH];
-
-    // the owner's part of panel `Q` (Q < NB2: layer 2 -> fragments of z; else layer 3 -> max over the rows -> out)
-    auto exch_write = [&](int par, const f32x16& a) {
-        float* dst = &exch[par][rb][0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst + (i * 64 + lane) * 4) = f32x4{a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
-    };
-    auto exch_add = [&](int par, f32x16& a) {
-        const float* src = &exch[par][rb][0];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (i * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[4 * i + j] += v[j];
-        }
-    };
-
-#define SAX_FINISH(Q, CENT)                                                                                                  \
-    {                                                                                                                        \
-        constexpr int own_ = (Q) < NB2 ? (Q) / (NB2 / 2) : ((Q) - NB2) & 1;                                                  \
-        if (kh == own_) {                                                                                                    \
-            exch_add((Q) & 1, acc[(Q) & 1]);                                                                                 \
-            if constexpr ((Q) < NB2) {                                                                                       \
-                constexpr int nbl_ = (Q) % (NB2 / 2);                                                                        \
-                _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                           \
-                    float v[8];                                                                                              \
-                    _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = reluf(acc[(Q) & 1][8 * s2 + j]);                    \
-                    split8u<NP>(v, zh[2 * nbl_ + s2], zl[2 * nbl_ + s2]);                                                    \
-                }                                                                                                            \
-            } else {                                                                                                         \
-                float m = acc[(Q) & 1][0];                                                                                   \
-                _Pragma("unroll") for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[(Q) & 1][r]);                                \
-                m = fmaxf(m, __shfl_xor(m, 32));                                                                             \
-                if (lane < 32) out[(size_t)(CENT) * C3 + ((Q) - NB2) * 32 + lane] = reluf(m + bl[C2 + ((Q) - NB2) * 32 + lane]); \
-            }                                                                                                                \
-        }                                                                                                                    \
-    }
-    // panel step Q: request panel Q + 2; this wave's half of the contraction; finish the previous panel if owned; hand the
-    // partial to the owner if not; publish panel Q + 1
-#define SAX_STEP(Q)                                                                                                          \
-    {                                                                                                                        \
-        fetch(((Q) + 2) % NPANEL);                                                                                           \
-        const __bf16* W = &wl[(Q) & 1][0] + (size_t)kh * KSH * NP * 512;                                                     \
-        constexpr int own_ = (Q) < NB2 ? (Q) / (NB2 / 2) : ((Q) - NB2) & 1;                                                  \
-        if ((Q) < NB2 && kh == own_) {                                                                                       \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                               \
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + 32 * (Q) + 8 * q4 + 4 * h);                            \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[(Q) & 1][4 * q4 + j] = bq[j];                              \
-            }                                                                                                                \
-        } else {                                                                                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[(Q) & 1][r] = 0.0f;                                           \
-        }                                                                                                                    \
-        _Pragma("unroll") for (int s = 0; s < KSH; ++s) {                                                                    \
-            const bf16x8 wh = wfrag_lds_u<NP>(W, KSH, 0, s, 0, lane);                                                        \
-            const bf16x8 wlo = wfrag_lds_u<NP>(W, KSH, 0, s, 1, lane);                                                       \
-            if constexpr ((Q) < NB2) {                                                                                       \
-                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[s], acc[(Q) & 1], 0, 0, 0);                    \
-                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh[s], acc[(Q) & 1], 0, 0, 0);                   \
-                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[s], acc[(Q) & 1], 0, 0, 0);                    \
-            } else {                                                                                                         \
-                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], wh, acc[(Q) & 1], 0, 0, 0);                    \
-                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wlo, acc[(Q) & 1], 0, 0, 0);                   \
-                acc[(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wh, acc[(Q) & 1], 0, 0, 0);                    \
-            }                                                                                                                \
-            if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);                                                               \
-        }                                                                                                                    \
-        if (kh != own_) exch_write((Q) & 1, acc[(Q) & 1]);                                                                   \
-        commit(((Q) + 1) % NPANEL);                                                                                          \
-        __syncthreads();                                                                                                     \
-    }
-    for (long long rd = rbeg; rd < rend; ++rd) {
-        const long long cent = rd * 4 + rb;
-        const long long c = cent / S;
-        {
-            const int idx = ball[cent * kNSample + p];
-            const int ci = cent_idx[cent];
-            const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 128 * kh + 8 * h;
-            const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 128 * kh + 8 * h;
-            f32x4 u0[KSH], u1[KSH], v0[KSH], v1[KSH];
-#pragma unroll
-            for (int s = 0; s < KSH; ++s) {
-                u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
-                v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
-            }
-#pragma unroll
-            for (int s = 0; s < KSH; ++s) {
-                const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
-                                    reluf(u1[s][0] - v1[s][0]), reluf(u1[s][1] - v1[s][1]), reluf(u1[s][2] - v1[s][2]), reluf(u1[s][3] - v1[s][3])};
-                split8u<NP>(t, xh[s], xl[s]);
-            }
-        }
-        // panel 0 of this round next to the finish of the previous round's last panel
-        SAX_STEP(0)
-        if (cent_prev >= 0) SAX_FINISH(NPANEL - 1, cent_prev)
-        SAX_STEP(1) SAX_FINISH(0, cent)
-        SAX_STEP(2) SAX_FINISH(1, cent)
-        SAX_STEP(3) SAX_FINISH(2, cent)
-        SAX_STEP(4) SAX_FINISH(3, cent)
-        SAX_STEP(5) SAX_FINISH(4, cent)
-        SAX_STEP(6) SAX_FINISH(5, cent)
-        SAX_STEP(7) SAX_FINISH(6, cent)
-        SAX_FINISH(7, cent)            // (layer boundary: the last fragments of z before the first panel of layer 3)
-        SAX_STEP(8)
-        SAX_STEP(9) SAX_FINISH(8, cent)
-        SAX_STEP(10) SAX_FINISH(9, cent)
-        SAX_STEP(11) SAX_FINISH(10, cent)
-        SAX_STEP(12) SAX_FINISH(11, cent)
-        SAX_STEP(13) SAX_FINISH(12, cent)
-        SAX_STEP(14) SAX_FINISH(13, cent)
-        SAX_STEP(15) SAX_FINISH(14, cent)
-        SAX_STEP(16) SAX_FINISH(15, cent)
-        SAX_STEP(17) SAX_FINISH(16, cent)
-        SAX_STEP(18) SAX_FINISH(17, cent)
-        SAX_STEP(19) SAX_FINISH(18, cent)
-        SAX_STEP(20) SAX_FINISH(19, cent)
-        SAX_STEP(21) SAX_FINISH(20, cent)
-        SAX_STEP(22) SAX_FINISH(21, cent)
-        SAX_STEP(23) SAX_FINISH(22, cent)
-        cent_prev = cent;
-    }
-    if (cent_prev >= 0) SAX_FINISH(NPANEL - 1, cent_prev)
-#undef SAX_STEP
-#undef SAX_FINISH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -669,11 +464,11 @@ __global__ __launch_bounds__(512, 2) void sa_x_kernel(const float* __restrict__ 
 //
 // A wave owns a centroid's 32 rows and carries BOTH 256-wide operands of the chained layers in registers (x: 128, z: 128 -- with one
 // wave per SIMD the 512-entry register file of gfx950 belongs to it; the matrix instructions read their operands from either half).
-// No exchange between waves, no K split: 4 centroids = 128 rows per pass over the weights (as sa_x), twelve panels of 64 KB (two
+// No exchange between waves, no K split: 4 centroids = 128 rows per pass over the weights, twelve panels of 64 KB (two
 // channel blocks x all of K) by LDS-DMA, one barrier per panel.  The two channel blocks of a panel are two INDEPENDENT accumulator
 // chains, issued alternately -- a single dependent chain leaves the matrix pipe idle a quarter of the time at one wave per SIMD
 // (tools/ubench/mfma_clock: 1.59 vs 2.08 PFLOP/s).
-// blob: as sa_x_kernel (build_chain_blob, [nb][s = 0..15][plane][lane][8]); biases [256 | 512].
+// blob: build_chain_blob({conv1 256 x 256, conv2 512 x 256}, identity first map): [nb][s = 0..15][plane][lane][8]; biases [256 | 512].
 template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
@@ -1040,18 +835,19 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
     }
     if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
     if (which == 2) {
+#ifdef LSDM_TIMING_EXPERIMENTS   // `make TIMING=1` only: results are wrong with these (1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs)
         static const int dbg = getenv("LSDM_DBG_FP2") ? atoi(getenv("LSDM_DBG_FP2")) : 0;
+#else
+        constexpr int dbg = 0;
+#endif
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
                            none, nullptr, 1 | (dbg << 1));
     }
     else if (ynext) {
-        // LSDM_FP3_TM=128: 128-row tiles, one 8-wave work-group per CU (half the weight stream per row; measured slower, 175 vs 156 us:
-        // two independent work-groups per CU cover each other's gather and barrier phases)
-        static const int big = getenv("LSDM_FP3_TM") ? atoi(getenv("LSDM_FP3_TM")) == 128 : 0;
-        if (big) hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 128, 8>), dim3(256 / 128 * nc), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w,
-                                    256, 64, l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0);
-        else hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
-                                out, wb_next, ynext, keep_out ? 1 : 0);
+        // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
+        // each other's gather and barrier phases)
+        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
+                           out, wb_next, ynext, keep_out ? 1 : 0);
     }
     else
         hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out,
@@ -1069,22 +865,18 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
     if (level == 3) {
-        static const int w = getenv("LSDM_SA4_X") ? atoi(getenv("LSDM_SA4_X")) : 2;   // 1 = sa_x (K-split wave pairs), 2 = sa_w (one wave per SIMD)
-        static const int dbg = getenv("LSDM_DBG_SAW") ? atoi(getenv("LSDM_DBG_SAW")) : 0;   // timing experiments: 1 no panel copy, 2 no barrier
-        if (w == 2) hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg);
-        else hipLaunchKernelGGL((sa_x_kernel<2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out);
+#ifdef LSDM_TIMING_EXPERIMENTS   // `make TIMING=1` only: results are wrong with these (1 no panel copy, 2 no barrier)
+        static const int dbg = getenv("LSDM_DBG_SAW") ? atoi(getenv("LSDM_DBG_SAW")) : 0;
+#else
+        constexpr int dbg = 0;
+#endif
+        hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg);
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;
         hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
-        // LSDM_SA3_V1=1: the older kernel that streams both layers (A/B switch for measurements)
-        static const bool v1 = getenv("LSDM_SA3_V1") && atoi(getenv("LSDM_SA3_V1")) != 0;
-        if (v1) hipLaunchKernelGGL((sa_u_kernel<128, 128, 256, 4, 2>), dim3(512), dim3(256), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
-        else {
-            static const int dbg = getenv("LSDM_DBG_SA3") ? atoi(getenv("LSDM_DBG_SA3")) : 0;
-            hipLaunchKernelGGL((sa_u2_kernel<128, 128, 256, 8, 2>), dim3(256), dim3(512), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out, dbg);
-        }
+        hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
     }
 }
 

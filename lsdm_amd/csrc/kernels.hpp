@@ -95,16 +95,11 @@ void launch_sa_h(int np, int level, int num_clouds, const float* src_xyz, const 
                  const DenseH* l, void* out, hipStream_t st);
 void launch_fp_h(int np, int which, int num_clouds, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
                  const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st);
-void launch_sa_h_pre(int num_clouds, const float* U, const float* V, const int* cent, const float* new_xyz, const int* ball, const DenseH* l,
-                     float* out, hipStream_t st);
 // encoder_reg.hip: register-chained SA kernel for levels 0 and 1 (weights resident in LDS)
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
-// fp2 as a register-chained stack on the pre-multiplied interpolation operand y (launch_fp_y): points1 (nc,1024,64) [through
-// p1_remap when given], y (nc,256,256), out (nc,1024,128)
+// y = coarse-level FP output x Wb^T (the pre-multiplied interpolation operand of the next finer FP stage), R rows of 256 channels
 void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
-void launch_fp_ps(int num_clouds, const float* points1, const int* p1_remap, const float* y, const int* nn_idx, const float* nn_w,
-                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st);
 // fp1 + head as one register-chained stack (bf16x3): points2 (nc,1024,128) fp32, out (nc,1024,3)
 void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b,
                  float* out, hipStream_t st);

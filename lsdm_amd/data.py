@@ -7,6 +7,11 @@ Restates the *format* consumed by ``posa.dataset.ProxDataset_txt`` (posa/dataset
     <data_dir>/reduced_vertices/<seq>.npy  (1024,3) human vertices
     <objs_dir>/<scene>/<cat>_<i>.npy       (1024,3) object point clouds; scene = <seq>.split('_')[0]
 
+Iteration order: the reference enumerates ``os.listdir(context_dir)`` as the file system returns it (posa/dataset.py:374,503) --
+unspecified and machine-dependent.  The loaders here default to ``order="sorted"`` (reproducible everywhere);
+``order="listdir"`` replays the reference's enumeration on the same file system, which is what decides which draws of the
+CLI's single RNG stream a sample receives (run/test_sdm.py:111,146: B = 1, one global generator).
+
 ``data_dir`` must contain an underscore-separated split name (``proxd_test``), as the reference parses
 ``data_dir.split('_')[1]`` (posa/dataset.py:369).  Each item is the tuple the sampling loop consumes:
 (mask (9,), given_objs (9,1024,3), given_cats (9,C), target_obj (1024,3), target_cat (C,), prompt).
@@ -28,15 +33,23 @@ CATEGORY_IDS = {"human": 0, "chair": 1, "table": 2, "cabinet": 3, "sofa": 4, "be
                 "stool": 7, "tv_monitor": 8, "tv": 8, "lighting": 9, "shelving": 10, "seating": 11, "furniture": 12}
 
 
+def _ordered(names, order):
+    if order == "sorted":
+        return sorted(names)
+    if order == "listdir":
+        return list(names)
+    raise ValueError("order must be 'sorted' or 'listdir'")
+
+
 class ProxTextDataset(Dataset):
-    def __init__(self, data_dir, objs_data_dir='data/protext/objs', max_objs=8, pnt_size=1024, max_cats=13, **unused):
+    def __init__(self, data_dir, objs_data_dir='data/protext/objs', max_objs=8, pnt_size=1024, max_cats=13, order="sorted", **unused):
         self.data_dir, self.max_objs, self.pnt_size, self.max_cats = data_dir, max_objs, pnt_size, max_cats
         split = os.path.basename(os.path.normpath(data_dir)).split('_')
         if len(split) < 2:
             raise ValueError("data_dir must look like <name>_<split> (posa/dataset.py:369)")
         self.handle = 0 if split[1] == 'train' else 1
         ctx_dir = os.path.join(data_dir, "context")
-        self.seq_names = sorted(f[:-4] for f in os.listdir(ctx_dir) if f.endswith(".txt"))
+        self.seq_names = _ordered([f[:-4] for f in os.listdir(ctx_dir) if f.endswith(".txt")], order)
         self.objs, self.cats = {}, {}
         for scene in os.listdir(objs_data_dir):
             self.objs[scene], self.cats[scene] = {}, {}
@@ -80,11 +93,11 @@ HUMANISE_CATEGORY_IDS = {"human": 0, "bed": 1, "sofa": 2, "table": 3, "door": 4,
 class HumaniseDataset(Dataset):
     """``posa.dataset.HUMANISE`` (posa/dataset.py:477-602): same item tuple as ``ProxTextDataset``, C = 11."""
 
-    def __init__(self, data_dir, objs_data_dir='data/humanise/objs', max_objs=8, pnt_size=1024, max_cats=11, **unused):
+    def __init__(self, data_dir, objs_data_dir='data/humanise/objs', max_objs=8, pnt_size=1024, max_cats=11, order="sorted", **unused):
         self.data_dir, self.max_objs, self.pnt_size, self.max_cats = data_dir, max_objs, pnt_size, max_cats
         self.handle = 0 if data_dir.split('/')[-1] == 'train' else 1
         ctx_dir = os.path.join(data_dir, "context")
-        self.seq_names = sorted(f.split('.txt')[0] for f in os.listdir(ctx_dir))
+        self.seq_names = _ordered([f.split('.txt')[0] for f in os.listdir(ctx_dir)], order)
         self.objs, self.cats = {}, {}
         for scene in os.listdir(objs_data_dir):
             self.objs[scene], self.cats[scene] = {}, {}

@@ -202,11 +202,16 @@ class SceneDiffusionModel(nn.Module):
         t = timesteps.to(device=dev, dtype=torch.long).contiguous()
         if t.shape != (B,):
             raise ValueError("timesteps must be (B,)")
-        # the kernels index the positional table (5000 rows) and, in the sampler modes, the schedule tables by t
-        t_lo, t_hi = (int(v) for v in torch.aminmax(timesteps))
+        # the kernels index the positional table (5000 rows) and, in the sampler modes, the schedule tables by t.  Host tensors are
+        # range-checked here; DEVICE tensors are not read back (that would stall the stream once per step): LSDM_CHECK_TIMESTEPS=1
+        # opts into the synchronising check, otherwise an out-of-range device index is clamped into the table.
         t_max = 5000 if mode == _lib.MODE_FORWARD else getattr(self, "_schedule_len", 0)
-        if t_lo < 0 or t_hi >= t_max:
-            raise ValueError("timesteps must lie in [0, %d), got [%d, %d]" % (t_max, t_lo, t_hi))
+        if not timesteps.is_cuda or os.environ.get("LSDM_CHECK_TIMESTEPS", "0") == "1":
+            t_lo, t_hi = (int(v) for v in torch.aminmax(timesteps))
+            if t_lo < 0 or t_hi >= t_max:
+                raise ValueError("timesteps must lie in [0, %d), got [%d, %d]" % (t_max, t_lo, t_hi))
+        else:
+            t = t.clamp(0, t_max - 1)
         text = self._encode_text(y, B, dev)
         if fps_starts is None:
             # reference draw order and generator: CPU global RNG, sa1..sa4

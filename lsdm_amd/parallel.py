@@ -20,19 +20,28 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_samples(local, dist=None, total=None):
+def gather_samples(local, dist=None, total=None, agree=True):
     """All-gathers (B_local, ...) tensors into (sum of B_local, ...) in rank order.  ``dist`` is the initialised
     ``torch.distributed`` module or None for a single process.  Equal shard sizes (the bench: 64 chains per rank) take one
     ``all_gather_into_tensor``; with ``total`` = the job's unit count split by ``shard_range`` (sizes differing by one when
     ``total % world != 0``) every rank pads its shard to the largest size for the same single collective and the padding
-    rows are dropped afterwards."""
+    rows are dropped afterwards.  ``agree`` (default) first exchanges the shard sizes (one 8-byte all-gather) so that a rank holding
+    the wrong shard makes EVERY rank raise instead of leaving the others waiting in the collective; a caller that has already agreed
+    on the sizes (bench.py: the untimed warm-up gather) passes ``agree=False`` and issues exactly one collective."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
     sizes = [local.shape[0]] * world if total is None else [shard_range(total, r, world)[1] - shard_range(total, r, world)[0]
                                                             for r in range(world)]
-    if sizes[dist.get_rank()] != local.shape[0]:
-        raise ValueError("rank %d holds %d units, shard_range(%s) assigns %d" % (dist.get_rank(), local.shape[0], total, sizes[dist.get_rank()]))
+    # validity is agreed on COLLECTIVELY: a rank that raised alone would leave the others waiting in the all-gather
+    if agree:
+        held = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        every = torch.empty(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(every, held)
+        every = [int(v) for v in every.cpu()]
+        if every != sizes:
+            raise ValueError("shard sizes per rank %s, expected %s (%s)" % (every, sizes, "shard_range(%d)" % total if total is not None
+                                                                              else "equal shards: pass total= for a ragged split"))
     big = max(sizes)
     send = local.contiguous()
     if send.shape[0] < big:

@@ -5,7 +5,11 @@ there) and its outputs: ``<output_dir>/results.txt`` ("Chamfer distance for seq 
 "Final ..." lines, :211,227-231), ``predictions/<stem>.npy`` and ``guiding_points/<stem>.npy`` (float32 (1024,3)).
 Additions (defaults preserve reference behaviour): ``--device``, ``--use_ddim``, ``--timestep_respacing``,
 ``--synthetic N`` (write and evaluate an N-sample synthetic proxd_test tree with synthetic weights -- no dataset,
-checkpoint or CLIP weights are reachable offline), ``--objs_dir``.
+checkpoint or CLIP weights are reachable offline), ``--objs_dir``, ``--batch_size B`` (the reference evaluates one sample per
+sampling loop, run/test_sdm.py:111 -- 9 clouds per launch; B > 1 runs B samples as one batch of chains, metrics and files still
+per sample; results then differ from B = 1 because the RNG stream is consumed per batch and the reference's mask quirks Q2/Q3
+depend on B) and ``--order sorted|listdir`` (sample enumeration; ``listdir`` replays the reference's os.listdir order on this
+file system, lsdm_amd/data.py).
 
 The sampling backend is the HIP path; ``main(argv, backend_factory=...)`` lets tests inject another one.
 """
@@ -54,6 +58,8 @@ def build_parser():
     p.add_argument("--timestep_respacing", type=str, default="")
     p.add_argument("--synthetic", type=int, default=0, help="write and evaluate N synthetic samples under data_dir")
     p.add_argument("--objs_dir", type=str, default=None)
+    p.add_argument("--batch_size", type=int, default=1, help="samples per sampling loop (reference: 1)")
+    p.add_argument("--order", type=str, default="sorted", choices=["sorted", "listdir"])
     return p
 
 
@@ -103,10 +109,12 @@ def main(argv=None, backend_factory=None):
         text_encoder = synthetic_text_features
     # the reference picks the loader by --datatype (run/test_sdm.py:110-117); each has its own category table
     if args.datatype == 'proxd':
-        dataset = ProxTextDataset(data_dir, objs_data_dir=objs_dir or 'data/protext/objs', max_cats=13)
+        dataset = ProxTextDataset(data_dir, objs_data_dir=objs_dir or 'data/protext/objs', max_cats=13, order=args.order)
     else:
-        dataset = HumaniseDataset(data_dir, objs_data_dir=objs_dir or 'data/humanise/objs', max_cats=11)
-    loader = DataLoader(dataset, batch_size=1, shuffle=False, num_workers=0)
+        dataset = HumaniseDataset(data_dir, objs_data_dir=objs_dir or 'data/humanise/objs', max_cats=11, order=args.order)
+    if args.batch_size < 1:
+        raise ValueError("--batch_size must be >= 1")
+    loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=0)
     backend = (backend_factory or HipBackend)(args, text_encoder)
     lookup = {}
     for fn in os.listdir(os.path.join(data_dir, 'context')):
@@ -120,18 +128,20 @@ def main(argv=None, backend_factory=None):
             with torch.no_grad():
                 pred, pred_cat, guiding = backend.sample(list(target_obj.shape), mask, given_objs, given_cats, y)
             target_obj = target_obj.float().to(pred.device)
-            chamfer_s = float(chamfer_distance(pred, target_obj))
-            chamfer_list.append(chamfer_s)
-            emd_list.append(emd(pred, target_obj))
-            f1_list.append(calculate_fscore(pred.squeeze(0), target_obj.squeeze(0))[0])
             pred_cat = pred_cat.squeeze(1).cpu()
             tgt = torch.argmax(target_cat, dim=1)
-            total_topk.append(accuracy(pred_cat, tgt, topk=(3,))[0].item())
-            total_acc.append((torch.argmax(pred_cat, dim=1) == tgt).sum().item())
-            stem = lookup[y[0]]
-            f.write("Chamfer distance for seq {}: {:.4f}".format(stem, chamfer_s) + '\n')
-            np.save(os.path.join(args.output_dir, 'predictions', stem + '.npy'), pred[0].cpu().numpy())
-            np.save(os.path.join(args.output_dir, 'guiding_points', stem + '.npy'), guiding[0].cpu().numpy())
+            for i in range(pred.shape[0]):          # (one iteration in the reference's B = 1 loop)
+                pi, ti = pred[i:i + 1], target_obj[i:i + 1]
+                chamfer_s = float(chamfer_distance(pi, ti))
+                chamfer_list.append(chamfer_s)
+                emd_list.append(emd(pi, ti))
+                f1_list.append(calculate_fscore(pi.squeeze(0), ti.squeeze(0))[0])
+                total_topk.append(accuracy(pred_cat[i:i + 1], tgt[i:i + 1], topk=(3,))[0].item())
+                total_acc.append((torch.argmax(pred_cat[i:i + 1], dim=1) == tgt[i:i + 1]).sum().item())
+                stem = lookup[y[i]]
+                f.write("Chamfer distance for seq {}: {:.4f}".format(stem, chamfer_s) + '\n')
+                np.save(os.path.join(args.output_dir, 'predictions', stem + '.npy'), pred[i].cpu().numpy())
+                np.save(os.path.join(args.output_dir, 'guiding_points', stem + '.npy'), guiding[i].cpu().numpy())
         f.write("Final Chamfer distance: {:.4f}".format(list_mean(chamfer_list)) + '\n')
         f.write("Final EMD: {:.4f}".format(list_mean(emd_list)) + '\n')
         f.write("Final F1 score: {:.4f}".format(list_mean(f1_list)) + '\n')

@@ -16,6 +16,9 @@ Golden sets:
   G8  CLI metrics: emd / accuracy of the reference's util/evaluation.py on seeded clouds and logits.
   G9  p_sample_loop argument variants (gaussian_diffusion.py:611-759): noise=, init_image + skip_timesteps, dump_steps;
       and what const_noise=True does in the reference (a 4-D repeat inherited from MDM: a (B,B,1024,3) sample).
+  G11 dataset loaders: every tuple the reference's posa.dataset.ProxDataset_txt / HUMANISE yield on the trees written by
+      lsdm_amd.data.write_synthetic_dataset / write_synthetic_humanise (seeded), keyed by prompt, plus the reference's own
+      iteration order (os.listdir of the context directory, posa/dataset.py:374,503) as recorded in THIS container.
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
 import argparse
@@ -363,6 +366,37 @@ def g9():
         print("const_noise over two steps fails in the reference:", type(e).__name__, str(e)[:100])
         out["const_noise_two_steps_ok"] = np.array(0)
     save("g9_loop_variants", noise0=noise0, init=init, meta=np.array([B, C, K, 91, 92]), **out)
+
+
+def g11():
+    """The reference's two dataset classes on the synthetic trees (the generator is seeded, so the test re-writes the same trees and
+    compares its own loaders with these tuples).  The path must contain exactly the underscores / components the reference parses
+    (`data_dir.split('_')[1]`, posa/dataset.py:369; `data_dir.split('/')[-1]`, :497): a fresh directory under /tmp without underscores."""
+    import shutil
+    import tempfile
+    import posa.dataset as pds
+    from lsdm_amd.data import write_synthetic_dataset, write_synthetic_humanise
+    root = tempfile.mkdtemp(prefix="lsdmg11", dir="/tmp")
+    assert "_" not in root
+    try:
+        out = {}
+        for tag, writer, cls, kw in (("prox", lambda r: write_synthetic_dataset(r, num_samples=4, seed=11), pds.ProxDataset_txt, dict(max_cats=13)),
+                                     ("hum", lambda r: write_synthetic_humanise(r, num_scenes=2, prompts_per_scene=2, seed=12), pds.HUMANISE,
+                                      dict(max_cats=11))):
+            data_dir, objs_dir = writer(root)
+            ds = cls(data_dir, objs_data_dir=objs_dir, **kw)
+            items = [ds[i] for i in range(len(ds))]
+            order = [it[5] for it in items]                      # prompts in the reference's os.listdir order (this container)
+            by_prompt = sorted(range(len(items)), key=lambda i: items[i][5])
+            out[tag + "_prompts_listdir_order"] = np.array(order)
+            out[tag + "_seq_names_listdir_order"] = np.array(list(ds.seq_names))
+            out[tag + "_prompts"] = np.array([items[i][5] for i in by_prompt])
+            for j, name in enumerate(("mask", "given_objs", "given_cats", "target_obj", "target_cat")):
+                out[tag + "_" + name] = torch.stack([torch.as_tensor(items[i][j]).float() for i in by_prompt])
+            out[tag + "_len"] = np.array(len(ds))
+        save("g11_loaders", meta=np.array([4, 11, 2, 2, 12]), **out)
+    finally:
+        shutil.rmtree(root)
 
 
 def long_chain(steps):

@@ -227,6 +227,26 @@ def test_config1_cli_on_hip_backend_vs_oracle_backend(tmp_path, golden):
         assert a.split(":")[0] == b.split(":")[0] and abs(float(a.split(": ")[1]) - float(b.split(": ")[1])) <= 2e-3
 
 
+def test_cli_batch_size_4_on_hip_backend_vs_oracle_backend(tmp_path, golden):
+    """--batch_size 4 (an addition: the reference's loop is B = 1): the four synthetic samples as ONE batch of chains, ddim5, against
+    the same CLI driven by the oracle (g10b_cli_ddim5_b4, oracle/make_cli_fixture.py --b4) -- files, per-sample lines, finals."""
+    import run.test_sdm as cli
+    out = tmp_path / "out"
+    assert cli.main([str(tmp_path / "data"), "--synthetic", "4", "--device", "cuda:0", "--use_ddim", "--timestep_respacing", "ddim5",
+                     "--batch_size", "4", "--output_dir", str(out), "--fix_ori", "--test_on_valid_set", "--model_name", "sdm"]) == 0
+    g = golden("g10b_cli_ddim5_b4")
+    for sub in ("predictions", "guiding_points"):
+        files = sorted(os.listdir(out / sub))
+        assert files == [str(f) for f in g[sub + "_files"]] and len(files) == 4
+        for i, f in enumerate(files):
+            a = np.load(out / sub / f)
+            assert a.shape == (1024, 3) and a.dtype == np.float32 and np.abs(a - g[sub][i]).max() <= 1e-3, (sub, f)
+    lh, lr = open(out / "results.txt").read().splitlines(), str(g["results_txt"]).splitlines()
+    assert len(lh) == len(lr) == 9
+    for a, b in zip(lh, lr):
+        assert a.split(": ")[0] == b.split(": ")[0] and abs(float(a.split(": ")[1]) - float(b.split(": ")[1])) <= 2e-3, (a, b)
+
+
 def test_cli_humanise_datatype_on_hip_backend(tmp_path):
     """--datatype humanise: the HUMANISE loader (own category table, C = 11, scene = seq[:9] + '_00') feeding the HIP path."""
     import run.test_sdm as cli
@@ -473,11 +493,23 @@ def test_input_validation_is_loud():
     bad[2][0] = 256                                     # level 3 draws from [0, 256)
     with pytest.raises(ValueError, match="level 3"):
         m(x, bt["mask"], t, bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=bad)
+    # timesteps: host tensors are range-checked; device tensors are not read back (no per-step stall) unless opted in, and an
+    # out-of-range device index is clamped into the table instead of reading past it
     with pytest.raises(ValueError, match="timesteps"):
-        m(x, bt["mask"], torch.tensor([5, 5000], device=DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=good)
+        m(x, bt["mask"], torch.tensor([5, 5000]), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=good)
     with pytest.raises(ValueError, match="timesteps"):   # sampler modes index the schedule tables (1000 rows)
-        diff.p_sample(m, x, bt["mask"], torch.tensor([5, 1000], device=DEV), bt["given_objs"], bt["given_cats"], bt["text_features"],
+        diff.p_sample(m, x, bt["mask"], torch.tensor([5, 1000]), bt["given_objs"], bt["given_cats"], bt["text_features"],
                       clip_denoised=False)
+    os.environ["LSDM_CHECK_TIMESTEPS"] = "1"
+    try:
+        with pytest.raises(ValueError, match="timesteps"):
+            m(x, bt["mask"], torch.tensor([5, 5000], device=DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=good)
+    finally:
+        del os.environ["LSDM_CHECK_TIMESTEPS"]
+    xa, xb = x.clone(), x.clone()
+    oa = m(xa, bt["mask"], torch.tensor([5, 5000], device=DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=good)
+    ob = m(xb, bt["mask"], torch.tensor([5, 4999], device=DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=good)
+    assert torch.equal(oa[1], ob[1])
     with pytest.raises(ValueError):
         m(x, bt["mask"], t, bt["given_objs"], bt["given_cats"][:, :, :5], y=bt["text_features"], fps_starts=good)
     m(x, bt["mask"], t, bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=good)     # still usable

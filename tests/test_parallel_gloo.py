@@ -78,6 +78,15 @@ def _ragged_worker(rank, world, port, q):
         bad = False
     except ValueError:
         bad = True
+    try:        # ... also when only ONE rank is wrong: the sizes are agreed on collectively, so every rank raises
+        gather_samples(units[lo:hi] if rank == 0 else units[:1], dist, total=total)
+        bad = False
+    except ValueError:
+        pass
+    # fewer units than ranks: rank 1 holds an empty shard, one padded collective all the same
+    l1, h1 = shard_range(1, rank, world)
+    one = gather_samples(units[l1:h1], dist, total=1)
+    assert one.shape == (1, 2, 3) and bool((one == units[:1]).all())
     dist.barrier()
     if rank == 0:
         q.put((got.numpy(), bad))
