@@ -376,16 +376,24 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                 }
                 panel_end();
             }
-            float* sst = stash + (size_t)blk * (6 * 16 * 64);
             const bool guide = last && out_guiding != nullptr;   // out_guiding == NULL: a later forward of the call defines the guiding points
+            // The 24 piece addresses of the scratch tile are formed where they are used, from a pointer the compiler cannot see
+            // through: as loop invariants of the round it kept all of them in registers across the step loop and spilled them
+            // (79 VGPRs of scratch in round 2's build).
+            auto stash_tile = [&]() -> float* {
+                float* q = stash;
+                asm volatile("" : "+s"(q));
+                return q + (size_t)blk * (6 * 16 * 64) + lane * 4;
+            };
             if (guide) {
                 // park S for the guiding-point pass (lane-linear 16-byte pieces: 1 KiB per instruction)
+                float* sst = stash_tile();
 #pragma unroll
                 for (int nb = 0; nb < 6; ++nb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 v = {S[nb][4 * q], S[nb][4 * q + 1], S[nb][4 * q + 2], S[nb][4 * q + 3]};
-                        *reinterpret_cast<f32x4*>(sst + ((size_t)(nb * 4 + q) * 64 + lane) * 4) = v;
+                        *reinterpret_cast<f32x4*>(sst + (size_t)(nb * 4 + q) * 256) = v;
                     }
             }
             // ---- denoiser on the mutated x + sampler update -----------------------------------------------------------------------
@@ -418,11 +426,12 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             wave_sync();
             // ---- denoiser on the guiding points (saved_guiding_points, Q12): defined by the last forward ----------------------------
             if (guide) {
+                const float* sst = stash_tile();
 #pragma unroll
                 for (int nb = 0; nb < 6; ++nb)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = gload<f32x4>(sst + ((size_t)(nb * 4 + q) * 64 + lane) * 4);
+                        const f32x4 v = gload<f32x4>(sst + (size_t)(nb * 4 + q) * 256);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) S[nb][4 * q + j] = v[j];
                     }
