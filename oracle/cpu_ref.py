@@ -112,14 +112,34 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return idx
 
 
-def _conv_bn_relu(h, w, b, bn, prefix_dim):
-    """Conv(1x1)+BatchNorm(eval)+ReLU as the reference executes it (pointnet2_utils.py:190-192,
-    308-310): h is (B,C,...) channel-first."""
+class TrainMode:
+    """model.train() of the reference (run/train_sdm.py:46) as far as this path is concerned: the PointNet++ BatchNorm layers
+    normalise with the statistics of the batch (nn.BatchNorm{1,2}d in training mode; the momentum-0.1 running-statistics update
+    they would perform is recorded in ``new_running``), and the encoder head's Dropout(0.5) (pointnet2.py:58,76) multiplies by
+    ``dropout_mask`` -- the (BO,128,1024) 0/1 draw of ``torch.empty_like(h).bernoulli_(0.5)`` that F.dropout makes on the global
+    CPU generator right after the four FPS randints -- and by 1/(1-p) = 2."""
+
+    def __init__(self, dropout_mask=None):
+        self.dropout_mask = dropout_mask
+        self.new_running = {}
+
+
+def _conv_bn_relu(h, w, b, bn, prefix_dim, train=None, bn_name=None):
+    """Conv(1x1)+BatchNorm+ReLU as the reference executes it (pointnet2_utils.py:190-192,
+    308-310): h is (B,C,...) channel-first.  BatchNorm in eval mode unless ``train`` (a TrainMode) is given."""
     if prefix_dim == 2:
         h = F.conv2d(h, w, b)
     else:
         h = F.conv1d(h, w, b)
-    h = F.batch_norm(h, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, BN_EPS)
+    if train is None:
+        h = F.batch_norm(h, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, BN_EPS)
+    else:
+        with torch.no_grad():
+            dims = [d for d in range(h.dim()) if d != 1]
+            n = h.numel() // h.shape[1]
+            mean, var = h.mean(dim=dims), h.var(dim=dims, unbiased=True) if n > 1 else h.var(dim=dims, unbiased=False)
+            train.new_running[bn_name] = (0.9 * bn["running_mean"] + 0.1 * mean, 0.9 * bn["running_var"] + 0.1 * var)
+        h = F.batch_norm(h, None, None, bn["weight"], bn["bias"], True, 0.0, BN_EPS)
     return F.relu(h)
 
 
@@ -127,7 +147,7 @@ def _bn(sd, prefix):
     return {k: sd[prefix + "." + k] for k in ("weight", "bias", "running_mean", "running_var")}
 
 
-def set_abstraction(sd, name, level, xyz, points, start, taps=None):
+def set_abstraction(sd, name, level, xyz, points, start, taps=None, train=None):
     """PointNetSetAbstraction.forward (pointnet2_utils.py:173-199) + sample_and_group (:107-135).
 
     xyz (B,N,3), points (B,N,D) channel-last.  Returns new_xyz (B,S,3), new_points (B,S,C').
@@ -142,7 +162,7 @@ def set_abstraction(sd, name, level, xyz, points, start, taps=None):
     for i in range(3):
         p = "pcd_backbone.%s" % name
         h = _conv_bn_relu(h, sd["%s.mlp_convs.%d.weight" % (p, i)], sd["%s.mlp_convs.%d.bias" % (p, i)],
-                          _bn(sd, "%s.mlp_bns.%d" % (p, i)), 2)
+                          _bn(sd, "%s.mlp_bns.%d" % (p, i)), 2, train, "%s.mlp_bns.%d" % (p, i))
     new_points = torch.max(h, 2)[0].permute(0, 2, 1).contiguous()  # (B,S,C')
     if taps is not None:
         taps["%s.fps_idx" % name] = fps_idx
@@ -162,7 +182,7 @@ def three_nn(xyz1, xyz2):
     return idx, w
 
 
-def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=None, nn_inject=None):
+def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=None, nn_inject=None, train=None):
     """PointNetFeaturePropagation.forward (pointnet2_utils.py:273-312), channel-last in/out.
 
     ``nn_inject`` (tests only): use these (B,N,3) neighbour indices instead of the sort's -- the weights follow from the
@@ -182,7 +202,7 @@ def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=No
     p = "pcd_backbone.%s" % name
     for i in range(nlayers):
         h = _conv_bn_relu(h, sd["%s.mlp_convs.%d.weight" % (p, i)], sd["%s.mlp_convs.%d.bias" % (p, i)],
-                          _bn(sd, "%s.mlp_bns.%d" % (p, i)), 1)
+                          _bn(sd, "%s.mlp_bns.%d" % (p, i)), 1, train, "%s.mlp_bns.%d" % (p, i))
     out = h.permute(0, 2, 1).contiguous()
     if taps is not None:
         taps["%s.nn_idx" % name] = idx
@@ -191,13 +211,13 @@ def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=No
     return out
 
 
-def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72):
+def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72, train=None):
     """get_backbone.forward (pointnet2.py:61-80).  clouds (BO,N,3); starts = 4 int64 tensors (BO,).
 
     Clouds are independent (eval-mode BatchNorm), so more than ``chunk`` of them are evaluated ``chunk`` at a time -- the
     (BO,1024,1024) distance temporaries of 576 clouds would need tens of GB -- with identical results.
     ``nn_inject``: optional {"fp4"|"fp3"|"fp2"|"fp1": (BO,N,3) indices}, see feature_propagation."""
-    if clouds.shape[0] > chunk:
+    if clouds.shape[0] > chunk and train is None:      # (training-mode BatchNorm couples the clouds of a batch)
         outs, parts = [], []
         for lo in range(0, clouds.shape[0], chunk):
             sl = slice(lo, lo + chunk)
@@ -212,16 +232,18 @@ def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72):
     inj = nn_inject or {}
     l0_xyz = clouds
     l0_points = clouds  # dimension=3: features are the coordinates themselves (:63-64)
-    l1_xyz, l1_points = set_abstraction(sd, "sa1", 0, l0_xyz, l0_points, starts[0], taps)
-    l2_xyz, l2_points = set_abstraction(sd, "sa2", 1, l1_xyz, l1_points, starts[1], taps)
-    l3_xyz, l3_points = set_abstraction(sd, "sa3", 2, l2_xyz, l2_points, starts[2], taps)
-    l4_xyz, l4_points = set_abstraction(sd, "sa4", 3, l3_xyz, l3_points, starts[3], taps)
-    l3_points = feature_propagation(sd, "fp4", 2, l3_xyz, l4_xyz, l3_points, l4_points, taps, inj.get("fp4"))
-    l2_points = feature_propagation(sd, "fp3", 2, l2_xyz, l3_xyz, l2_points, l3_points, taps, inj.get("fp3"))
-    l1_points = feature_propagation(sd, "fp2", 2, l1_xyz, l2_xyz, l1_points, l2_points, taps, inj.get("fp2"))
-    l0_feat = feature_propagation(sd, "fp1", 3, l0_xyz, l1_xyz, None, l1_points, taps, inj.get("fp1"))
+    l1_xyz, l1_points = set_abstraction(sd, "sa1", 0, l0_xyz, l0_points, starts[0], taps, train)
+    l2_xyz, l2_points = set_abstraction(sd, "sa2", 1, l1_xyz, l1_points, starts[1], taps, train)
+    l3_xyz, l3_points = set_abstraction(sd, "sa3", 2, l2_xyz, l2_points, starts[2], taps, train)
+    l4_xyz, l4_points = set_abstraction(sd, "sa4", 3, l3_xyz, l3_points, starts[3], taps, train)
+    l3_points = feature_propagation(sd, "fp4", 2, l3_xyz, l4_xyz, l3_points, l4_points, taps, inj.get("fp4"), train)
+    l2_points = feature_propagation(sd, "fp3", 2, l2_xyz, l3_xyz, l2_points, l3_points, taps, inj.get("fp3"), train)
+    l1_points = feature_propagation(sd, "fp2", 2, l1_xyz, l2_xyz, l1_points, l2_points, taps, inj.get("fp2"), train)
+    l0_feat = feature_propagation(sd, "fp1", 3, l0_xyz, l1_xyz, None, l1_points, taps, inj.get("fp1"), train)
     h = l0_feat.permute(0, 2, 1)
-    h = _conv_bn_relu(h, sd["pcd_backbone.conv1.weight"], sd["pcd_backbone.conv1.bias"], _bn(sd, "pcd_backbone.bn1"), 1)
+    h = _conv_bn_relu(h, sd["pcd_backbone.conv1.weight"], sd["pcd_backbone.conv1.bias"], _bn(sd, "pcd_backbone.bn1"), 1, train, "pcd_backbone.bn1")
+    if train is not None and train.dropout_mask is not None:
+        h = h * train.dropout_mask * 2.0      # Dropout(0.5) in training mode (pointnet2.py:76)
     h = F.conv1d(h, sd["pcd_backbone.conv2.weight"], sd["pcd_backbone.conv2.bias"])
     return h.permute(0, 2, 1).contiguous()  # (BO,N,3)
 
@@ -276,7 +298,7 @@ def denoise_mlp(sd, z, emb):
     return h
 
 
-def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_starts=None, taps=None, pcd_override=None):
+def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_starts=None, taps=None, pcd_override=None, train=None):
     """One denoising-network evaluation.  Mutates ``x`` in place (Q5).  Returns (out_cat, out, guiding).
     ``pcd_override`` (tests only): a precomputed scene-encoder output (B,O,3072) used instead of running the encoder.
 
@@ -293,7 +315,7 @@ def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_s
     # 2. text embedding: the 3-layer MLP (Q9; sdm.py:52-59,152-154)
     enc = _mlp(sd, "embed_text", (0, 2, 4), text_features, F.gelu).unsqueeze(1)  # (B,1,128)
     # 3. category head (sdm.py:68-76,157-158), GELU on the logits before softmax (Q10)
-    out_cat = torch.softmax(_mlp(sd, "predict_cat", (0, 2, 4), enc, F.gelu), dim=2)
+    out_cat = torch.softmax(_mlp(sd, "predict_cat", (0, 2, 4), enc.detach(), F.gelu), dim=2)   # (.clone().detach(), sdm.py:157)
     # 4. category embedding (sdm.py:62-65,161)
     ecat = _mlp(sd, "embed_cat", (0,), given_cats, F.gelu)  # (B,O,32)
     # 5. up-sampled conditioning (sdm.py:164-167)
@@ -306,7 +328,7 @@ def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_s
     if pcd_override is not None:
         pcd = pcd_override.reshape(B, O, -1)
     else:
-        pcd = scene_encoder(sd, given_objs.reshape(B * O, N, 3), fps_starts, taps).reshape(B, O, -1)
+        pcd = scene_encoder(sd, given_objs.reshape(B * O, N, 3), fps_starts, taps, train=train).reshape(B, O, -1)
     # 8. object attention weights (sdm.py:180-182): 8 heads x 16, float mask ADDED (Q4), row (b,h) of the
     #    mask is mask[(b*8+h) % B] (Q3); only the head-averaged weights are used (Q6).
     wq, wk = sd["attn_layer.q_proj_weight"], sd["attn_layer.k_proj_weight"]

@@ -19,6 +19,11 @@ Golden sets:
   G11 dataset loaders: every tuple the reference's posa.dataset.ProxDataset_txt / HUMANISE yield on the trees written by
       lsdm_amd.data.write_synthetic_dataset / write_synthetic_humanise (seeded), keyed by prompt, plus the reference's own
       iteration order (os.listdir of the context directory, posa/dataset.py:374,503) as recorded in THIS container.
+  G12 the training objective (gaussian_diffusion.py:1256-1342) on the real reference, B = 2, in model.eval() and in model.train()
+      (batch-statistics BatchNorm, Dropout(0.5) of the encoder head with the mask the global generator gives): the three loss terms,
+      every parameter's gradient (small tensors in full; large ones as norm / sum / a strided sample), the BatchNorm running
+      statistics after the forward.  pytorch3d's chamfer_distance is absent: its published definition (oracle/train_ref.py) is
+      patched in -- the chamfer term's parity is unpinned.
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
 import argparse
@@ -397,6 +402,71 @@ def g11():
         save("g11_loaders", meta=np.array([4, 11, 2, 2, 12]), **out)
     finally:
         shutil.rmtree(root)
+
+
+GRAD_FULL = 4096      # gradients of tensors up to this size are stored in full; larger ones as a strided sample of this many entries
+
+
+def grad_digest(g):
+    """What G12 keeps of one gradient tensor: (l2 norm, sum, numel) in float64 and a strided sample (everything when small)."""
+    flat = g.detach().double().reshape(-1)
+    stride = max(1, flat.numel() // GRAD_FULL)
+    return np.array([float(flat.norm()), float(flat.sum()), flat.numel(), stride]), flat[::stride].float().numpy()
+
+
+def g12():
+    from oracle import train_ref
+    gd.chamfer_distance = lambda x, y: (train_ref.chamfer_distance(x, y), None)      # pytorch3d stand-in (its published definition)
+    B, C = 2, 13
+    diff = ref_diffusion()
+    bt = make_synthetic_batch(B, seed=121, max_cats=C)
+    g = torch.Generator().manual_seed(122)
+    x_start = bt["given_objs"][:, 1] + 0.05 * torch.randn(B, 1024, 3, generator=g)      # a target cloud near the first object
+    noise = torch.randn(B, 1024, 3, generator=g)
+    t = torch.tensor([37, 641])
+    target_cat = torch.zeros(B, C)
+    target_cat[0, 4] = 1
+    target_cat[1, 9] = 1
+    out = dict(x_start=x_start, noise=noise, t=t, target_cat=target_cat, meta=np.array([B, C, 121, 122]))
+    for mode in ("eval", "train"):
+        m = ref_model(C)
+        m.train(mode == "train")
+        m.requires_grad_(True)
+        for p_ in m.clip_model.parameters() if hasattr(m, "clip_model") else ():
+            p_.requires_grad_(False)
+        clip._model.features = bt["text_features"]
+        torch.manual_seed(123)
+        state = torch.get_rng_state()
+        starts = [torch.randint(0, n, (B * 9,), dtype=torch.long) for n in (1024, 1024, 256, 64)]
+        drop = torch.empty(B * 9, 128, 1024).bernoulli_(0.5)          # what F.dropout draws next on the same generator (train mode)
+        torch.set_rng_state(state)
+        with torch.enable_grad():
+            terms = diff.training_losses(m, x_start.clone(), bt["mask"], t, bt["given_objs"], bt["given_cats"], target_cat, y=["p"] * B,
+                                         noise=noise.clone())
+            loss = (terms["loss"] * torch.ones(B)).mean()              # run/train_sdm.py:76 with the uniform sampler's weights
+            loss.backward()
+        out[mode + "_fps_starts"] = torch.stack([s_.clone() for s_ in starts])
+        if mode == "train":
+            out["train_dropout_mask"] = np.packbits(drop.numpy().astype(np.uint8).reshape(-1))
+        for k in ("loss", "mse", "cat_loss"):
+            out["%s_%s" % (mode, k)] = np.array(float(terms[k]))
+        sd_after = m.state_dict()
+        names, none = [], []
+        for name, p_ in m.named_parameters():
+            if name.startswith("clip_model."):
+                continue
+            if p_.grad is None:
+                none.append(name)
+                continue
+            names.append(name)
+            out["%s_gstat/%s" % (mode, name)], out["%s_grad/%s" % (mode, name)] = grad_digest(p_.grad)
+        out[mode + "_grad_names"], out[mode + "_grad_none"] = np.array(names), np.array(none)
+        if mode == "train":
+            for k, v in sd_after.items():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    out["train_running/" + k] = v.detach().clone()
+        print(mode, {k: float(terms[k]) for k in ("loss", "mse", "cat_loss")}, "params with grad:", len(names), "without:", none)
+    save("g12_training", **out)
 
 
 def long_chain(steps):

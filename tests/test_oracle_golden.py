@@ -214,3 +214,66 @@ def test_g9_loop_variants(golden):
     torch.manual_seed(95)
     smp.sample_loop(*args, skip_timesteps=1000 - K, on_step=lambda i, o: dump.__setitem__(i, o["sample"].clone()))
     assert maxabs(dump[K - 1], g["dump0"]) <= 5e-5 and maxabs(dump[0], g["dump2"]) <= 5e-5      # on_step is keyed by t
+
+
+# ---------------------------------------------------------------- G12: the training objective and its gradients
+def g12_inputs(g):
+    """Inputs of G12 regenerated from their seeds + the recorded draws (shared with the GPU training tests)."""
+    B, C, bt_seed, _ = [int(v) for v in g["meta"]]
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
+    return B, C, bt, T(g["x_start"]), T(g["noise"]), T(g["t"]).long(), T(g["target_cat"])
+
+
+def g12_check_grads(g, mode, grads, rel_norm, rel_sample):
+    """Every gradient the reference produced: l2 norm and sum within ``rel_norm`` (relative to the reference norm) and the
+    strided sample within ``rel_sample`` of the reference tensor's largest sampled magnitude; parameters the reference gives no
+    gradient (dead attention branches, Q6) must have none / zero."""
+    names = [str(v) for v in g[mode + "_grad_names"]]
+    assert len(names) == 157
+    worst = (0.0, "")
+    for name in names:
+        norm, total, numel, stride = g["%s_gstat/%s" % (mode, name)]
+        got = grads[name].detach().double().reshape(-1).cpu()
+        assert got.numel() == int(numel), name
+        if mode == "train" and name.startswith("pcd_backbone.") and name.endswith(".bias") and "conv" in name and name != "pcd_backbone.conv2.bias":
+            # a conv bias in front of a batch-statistics BatchNorm has NO effect on the loss: the exact gradient is 0 and what either
+            # implementation reports is rounding residue (reference: 3e-8 .. 1e-4 against O(1 .. 90) for live tensors)
+            assert norm <= 1e-3 and float(got.norm()) <= 1e-3, (name, norm, float(got.norm()))
+            continue
+        assert abs(float(got.norm()) - norm) <= rel_norm * norm + 1e-12, (name, float(got.norm()), norm)
+        ref = T(g["%s_grad/%s" % (mode, name)]).double()
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got[::int(stride)] - ref).abs().max()) / scale
+        worst = max(worst, (err, name))
+        assert err <= rel_sample, (name, err)
+        assert abs(float(got.sum()) - total) <= rel_norm * max(norm, abs(total)) * np.sqrt(numel) + 1e-12, name
+    for name in (str(v) for v in g[mode + "_grad_none"]):
+        assert grads.get(name) is None or float(grads[name].abs().max()) == 0.0, name
+    return worst
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_g12_training_losses_and_gradients(golden, mode):
+    """oracle/train_ref.py (autograd through cpu_ref.forward) against the real reference's diffusion.training_losses(...).backward()
+    in model.eval() and model.train(): loss terms, 157 gradients, BatchNorm running statistics after a training-mode forward."""
+    from oracle import train_ref
+    g = golden("g12_training")
+    B, C, bt, x_start, noise, t, target_cat = g12_inputs(g)
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    tab = cpu_ref.Sampler(sd).tab
+    starts = [s.long() for s in T(g[mode + "_fps_starts"])]
+    train = None
+    if mode == "train":
+        mask = np.unpackbits(g["train_dropout_mask"])[:B * 9 * 128 * 1024].reshape(B * 9, 128, 1024)
+        train = cpu_ref.TrainMode(dropout_mask=torch.from_numpy(mask.astype(np.float32)))
+    losses, grads = train_ref.losses_and_grads(sd, tab, x_start.clone(), bt["mask"], t, bt["given_objs"], bt["given_cats"], target_cat,
+                                               bt["text_features"], noise, starts, lambda_cat=0.1, train=train)
+    for k in ("loss", "mse", "cat_loss"):
+        assert abs(losses[k] - float(g["%s_%s" % (mode, k)])) <= 2e-5 * max(1.0, abs(float(g["%s_%s" % (mode, k)]))), (k, losses[k])
+    worst = g12_check_grads(g, mode, grads, rel_norm=2e-4, rel_sample=2e-4)
+    print("worst sampled gradient deviation:", worst)
+    if mode == "train":
+        for k, (rm, rv) in train.new_running.items():
+            assert maxabs(rm, g["train_running/%s.running_mean" % k]) <= 1e-5 * (1 + float(rm.abs().max()))
+            assert maxabs(rv, g["train_running/%s.running_var" % k]) <= 1e-5 * (1 + float(rv.abs().max()))
+        assert len(train.new_running) == 22
