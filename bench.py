@@ -189,11 +189,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if torch.cuda.device_count() < a.gpus:
-        sys.exit("bench.py: --gpus %d but only %d visible device(s) -- refusing to run ranks on shared GPUs" % (a.gpus, torch.cuda.device_count()))
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (python -m torch.distributed.run "
                  "--nproc-per-node %d bench.py --gpus %d ...) or run `python bench.py --gpus %d` directly" % (a.gpus, world, a.gpus, a.gpus, a.gpus))
+    if torch.cuda.device_count() < a.gpus:
+        sys.exit("bench.py: --gpus %d but only %d visible device(s) -- refusing to run ranks on shared GPUs" % (a.gpus, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -164,6 +164,41 @@ int lsdm_profile_begin(lsdm_ctx* ctx);
 int lsdm_profile_end(lsdm_ctx* ctx, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit);
 const char* lsdm_profile_kernel_name(int k);
 
+/* ---- training objective: replaces diffusion.training_losses(...) + loss.backward()  (gaussian_diffusion.py:1256-1342,
+ *      run/train_sdm.py:62-80) -------------------------------------------------------------------------------------------------
+ * A training session is its own object (it keeps every activation of a step; the sampling context keeps none).  Parameters are
+ * NOT copied: lsdm_train_bind hands over, per state_dict key (BatchNorm running_mean / running_var and
+ * sequence_pos_encoder.pe with grad = NULL), the device pointer of the caller's fp32 tensor and of the buffer that receives its
+ * gradient -- an optimizer step on the caller's tensors is seen by the next lsdm_train_step.  attn_layer.{v_proj_weight,out_proj.*}
+ * do not enter the loss and need not be bound. */
+typedef struct lsdm_train lsdm_train;
+int lsdm_train_create(lsdm_train** out, int device, int max_cats);
+int lsdm_train_destroy(lsdm_train* s);
+const char* lsdm_train_last_error(const lsdm_train* s);
+int lsdm_train_bind(lsdm_train* s, const char* name, float* param, float* grad, int64_t numel);
+/* One training batch: x_t = qa[b] x_start + qb[b] noise (q_sample, :233-256; qa = sqrt_alphas_cumprod[t], qb =
+ * sqrt_one_minus_alphas_cumprod[t] gathered from the float64 tables and cast by the caller, as _extract_into_tensor does),
+ * SceneDiffusionModel.forward(x_t, mask, t, given_objs, given_cats, text) with every activation kept,
+ *   mse      = chamfer_distance(model_output, x_start)          (:1334; pytorch3d defaults: squared L2, point mean, both directions, batch mean)
+ *   cat_loss = lambda_cat * CrossEntropy(out_cat, target)        (:1296-1300; out_cat already a softmax, target = class indices (B,))
+ *   losses   = [mse + cat_loss, mse, cat_loss]                   (device, 3 floats)
+ * and the reverse sweep: every bound gradient buffer is OVERWRITTEN with grad_scale * d (mse + cat_loss) / d parameter.
+ * flags & 1: training-mode BatchNorm (batch statistics; the bound running statistics are updated in place, momentum 0.1) --
+ * model.train() of run/train_sdm.py:46; otherwise the running statistics normalise (model.eval()).
+ * dropout_keep (nullable): (B*9,128,1024) bytes, the keep-mask of the encoder head's Dropout(0.5) (pointnet2.py:58,76), drawn by
+ * the caller (the reference draws it on the host generator right after the four FPS start draws); kept activations are doubled.
+ * fps_starts: (4, B*9) int64 as in lsdm_step.  model_output (B,1024,3) and out_cat (B,max_cats) are optional outputs. */
+int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const float* qa, const float* qb, const float* noise,
+                    const int64_t* t, const float* mask, const float* given_objs, const float* given_cats, const int64_t* target,
+                    const float* text, const int64_t* fps_starts, const unsigned char* dropout_keep, float lambda_cat,
+                    float grad_scale, float* losses, float* model_output, float* out_cat, void* stream);
+
+/* Test hook: copies an intermediate of the LAST lsdm_train_step to host memory (synchronises the step's stream).
+ * "sa1.arg" .. "sa4.arg": uint8 (B*9 * S, C) -- which of the 32 neighbours attains the max of every (centroid, channel), i.e. where the
+ * max-pool routes the gradient.  (Two neighbours whose activations differ in the last bits make that choice depend on the summation
+ * order of the layer before; the parity test injects these choices into the oracle and checks that every difference IS such a near-tie.) */
+int lsdm_train_read(lsdm_train* s, const char* name, void* host_dst, int64_t capacity_bytes, int64_t* nbytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,12 @@ _SIGNATURES = {
     "lsdm_profile_begin": (_i, [_vp]),
     "lsdm_profile_end": (_i, [_vp, _i, _vp, _vp, _vp]),
     "lsdm_profile_kernel_name": (C.c_char_p, [_i]),
+    "lsdm_train_create": (_i, [C.POINTER(_vp), _i, _i]),
+    "lsdm_train_destroy": (_i, [_vp]),
+    "lsdm_train_last_error": (C.c_char_p, [_vp]),
+    "lsdm_train_bind": (_i, [_vp, C.c_char_p, _vp, _vp, C.c_int64]),
+    "lsdm_train_read": (_i, [_vp, C.c_char_p, _vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "lsdm_train_step": (_i, [_vp, _i, _i] + [_vp] * 12 + [_f, _f] + [_vp] * 4),
 }
 EXPORTS = tuple(_SIGNATURES)
 

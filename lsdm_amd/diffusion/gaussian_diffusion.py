@@ -356,33 +356,25 @@ class GaussianDiffusion:
             final = sample
         return dump if dump_steps is not None else final["sample"]
 
-    # ------------------------------------------------------------------ training objective (forward values)
-    def training_losses(self, model, cf, mask, t, given_objs, given_cats, target_cat, y=None, noise=None):
-        """The loss terms of one training batch (gaussian_diffusion.py:1256-1342; MSE loss type, START_X, fixed variance):
-        x_t = q_sample(cf, t, noise); (out_cat, x0_hat) = model(x_t, ...);
+    # ------------------------------------------------------------------ training objective
+    def training_losses(self, model, cf, mask, t, given_objs, given_cats, target_cat, y=None, noise=None, **draws):
+        """The loss terms of one training batch AND their gradient (gaussian_diffusion.py:1256-1342; MSE loss type, START_X, fixed
+        variance): x_t = q_sample(cf, t, noise); (out_cat, x0_hat) = model(x_t, ...);
         ``cat_loss`` = lambda_cat * CrossEntropyLoss()(out_cat, argmax(target_cat)) -- out_cat are SOFTMAX outputs used as logits,
         as in the reference (:1296-1300); ``mse`` = pytorch3d chamfer_distance(x0_hat, cf) (:1334; mean squared nearest-neighbour
         distance, both directions summed, batch mean); ``loss`` = mse + cat_loss.
-        Every term is evaluated on the HIP path (network forward through liblsdm_hip, chamfer through lsdm_nn_distance).  These
-        are forward VALUES: the HIP kernels have no backward pass, so the tensors carry no autograd graph (run/train_sdm.py
-        reports them and refuses to step an optimizer)."""
-        from ..metrics import chamfer_distance
+        Everything runs in liblsdm_hip (``lsdm_train_step``, lsdm_amd/csrc/train.hip); ``terms["loss"]`` is a node of torch's graph whose
+        backward hands the library's d loss / d theta to the parameters (lsdm_amd/training.py), so ``loss.backward(); optimizer.step()``
+        of run/train_sdm.py:76-80 works unchanged.  ``model.training`` selects batch-statistics BatchNorm + the encoder head's dropout
+        (the reference's ``model.train()``); ``model.eval()`` gives the running-statistics objective ``validate()`` style."""
+        from ..training import training_losses
         if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE) or self.model_var_type != ModelVarType.FIXED_SMALL \
                 or self.model_mean_type != ModelMeanType.START_X:
             raise NotImplementedError("LSDM trains with MSE / START_X / FIXED_SMALL (util/model_util.py:127-163)")
-        x_start = cf
-        if noise is None:
-            noise = self._noise_like(x_start)
-        x_t = self.q_sample(x_start, t, noise=noise).contiguous()
-        out_cat, model_output = model(x_t, mask, self._scale_timesteps(t), given_objs, given_cats, y)
-        terms = {}
-        target = th.argmax(target_cat, dim=1)
-        cat_loss = th.nn.functional.cross_entropy(out_cat.squeeze(1), target) * self.lambda_cat
-        terms["cat_loss"] = cat_loss
-        assert model_output.shape == x_start.shape
-        terms["mse"] = chamfer_distance(model_output.float(), x_start.float())
-        terms["loss"] = terms["mse"] + cat_loss
-        return terms
+        m = _unwrap(model)
+        if not isinstance(m, SceneDiffusionModel):
+            raise NotImplementedError("training_losses runs on the HIP SceneDiffusionModel only (no eager fallback)")
+        return training_losses(self, m, cf, mask, t, given_objs, given_cats, target_cat, y=y, noise=noise, **draws)
 
     def ddim_sample_loop_progressive(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                                      denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False,

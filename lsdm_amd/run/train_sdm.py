@@ -1,14 +1,17 @@
-"""``python -m run.train_sdm`` -- the forward side of the reference's training script (run/train_sdm.py).
+"""``python -m run.train_sdm`` -- drop-in for the reference's training script (run/train_sdm.py) on the HIP path.
 
-What exists: the flags of run/train_sdm.py:187-213, the per-batch objective of ``train()`` (:30-107: uniform timestep sampler,
-``diffusion.training_losses``, ``(losses["loss"] * weights).mean()``) and the whole of ``validate()`` (:110-183: p_sample_loop,
-squared-error / chamfer / category accuracy, the reference's report line) -- all evaluated on the HIP path.
-What does not: parameter updates.  The HIP kernels have no backward pass, so ``--forward_only`` (report the objective of
-every batch without stepping) is the only training mode; without it the script stops with a clear error BEFORE touching
-an optimizer.  Additions: ``--synthetic N``, ``--device``, ``--forward_only``, ``--valid_skip_timesteps`` (shorter chains for
-smoke runs; 0 = the reference's full T = 1000)."""
+The flags of run/train_sdm.py:187-213; ``train()`` (:30-107: ``model.train()``, a fresh ``AdamW(lr)`` per epoch, uniform timestep
+sampler, ``diffusion.training_losses`` -> ``(losses["loss"] * weights).mean()`` -> ``backward`` -> ``optimizer.step()``); ``validate()``
+(:110-183: ``model.eval()``, p_sample_loop, squared error / chamfer / category accuracy, the reference's report line); checkpoints
+``<out_dir>/<experiment>/model_ckpt/epoch_%04d.pt`` + ``best_model_valid_loss.pt`` / ``best_model_cfd.pt`` every ``save_interval``
+epochs (:296-330).  The objective and its gradients come from ``lsdm_train_step`` (lsdm_amd/training.py); the optimizer is torch's
+AdamW on the device tensors the library reads in place.  No tensorboard writer (the package is absent; the scalars are printed).
+Additions: ``--synthetic N``, ``--device``, ``--forward_only`` (report the eval-mode objective of every batch without stepping),
+``--valid_skip_timesteps`` (shorter validation chains for smoke runs; 0 = the reference's full T = 1000), ``--batch_size``."""
 import argparse
+import os
 import sys
+import time
 
 import torch
 from torch.utils.data import DataLoader
@@ -51,24 +54,42 @@ def build_parser():
     return p
 
 
-def training_objective(model, diffusion, loader, device, sampler=None):
-    """One pass of run/train_sdm.py:52-82 without the optimizer: -> (mean objective, per-batch list of term dicts)."""
+def training_objective(model, diffusion, loader, device, sampler=None, optimizer=None):
+    """One pass of run/train_sdm.py:52-82: -> (mean objective, per-batch list of term dicts).  With ``optimizer`` every batch is a
+    training step (zero_grad, backward, step); without, the objective is only evaluated (no graph, no update)."""
     sampler = sampler or create_named_schedule_sampler('uniform', diffusion)
     total, batches = 0.0, []
     for mask, given_objs, given_cats, target_obj, target_cat, y in loader:
         mask, given_objs, given_cats = mask.to(device), given_objs.to(device), given_cats.to(device)
         target_obj, target_cat = target_obj.float().to(device), target_cat.to(device)
         t, weights = sampler.sample(target_obj.shape[0], device)
-        losses = diffusion.training_losses(model, target_obj, mask, t, given_objs, given_cats, target_cat, y=y)
-        loss = (losses["loss"] * weights).mean()
+        if optimizer is not None:
+            optimizer.zero_grad()
+        with torch.set_grad_enabled(optimizer is not None):
+            losses = diffusion.training_losses(model, target_obj, mask, t, given_objs, given_cats, target_cat, y=y)
+            loss = (losses["loss"] * weights).mean()
+        if optimizer is not None:
+            loss.backward()
+            optimizer.step()
         total += float(loss)
-        batches.append({k: float(v) for k, v in losses.items()})
+        batches.append({k: float(v) for k, v in losses.items() if v.dim() == 0})
     return total / max(len(batches), 1), batches
+
+
+def train(model, diffusion, loader, device, lr):
+    """run/train_sdm.py:30-107: one epoch in ``model.train()`` with a fresh AdamW (the reference builds its optimizer inside train())."""
+    model.train()
+    model.requires_grad_(True)
+    optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr)
+    total, _ = training_objective(model, diffusion, loader, device, optimizer=optimizer)
+    print('====> Total_train_loss: {:.4f}'.format(total))
+    return total
 
 
 def validate(model, diffusion, loader, device, skip_timesteps=0):
     """run/train_sdm.py:110-183: -> (recon_loss_semantics, chamfer distance, category accuracy), each a batch mean."""
     tot_sq, tot_cfd, tot_acc, n = 0.0, 0.0, 0.0, 0
+    model.eval()
     with torch.no_grad():
         for mask, given_objs, given_cats, target_obj, target_cat, y in loader:
             mask, given_objs, given_cats = mask.to(device), given_objs.to(device), given_cats.to(device)
@@ -112,15 +133,33 @@ def main(argv=None):
         model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=model.max_cats))
     if text_encoder is not None:
         model.text_encoder = text_encoder
-    if not args.forward_only:
-        raise NotImplementedError("run.train_sdm: parameter updates need the backward pass of the HIP kernels, which is not built "
-                                  "(SURVEY.md 8 f-4); use --forward_only to evaluate the training objective and the validation pass")
+    save_dir = os.path.join(args.out_dir, args.experiment, "model_ckpt")
+    best_valid, best_cfd = float('inf'), float('inf')
     for e in range(args.epochs):
         print('Training epoch {}'.format(e))
-        total, _ = training_objective(model, diffusion, train_loader, device)
-        print('====> Total_train_loss: {:.4f}'.format(total))
-        if e % args.save_interval == args.save_interval - 1 or e == args.epochs - 1:
-            validate(model, diffusion, valid_loader, device, args.valid_skip_timesteps)
+        t0 = time.time()
+        if args.forward_only:
+            model.eval()
+            total, _ = training_objective(model, diffusion, train_loader, device)
+            print('====> Total_train_loss: {:.4f}'.format(total))
+        else:
+            total = train(model, diffusion, train_loader, device, args.lr)
+        print('training_time = {:.4f}'.format(time.time() - t0))
+        if e % args.save_interval == args.save_interval - 1 or (args.forward_only and e == args.epochs - 1):
+            valid_loss, cfd, _ = validate(model, diffusion, valid_loader, device, args.valid_skip_timesteps)
+            if args.forward_only:
+                continue
+            os.makedirs(save_dir, exist_ok=True)
+            data = {'epoch': e, 'model_state_dict': model.state_dict(), 'total_train_loss': total, 'total_valid_loss': valid_loss}
+            torch.save(data, os.path.join(save_dir, 'epoch_{:04d}.pt'.format(e)))
+            if valid_loss < best_valid:
+                print("Updated best model due to new lowest valid_loss. Current epoch: {}".format(e))
+                best_valid = valid_loss
+                torch.save(data, os.path.join(save_dir, 'best_model_valid_loss.pt'))
+            if cfd < best_cfd:
+                print("Updated best model due to new highest total_cfd. Current epoch: {}".format(e))
+                best_cfd = cfd
+                torch.save(data, os.path.join(save_dir, 'best_model_cfd.pt'))
     return 0
 
 

@@ -147,15 +147,17 @@ def _bn(sd, prefix):
     return {k: sd[prefix + "." + k] for k in ("weight", "bias", "running_mean", "running_var")}
 
 
-def set_abstraction(sd, name, level, xyz, points, start, taps=None, train=None):
+def set_abstraction(sd, name, level, xyz, points, start, taps=None, train=None, pool_inject=None):
     """PointNetSetAbstraction.forward (pointnet2_utils.py:173-199) + sample_and_group (:107-135).
 
     xyz (B,N,3), points (B,N,D) channel-last.  Returns new_xyz (B,S,3), new_points (B,S,C').
     Grouped feature order is [xyz - centroid (3) || points (D)] (:126-130)."""
     npoint, radius, nsample = SA_CFG[level]
-    fps_idx = farthest_point_sample(xyz, npoint, start)
+    # (geometry decisions always in fp32 -- no-ops on the fp32 path; a float64 run of the oracle, used to measure the conditioning of
+    # the gradients, keeps the reference's discrete decisions)
+    fps_idx = farthest_point_sample(xyz.float(), npoint, start)
     new_xyz = gather_rows(xyz, fps_idx)
-    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    idx = query_ball_point(radius, nsample, xyz.float(), new_xyz.float())
     grouped_xyz = gather_rows(xyz, idx) - new_xyz[:, :, None, :]
     grouped = torch.cat([grouped_xyz, gather_rows(points, idx)], dim=-1)  # (B,S,ns,3+D)
     h = grouped.permute(0, 3, 2, 1)  # (B,C,ns,S)
@@ -163,7 +165,15 @@ def set_abstraction(sd, name, level, xyz, points, start, taps=None, train=None):
         p = "pcd_backbone.%s" % name
         h = _conv_bn_relu(h, sd["%s.mlp_convs.%d.weight" % (p, i)], sd["%s.mlp_convs.%d.bias" % (p, i)],
                           _bn(sd, "%s.mlp_bns.%d" % (p, i)), 2, train, "%s.mlp_bns.%d" % (p, i))
-    new_points = torch.max(h, 2)[0].permute(0, 2, 1).contiguous()  # (B,S,C')
+    if pool_inject is not None and name in pool_inject:
+        # tests only: take THESE neighbours (B,S,C') instead of the arg-max's -- the value differs from the max only where two
+        # neighbours tie to rounding, but the gradient is routed to the given one (attributes a deviation to near-ties)
+        pick = pool_inject[name].long().permute(0, 2, 1).unsqueeze(2)          # (B,C',1,S)
+        new_points = torch.gather(h, 2, pick).squeeze(2).permute(0, 2, 1).contiguous()
+    else:
+        new_points = torch.max(h, 2)[0].permute(0, 2, 1).contiguous()  # (B,S,C')
+    if taps is not None and taps.get("want_pool_in"):
+        taps["%s.pool_in" % name] = h
     if taps is not None:
         taps["%s.fps_idx" % name] = fps_idx
         taps["%s.ball_idx" % name] = idx
@@ -190,7 +200,8 @@ def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=No
     of exactly tied distances (``torch.sort`` is not stable): with the other implementation's equally-near choice injected,
     everything downstream must agree to rounding."""
     B, N, _ = xyz1.shape
-    idx, w = three_nn(xyz1, xyz2)
+    idx, w = three_nn(xyz1.float(), xyz2.float())
+    w = w.to(points2.dtype)
     if nn_inject is not None:
         idx = nn_inject.long()
         d = torch.gather(square_distance(xyz1, xyz2), 2, idx)
@@ -211,13 +222,13 @@ def feature_propagation(sd, name, nlayers, xyz1, xyz2, points1, points2, taps=No
     return out
 
 
-def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72, train=None):
+def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72, train=None, pool_inject=None):
     """get_backbone.forward (pointnet2.py:61-80).  clouds (BO,N,3); starts = 4 int64 tensors (BO,).
 
     Clouds are independent (eval-mode BatchNorm), so more than ``chunk`` of them are evaluated ``chunk`` at a time -- the
     (BO,1024,1024) distance temporaries of 576 clouds would need tens of GB -- with identical results.
     ``nn_inject``: optional {"fp4"|"fp3"|"fp2"|"fp1": (BO,N,3) indices}, see feature_propagation."""
-    if clouds.shape[0] > chunk and train is None:      # (training-mode BatchNorm couples the clouds of a batch)
+    if clouds.shape[0] > chunk and train is None and pool_inject is None:      # (training-mode BatchNorm couples the clouds of a batch)
         outs, parts = [], []
         for lo in range(0, clouds.shape[0], chunk):
             sl = slice(lo, lo + chunk)
@@ -232,10 +243,10 @@ def scene_encoder(sd, clouds, starts, taps=None, nn_inject=None, chunk=72, train
     inj = nn_inject or {}
     l0_xyz = clouds
     l0_points = clouds  # dimension=3: features are the coordinates themselves (:63-64)
-    l1_xyz, l1_points = set_abstraction(sd, "sa1", 0, l0_xyz, l0_points, starts[0], taps, train)
-    l2_xyz, l2_points = set_abstraction(sd, "sa2", 1, l1_xyz, l1_points, starts[1], taps, train)
-    l3_xyz, l3_points = set_abstraction(sd, "sa3", 2, l2_xyz, l2_points, starts[2], taps, train)
-    l4_xyz, l4_points = set_abstraction(sd, "sa4", 3, l3_xyz, l3_points, starts[3], taps, train)
+    l1_xyz, l1_points = set_abstraction(sd, "sa1", 0, l0_xyz, l0_points, starts[0], taps, train, pool_inject)
+    l2_xyz, l2_points = set_abstraction(sd, "sa2", 1, l1_xyz, l1_points, starts[1], taps, train, pool_inject)
+    l3_xyz, l3_points = set_abstraction(sd, "sa3", 2, l2_xyz, l2_points, starts[2], taps, train, pool_inject)
+    l4_xyz, l4_points = set_abstraction(sd, "sa4", 3, l3_xyz, l3_points, starts[3], taps, train, pool_inject)
     l3_points = feature_propagation(sd, "fp4", 2, l3_xyz, l4_xyz, l3_points, l4_points, taps, inj.get("fp4"), train)
     l2_points = feature_propagation(sd, "fp3", 2, l2_xyz, l3_xyz, l2_points, l3_points, taps, inj.get("fp3"), train)
     l1_points = feature_propagation(sd, "fp2", 2, l1_xyz, l2_xyz, l1_points, l2_points, taps, inj.get("fp2"), train)
@@ -298,7 +309,8 @@ def denoise_mlp(sd, z, emb):
     return h
 
 
-def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_starts=None, taps=None, pcd_override=None, train=None):
+def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_starts=None, taps=None, pcd_override=None, train=None,
+            pool_inject=None):
     """One denoising-network evaluation.  Mutates ``x`` in place (Q5).  Returns (out_cat, out, guiding).
     ``pcd_override`` (tests only): a precomputed scene-encoder output (B,O,3072) used instead of running the encoder.
 
@@ -328,7 +340,7 @@ def forward(sd, x, mask, timesteps, given_objs, given_cats, text_features, fps_s
     if pcd_override is not None:
         pcd = pcd_override.reshape(B, O, -1)
     else:
-        pcd = scene_encoder(sd, given_objs.reshape(B * O, N, 3), fps_starts, taps, train=train).reshape(B, O, -1)
+        pcd = scene_encoder(sd, given_objs.reshape(B * O, N, 3), fps_starts, taps, train=train, pool_inject=pool_inject).reshape(B, O, -1)
     # 8. object attention weights (sdm.py:180-182): 8 heads x 16, float mask ADDED (Q4), row (b,h) of the
     #    mask is mask[(b*8+h) % B] (Q3); only the head-averaged weights are used (Q6).
     wq, wk = sd["attn_layer.q_proj_weight"], sd["attn_layer.k_proj_weight"]

@@ -38,11 +38,12 @@ def q_sample(tab, x_start, t, noise):
 
 
 def training_losses(sd, tab, x_start, mask, t, given_objs, given_cats, target_cat, text_features, noise, fps_starts, lambda_cat=0.1,
-                    train=None):
+                    train=None, pool_inject=None, taps=None):
     """Returns {"loss", "mse", "cat_loss"} (scalars).  ``sd`` may hold tensors with requires_grad; ``train`` = cpu_ref.TrainMode or
     None (eval-mode BatchNorm, no dropout)."""
-    x_t = q_sample(tab, x_start, t, noise)
-    out_cat, out, _ = cpu_ref.forward(sd, x_t, mask, t, given_objs, given_cats, text_features, fps_starts, train=train)
+    x_t = q_sample(tab, x_start, t, noise).to(x_start.dtype)
+    out_cat, out, _ = cpu_ref.forward(sd, x_t, mask, t, given_objs, given_cats, text_features, fps_starts, train=train,
+                                      pool_inject=pool_inject, taps=taps)
     cat_loss = F.cross_entropy(out_cat.squeeze(1), torch.argmax(target_cat, dim=1)) * lambda_cat
     mse = chamfer_distance(out.float(), x_start.float())
     return {"loss": mse + cat_loss, "mse": mse, "cat_loss": cat_loss}
@@ -54,10 +55,18 @@ def trainable_names(sd):
                                   or k.endswith(".pe"))]
 
 
-def losses_and_grads(sd, tab, *args, **kw):
+def losses_and_grads(sd, tab, *args, dtype=None, **kw):
     """training_losses + backward.  Returns (losses: dict of floats, grads: dict name -> tensor; parameters the loss does not
-    depend on -- the value / output projections of the two attention modules' dead branches, Q6 -- map to None)."""
-    leaves = {k: (v.detach().clone().requires_grad_(True) if k in set(trainable_names(sd)) else v) for k, v in sd.items()}
+    depend on -- the value / output projections of the two attention modules' dead branches, Q6 -- map to None).
+    ``dtype=torch.float64`` evaluates the same graph in double precision with the discrete geometry decisions still taken in fp32
+    (cpu_ref.set_abstraction / feature_propagation): the mathematically exact gradient of the reference's objective, against which
+    the conditioning of an fp32 evaluation can be measured (in training mode torch's own fp32 result is 6e-4 .. 1e-3 away from it)."""
+    cast = (lambda v: v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) if dtype is not None else (lambda v: v)
+    names = set(trainable_names(sd))
+    leaves = {k: (cast(v).detach().clone().requires_grad_(True) if k in names else cast(v)) for k, v in sd.items()}
+    args = [cast(a) for a in args]
+    if kw.get("train") is not None and kw["train"].dropout_mask is not None:
+        kw["train"].dropout_mask = cast(kw["train"].dropout_mask)
     with torch.enable_grad():
         terms = training_losses(leaves, tab, *args, **kw)
         terms["loss"].backward()

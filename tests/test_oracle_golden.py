@@ -224,13 +224,13 @@ def g12_inputs(g):
     return B, C, bt, T(g["x_start"]), T(g["noise"]), T(g["t"]).long(), T(g["target_cat"])
 
 
-def g12_check_grads(g, mode, grads, rel_norm, rel_sample):
-    """Every gradient the reference produced: l2 norm and sum within ``rel_norm`` (relative to the reference norm) and the
-    strided sample within ``rel_sample`` of the reference tensor's largest sampled magnitude; parameters the reference gives no
-    gradient (dead attention branches, Q6) must have none / zero."""
+def g12_check_grads(g, mode, grads, rel_l2, rel_max):
+    """Every gradient the reference produced, per tensor: relative l2 error (over the recorded entries: all of a small tensor, a
+    strided sample of a large one) <= ``rel_l2``, largest entry-wise error <= ``rel_max`` of the tensor's largest entry, l2 norm of
+    the whole tensor within ``rel_l2``; parameters the reference gives no gradient (dead attention branches, Q6) must have none / zero."""
     names = [str(v) for v in g[mode + "_grad_names"]]
     assert len(names) == 157
-    worst = (0.0, "")
+    worst, failures = (0.0, 0.0, ""), []
     for name in names:
         norm, total, numel, stride = g["%s_gstat/%s" % (mode, name)]
         got = grads[name].detach().double().reshape(-1).cpu()
@@ -240,13 +240,14 @@ def g12_check_grads(g, mode, grads, rel_norm, rel_sample):
             # implementation reports is rounding residue (reference: 3e-8 .. 1e-4 against O(1 .. 90) for live tensors)
             assert norm <= 1e-3 and float(got.norm()) <= 1e-3, (name, norm, float(got.norm()))
             continue
-        assert abs(float(got.norm()) - norm) <= rel_norm * norm + 1e-12, (name, float(got.norm()), norm)
         ref = T(g["%s_grad/%s" % (mode, name)]).double()
-        scale = float(ref.abs().max()) + 1e-30
-        err = float((got[::int(stride)] - ref).abs().max()) / scale
-        worst = max(worst, (err, name))
-        assert err <= rel_sample, (name, err)
-        assert abs(float(got.sum()) - total) <= rel_norm * max(norm, abs(total)) * np.sqrt(numel) + 1e-12, name
+        diff = got[::int(stride)] - ref
+        l2 = float(diff.norm()) / (float(ref.norm()) + 1e-30)
+        mx = float(diff.abs().max()) / (float(ref.abs().max()) + 1e-30)
+        worst = max(worst, (l2, mx, name))
+        if l2 > rel_l2 or mx > rel_max or abs(float(got.norm()) - norm) > rel_l2 * norm + 1e-12:
+            failures.append((name, "l2 %.2e" % l2, "max %.2e" % mx, "norm %.6g vs %.6g" % (float(got.norm()), norm)))
+    assert not failures, "\n".join(str(f) for f in failures)
     for name in (str(v) for v in g[mode + "_grad_none"]):
         assert grads.get(name) is None or float(grads[name].abs().max()) == 0.0, name
     return worst
@@ -270,7 +271,7 @@ def test_g12_training_losses_and_gradients(golden, mode):
                                                bt["text_features"], noise, starts, lambda_cat=0.1, train=train)
     for k in ("loss", "mse", "cat_loss"):
         assert abs(losses[k] - float(g["%s_%s" % (mode, k)])) <= 2e-5 * max(1.0, abs(float(g["%s_%s" % (mode, k)]))), (k, losses[k])
-    worst = g12_check_grads(g, mode, grads, rel_norm=2e-4, rel_sample=2e-4)
+    worst = g12_check_grads(g, mode, grads, rel_l2=2e-4, rel_max=2e-4)
     print("worst sampled gradient deviation:", worst)
     if mode == "train":
         for k, (rm, rv) in train.new_running.items():
