@@ -15,8 +15,9 @@
  *   - one context per (process, device); a context is not thread-safe; different contexts are independent.
  *   - all floating-point tensors are fp32, dense, row-major; timesteps / FPS starts are int64 (torch.long),
  *     internal index outputs are int32.
- *   - fixed by the model (model/sdm.py:19-22, pointnet2.py:46-55): 9 object slots, 1024 points per cloud,
- *     text feature width 512, latent 128.
+ *   - fixed by the model (model/sdm.py:19-22, pointnet2.py:46-55): 9 object slots, 1024 points per cloud, latent 128.
+ *     The text feature width D is the model's clip_dim, read off embed_text.0.weight (D/2, D): 512 with the defaults of
+ *     util/model_util.py (CLIP ViT-B/32), 768 for the BERT pooler output (model/sdm.py:261-264); every `text` pointer is (B, D).
  */
 #ifndef LSDM_HIP_H
 #define LSDM_HIP_H
@@ -81,7 +82,7 @@ int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
  *   t            (B)          int64 timesteps (index into the schedule tables and the pe buffer)
  *   given_objs   (B,9,1024,3)
  *   given_cats   (B,9,C)
- *   text_feat    (B,512)      CLIP encode_text output (the path boundary, model/sdm.py:147)
+ *   text_feat    (B,D)        text-encoder output, D = clip_dim (the path boundary, model/sdm.py:146-149)
  *   fps_start    (4,B*9)      int64 FPS start indices of sa1..sa4 (pointnet2_utils.py:72), ranges 1024,1024,256,64
  *   noise        (B,1024,3)   randn draw of p_sample (gaussian_diffusion.py:545); may be NULL for LSDM_MODE_FORWARD
  *   out_cat      (B,1,C)      softmax category prediction (= model.saved_cat)

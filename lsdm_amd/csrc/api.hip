@@ -956,9 +956,17 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
         ok = pe != nullptr;
         if (ok) c->cond.pe = upload(c, pe->data.data(), pe->data.size());
     }
+    // the width of the text feature is the model's clip_dim (model/sdm.py:52-59): read off embed_text.0.weight (D/2, D)
+    int D = 512;
+    if (ok) {
+        auto it = c->host.find("embed_text.0.weight");
+        if (it != c->host.end() && it->second.shape.size() == 2) D = (int)it->second.shape[1];
+        if (D < 2 || D > 1024 || D % 2) { fail(c, LSDM_ERR_PARAM, "embed_text.0.weight: text feature width %d is not an even number <= 1024", D); ok = false; }
+        c->cond.text_dim = D;
+    }
     ok = ok && load_lin(c, "embed_timestep.time_embed.0", 128, 128, &c->cond.time0) &&
-         load_lin(c, "embed_timestep.time_embed.2", 128, 128, &c->cond.time2) && load_lin(c, "embed_text.0", 256, 512, &c->cond.text0) &&
-         load_lin(c, "embed_text.2", 256, 256, &c->cond.text2) && load_lin(c, "embed_text.4", 128, 256, &c->cond.text4) &&
+         load_lin(c, "embed_timestep.time_embed.2", 128, 128, &c->cond.time2) && load_lin(c, "embed_text.0", D / 2, D, &c->cond.text0) &&
+         load_lin(c, "embed_text.2", 256, D / 2, &c->cond.text2) && load_lin(c, "embed_text.4", 128, 256, &c->cond.text4) &&
          load_lin(c, "predict_cat.0", 64, 128, &c->cond.pcat0) && load_lin(c, "predict_cat.2", 32, 64, &c->cond.pcat2) &&
          load_lin(c, "predict_cat.4", C, 32, &c->cond.pcat4) && load_lin(c, "embed_cat.0", 32, C, &c->cond.ecat) &&
          load_lin(c, "translation_layer.0", 128, 160, &c->cond.tr0) && load_lin(c, "translation_layer.2", 12, 128, &c->cond.tr2);

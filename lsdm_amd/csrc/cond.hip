@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
                                                    const float* __restrict__ given_cats, const float* __restrict__ mask, int B,
                                                    int C, float* __restrict__ out_cat, float* __restrict__ e0,
                                                    float* __restrict__ tr_out, float* __restrict__ w_out, int time_only, int tstride) {
-    __shared__ float sa[512], sb[512], enc[128], ecat[kSlots * 32], trh[kSlots * 128];
+    __shared__ float sa[1024], sb[512], enc[128], ecat[kSlots * 32], trh[kSlots * 128];
     __shared__ float q[128], kk[kSlots * 128], logit[8 * kSlots];
     // A launch may cover G consecutive steps of the same batch (grid = G*B): block r = step*B + b reads the conditioning
     // of sample b and step `step`'s timestep, and writes row r of e0 / tr / w (the front sets are contiguous).
@@ -50,13 +50,14 @@ __global__ __launch_bounds__(256) void cond_kernel(CondParams P, const int64_t* 
     __syncthreads();
     dense_vec<ACT_NONE>(sb, 128, P.time2, e0 + (size_t)r * 256, 128);
     if (time_only) return;
-    // 2. text embedding 512 -> 256 -> 256 -> 128, GELU after every layer (Q9)
+    // 2. text embedding D -> D/2 -> 256 -> 128, GELU after every layer (Q9); D = clip_dim <= 1024
     __syncthreads();
-    for (int k = tid; k < 512; k += 256) sa[k] = text[(size_t)b * 512 + k];
+    const int D = P.text_dim;
+    for (int k = tid; k < D; k += 256) sa[k] = text[(size_t)b * D + k];
     __syncthreads();
-    dense_vec<ACT_GELU>(sa, 512, P.text0, sb, 256);
+    dense_vec<ACT_GELU>(sa, D, P.text0, sb, D / 2);
     __syncthreads();
-    dense_vec<ACT_GELU>(sb, 256, P.text2, sa, 256);
+    dense_vec<ACT_GELU>(sb, D / 2, P.text2, sa, 256);
     __syncthreads();
     dense_vec<ACT_GELU>(sa, 256, P.text4, enc, 128);
     __syncthreads();

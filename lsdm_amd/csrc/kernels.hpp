@@ -20,7 +20,8 @@ struct Lin {  // plain torch.nn.Linear parameters: weight (N,K) row-major, bias 
 struct CondParams {
     const float* pe;                            // sequence_pos_encoder.pe (5000,1,128)
     Lin time0, time2;                           // embed_timestep.time_embed.{0,2}
-    Lin text0, text2, text4;                    // embed_text.{0,2,4}
+    Lin text0, text2, text4;                    // embed_text.{0,2,4}: D -> D/2 -> 256 -> 128
+    int text_dim;                               // D = clip_dim: 512 (CLIP ViT-B/32, util/model_util.py:26-72) or 768 (BERT pooler, sdm.py:261-264)
     Lin pcat0, pcat2, pcat4;                    // predict_cat.{0,2,4}
     Lin ecat;                                   // embed_cat.0
     const float *attn_wq, *attn_wk, *attn_inb;  // attn_layer.{q,k}_proj_weight, in_proj_bias

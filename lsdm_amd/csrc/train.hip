@@ -888,9 +888,14 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
     Ten th = dense(s, pe_t, "embed_timestep.time_embed.0", 128, T_SILU, nullptr, false);
     Ten ets = cols(e0, 0, 128);
     dense(s, th, "embed_timestep.time_embed.2", 128, T_NONE, &ets);
-    // 2. text embedding 512 -> 256 -> 256 -> 128, GELU after every layer (Q9)
-    Ten tx; tx.d = const_cast<float*>(text); tx.rows = B; tx.C = 512; tx.ld = 512;
-    Ten t1 = dense(s, tx, "embed_text.0", 256, T_GELU, nullptr, false);
+    // 2. text embedding D -> D/2 -> 256 -> 128, GELU after every layer (Q9); D = clip_dim from the bound embed_text.0.weight (D/2, D)
+    int D = 512;
+    {
+        auto it = s->bound.find("embed_text.0.weight");
+        if (it != s->bound.end()) D = (int)std::llround(std::sqrt(2.0 * (double)it->second.n));
+    }
+    Ten tx; tx.d = const_cast<float*>(text); tx.rows = B; tx.C = D; tx.ld = D;
+    Ten t1 = dense(s, tx, "embed_text.0", D / 2, T_GELU, nullptr, false);
     Ten t2 = dense(s, t1, "embed_text.2", 256, T_GELU);
     Ten enc = cols(e0, 128, 128);
     dense(s, t2, "embed_text.4", 128, T_GELU, &enc);

@@ -77,8 +77,10 @@ class GaussianDiffusion:
         self.rescale_timesteps = rescale_timesteps
         self.data_rep = data_rep
         self.lambda_cat = lambda_cat
-        # host_rng=True draws the per-step noise from the CPU generator (parity with the CPU reference);
-        # False uses the device generator like the reference does when it runs on an accelerator.
+        # host_rng=True draws x_T, the per-step FPS starts and the per-step noise from the CPU generator in the reference's order
+        # (parity with the CPU reference).  False = throughput mode: all of them from the DEVICE generator (the reference on an
+        # accelerator draws its noise there too; its FPS starts stay on the host, pointnet2_utils.py:72) -- nothing is drawn or
+        # uploaded by the host inside the loop.
         self.host_rng = host_rng
         betas = np.array(betas, dtype=np.float64)
         assert betas.ndim == 1 and (betas > 0).all() and (betas <= 1).all()
@@ -195,7 +197,11 @@ class GaussianDiffusion:
     def _fused_step(self, mode, eta, model, x, mask, t, given_objs, given_cats, y, const_noise):
         inner = _unwrap(model)
         inner._set_schedule(self._schedule_key(), self._device_tables())
-        _, x0, sample = inner._run(mode, eta, x, mask, t, given_objs, given_cats, y,
+        starts = None
+        if not self.host_rng and x.is_cuda:       # device-RNG mode: the FPS starts come from the device generator as well
+            from ..model.sdm import FPS_RANGES, NUM_SLOTS
+            starts = [th.randint(0, n, (x.shape[0] * NUM_SLOTS,), device=x.device, dtype=th.long) for n in FPS_RANGES]
+        _, x0, sample = inner._run(mode, eta, x, mask, t, given_objs, given_cats, y, fps_starts=starts, trusted_starts=starts is not None,
                                    noise_fn=lambda: self._noise_like(x, const_noise))
         return {"sample": sample, "pred_xstart": x0}
 
@@ -254,6 +260,19 @@ class GaussianDiffusion:
                 starts_d = (pinned if hoist_conditioning else st["starts"][:k]).to(x.device, non_blocking=True)
                 st["ev"] = th.cuda.Event()
                 st["ev"].record(th.cuda.current_stream(x.device))
+            elif not self.host_rng and x.is_cuda:
+                # Device-RNG (throughput) mode: the FPS starts and the noise of the chunk come from the DEVICE generator -- two
+                # launches per chunk, no host draw, no upload; deterministic under torch.manual_seed (which seeds the device
+                # generator too), statistically the same process, not comparable draw by draw with the CPU reference.
+                if hoist_conditioning:
+                    if pinned is None:
+                        pinned = th.stack([th.randint(0, n, (B * NUM_SLOTS,), device=x.device, dtype=th.long) for n in FPS_RANGES])
+                    starts_d = pinned
+                else:
+                    starts_d = th.stack([th.randint(0, n, (k, B * NUM_SLOTS), device=x.device, dtype=th.long) for n in FPS_RANGES], dim=1)
+                noises_d = th.randn(k, *x.shape, device=x.device, dtype=th.float32)
+                if const_noise:
+                    noises_d = noises_d[:, :1].expand(-1, B, -1, -1).contiguous()
             else:
                 starts, noises = [], []
                 for _ in range(k):

@@ -9,9 +9,10 @@ Same constructor signature, ``forward`` signature, side-effect attributes (``sav
 with host tensors raises.
 
 Extensions (keyword-only, defaults preserve reference behaviour):
-  * ``y`` may be a ``(B, 512)`` tensor of precomputed CLIP text features -- the boundary of this
-    path (the reference re-runs ``clip_model.encode_text`` every step, model/sdm.py:147); a list of
-    strings is encoded through ``self.text_encoder`` (the ``clip`` package when importable).
+  * ``y`` may be a ``(B, clip_dim)`` tensor of precomputed text features -- the boundary of this
+    path (the reference re-runs its text encoder every step, model/sdm.py:146-149); a list of strings is encoded
+    through ``self.text_encoder`` (by ``text_encoder_type``: the ``clip`` package, or ``transformers``' BERT pooler
+    output with ``clip_dim=768``, when importable).
   * ``precision=`` ("f32" | "bf16x3" | "bf16", also ``model.set_precision``; default from ``LSDM_PRECISION`` or
     "f32") selects the arithmetic of the dense 1x1-conv / Linear stacks: exact fp32 MFMA, fp32 operands split into
     bf16 hi+lo with 3 bf16 MFMAs per product (fp32-class results, same <= 1e-3 parity bar), or plain bf16 products.
@@ -60,10 +61,12 @@ class SceneDiffusionModel(nn.Module):
         if pcd_backbone_type != "PNT2" or human_backbone_type != "POSA":
             raise NotImplementedError("only the default PNT2 / POSA backbones are on the accelerated path "
                                       "(DGCNN / P2R are ablation options of the reference, SURVEY.md §2)")
-        if (clip_dim, latent_dim, cat_emb, pcd_points, xyz_dim, translation_params, n_head) != (512, 128, 32, 1024, 3, 12, 8) \
-                or pcd_dim != 3:
+        if (latent_dim, cat_emb, pcd_points, xyz_dim, translation_params, n_head) != (128, 32, 1024, 3, 12, 8) or pcd_dim != 3 \
+                or clip_dim % 2 or not 2 <= clip_dim <= 1024:
             raise NotImplementedError("kernels are specialised for the proxd/humanise defaults of util/model_util.py:26-72 "
-                                      "(clip_dim=512, latent_dim=128, pcd_dim=3, n_head=8)")
+                                      "(latent_dim=128, pcd_dim=3, n_head=8; clip_dim even and <= 1024: 512 for CLIP, 768 for BERT)")
+        if text_encoder_type not in ("CLIP", "BERT"):
+            raise ValueError("text_encoder_type must be 'CLIP' or 'BERT' (model/sdm.py:146-149)")
         self.seg_len, self.modality, self.clip_version, self.clip_dim = seg_len, modality, clip_version, clip_dim
         self.latent_dim, self.pcd_dim, self.pcd_points, self.xyz_dim = latent_dim, pcd_dim, pcd_points, xyz_dim
         self.max_cats, self.n_head, self.translation_params = max_cats, n_head, translation_params
@@ -74,7 +77,7 @@ class SceneDiffusionModel(nn.Module):
         self.saved_guiding_points = None
         self.text_encoder = None  # callable(list[str]) -> (B,512) tensor
         gen = torch.Generator().manual_seed(0)
-        for name, (shape, kind) in state_dict_spec(max_cats=max_cats).items():
+        for name, (shape, kind) in state_dict_spec(max_cats=max_cats, clip_dim=clip_dim).items():
             if kind == "pe":
                 from ..synthetic import sinusoid_table
                 t = sinusoid_table(shape[0], shape[2])
@@ -158,12 +161,13 @@ class SceneDiffusionModel(nn.Module):
         if isinstance(y, torch.Tensor):
             feats = y
         else:
-            if self.text_encoder is None:
-                self.text_encoder = _default_clip_encoder(self.clip_version, device)
+            if self.text_encoder is None:       # model/sdm.py:146-149: the encoder is chosen by text_encoder_type
+                self.text_encoder = (_default_clip_encoder(self.clip_version, device) if self.text_encoder_type == "CLIP"
+                                     else _default_bert_encoder(device))
             feats = self.text_encoder(list(y))
         feats = feats.to(device=device, dtype=torch.float32).contiguous()
         if feats.shape != (batch, self.clip_dim):
-            raise ValueError("text features must be (B, %d), got %s" % (self.clip_dim, tuple(feats.shape)))
+            raise ValueError("text features must be (B, %d) = (B, clip_dim), got %s" % (self.clip_dim, tuple(feats.shape)))
         return feats
 
     # ------------------------------------------------------------------ the hot path
@@ -185,7 +189,7 @@ class SceneDiffusionModel(nn.Module):
             if lo[l] < 0 or hi[l] >= n:
                 raise ValueError("fps_starts of level %d must lie in [0, %d), got [%d, %d]" % (l + 1, n, lo[l], hi[l]))
 
-    def _run(self, mode, eta, x, mask, timesteps, given_objs, given_cats, y, fps_starts=None, noise_fn=None):
+    def _run(self, mode, eta, x, mask, timesteps, given_objs, given_cats, y, fps_starts=None, noise_fn=None, trusted_starts=False):
         self._check_device(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError("x must be a contiguous float32 tensor (it is updated in place)")
@@ -216,7 +220,7 @@ class SceneDiffusionModel(nn.Module):
         if fps_starts is None:
             # reference draw order and generator: CPU global RNG, sa1..sa4
             fps_starts = [torch.randint(0, n, (B * O,), dtype=torch.long) for n in FPS_RANGES]
-        else:
+        elif not trusted_starts:      # (device-generated starts are in range by construction; checking them would read them back)
             self._check_starts(torch.stack([s.reshape(-1) for s in fps_starts]).long(), B * O)
         starts = torch.stack([s.reshape(-1) for s in fps_starts]).to(device=dev, dtype=torch.long).contiguous()
         noise = noise_fn() if noise_fn is not None else None
@@ -281,5 +285,28 @@ def _default_clip_encoder(clip_version, device):
         tok = torch.cat([tok, torch.zeros(tok.shape[0], 77 - 22, dtype=tok.dtype, device=tok.device)], dim=1)
         with torch.no_grad():
             return clip_model.encode_text(tok).float()
+
+    return encode
+
+
+def _default_bert_encoder(device):
+    """The reference's other text tower (model/sdm.py:261-264, 279-285): ``bert-base-uncased`` tokenizer with padding, the model's
+    ``pooler_output`` (B,768) -- so the model must be built with ``clip_dim=768``.  Third party (``transformers`` + downloaded weights):
+    parity unpinned, like CLIP; everything downstream of the (B,768) feature is pinned (golden G13)."""
+    try:
+        from transformers import BertModel, BertTokenizer
+        tokenizer = BertTokenizer.from_pretrained("bert-base-uncased")
+        bert = BertModel.from_pretrained("bert-base-uncased").to(device)
+    except Exception as e:      # no package, or no weights reachable offline
+        raise RuntimeError("the BERT text encoder is not available (%s): pass precomputed (B,768) text features as `y` or set "
+                           "model.text_encoder" % type(e).__name__) from e
+    bert.eval()
+    for p in bert.parameters():
+        p.requires_grad = False
+
+    def encode(texts):
+        enc = tokenizer(list(texts), padding=True, return_tensors='pt').to(device)
+        with torch.no_grad():
+            return bert(**enc).pooler_output.float()
 
     return encode

@@ -83,8 +83,8 @@ def make_synthetic_state_dict(seed=0, gain=DEFAULT_GAIN, max_cats=13, **spec_kwa
 
 
 def make_synthetic_batch(batch, seed=1, max_cats=13, num_slots=9, num_points=1024, all_ones_mask=False,
-                         num_objects=None):
-    """Returns dict(mask (B,O), given_objs (B,O,N,3), given_cats (B,O,C), text_features (B,512)), fp32.
+                         num_objects=None, text_dim=512):
+    """Returns dict(mask (B,O), given_objs (B,O,N,3), given_cats (B,O,C), text_features (B,text_dim)), fp32.
 
     ``num_objects``: fixed k for every sample (e.g. 8 = BASELINE config 3's "8192-pt scene cloud");
     default k ~ U{1..8} per sample."""
@@ -105,7 +105,7 @@ def make_synthetic_batch(batch, seed=1, max_cats=13, num_slots=9, num_points=102
             cats[b, o, int(rng.integers(1, C))] = 1.0
     if all_ones_mask:
         mask[:] = 1.0
-    text = rng.normal(0.0, 1.0, size=(B, 512)).astype(np.float32)
+    text = rng.normal(0.0, 1.0, size=(B, text_dim)).astype(np.float32)
     return {
         "mask": torch.from_numpy(mask),
         "given_objs": torch.from_numpy(objs),

@@ -74,8 +74,8 @@ class TrainSession:
         x_start, qa, qb, noise, mask, given_objs, given_cats, text = (f32(v) for v in (x_start, qa, qb, noise, mask, given_objs, given_cats, text))
         t, target, starts = i64(t), i64(target), i64(fps_starts)
         if x_start.shape != (B, 1024, 3) or given_objs.shape != (B, NUM_SLOTS, 1024, 3) or given_cats.shape != (B, NUM_SLOTS, self.model.max_cats) \
-                or mask.shape != (B, NUM_SLOTS) or text.shape != (B, 512) or starts.shape != (4, B * NUM_SLOTS) or t.shape != (B,) or target.shape != (B,):
-            raise ValueError("training batch: expected x_start (B,1024,3), given_objs (B,9,1024,3), given_cats (B,9,C), mask (B,9), text (B,512)")
+                or mask.shape != (B, NUM_SLOTS) or text.shape != (B, self.model.clip_dim) or starts.shape != (4, B * NUM_SLOTS) or t.shape != (B,) or target.shape != (B,):
+            raise ValueError("training batch: expected x_start (B,1024,3), given_objs (B,9,1024,3), given_cats (B,9,C), mask (B,9), text (B,clip_dim)")
         keep = None
         if dropout_keep is not None:
             keep = dropout_keep.to(device=dev, dtype=torch.uint8).contiguous()

@@ -24,6 +24,10 @@ Golden sets:
       every parameter's gradient (small tensors in full; large ones as norm / sum / a strided sample), the BatchNorm running
       statistics after the forward.  pytorch3d's chamfer_distance is absent: its published definition (oracle/train_ref.py) is
       patched in -- the chamfer term's parity is unpinned.
+  G13 the other text tower's width: the reference built with clip_dim = 768 (the BERT pooler_output width, model/sdm.py:261-264, with
+      embed_text 768 -> 384 -> 256 -> 128): one forward at B = 2 with injected (B,768) features -- outputs, saved_cat, guiding points,
+      the embedding tap.  (The encoder itself -- transformers' bert-base-uncased -- is third party and not reachable offline: the
+      boundary is its (B,768) feature, like CLIP's (B,512).)
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
 import argparse
@@ -467,6 +471,29 @@ def g12():
                     out["train_running/" + k] = v.detach().clone()
         print(mode, {k: float(terms[k]) for k in ("loss", "mse", "cat_loss")}, "params with grad:", len(names), "without:", none)
     save("g12_training", **out)
+
+
+def g13():
+    B, C, D = 2, 13, 768
+    kw = mu.get_default_model_proxd()
+    kw["max_cats"], kw["clip_dim"] = C, D
+    m = SDM(**kw, use_cuda=False).eval()          # text_encoder_type stays "CLIP": the stub returns whatever width is injected
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C, clip_dim=D))
+    bt = make_synthetic_batch(B, seed=131, max_cats=C, text_dim=D)
+    clip._model.features = bt["text_features"]
+    torch.manual_seed(132)
+    x = torch.randn(B, 1024, 3)
+    t = torch.tensor([11, 777])
+    state = torch.get_rng_state()
+    starts = torch.stack([torch.randint(0, n, (B * 9,), dtype=torch.long) for n in (1024, 1024, 256, 64)])
+    torch.set_rng_state(state)
+    taps = {}
+    hook = m.embed_text.register_forward_hook(lambda mod, i, o: taps.__setitem__("enc", o.detach().clone()))
+    x_in = x.clone()
+    out_cat, out = m(x, bt["mask"], t, bt["given_objs"], bt["given_cats"], ["p"] * B)
+    hook.remove()
+    save("g13_forward_clipdim768", x_in=x_in, t=t, starts=starts, out_cat=out_cat, out=out, guiding=m.saved_guiding_points, x_mutated=x,
+         enc=taps["enc"], meta=np.array([B, C, D, 131, 132]))
 
 
 def long_chain(steps):

@@ -483,6 +483,74 @@ def test_plain_bf16_multi_step_group_equals_single_steps():
         assert torch.equal(_chain(m, diff, bt, B, K, 8, hoist_invariants=inv)[0], loop)
 
 
+# ======================================================================================= clip_dim = 768 (BERT pooler width)
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_forward_with_768_wide_text_features_vs_reference_golden(golden, precision):
+    """text_encoder_type="BERT" feeds embed_text with pooler_output (B,768) (model/sdm.py:146-149, 261-264): clip_dim = 768, embed_text
+    768 -> 384 -> 256 -> 128.  The library reads the width off embed_text.0.weight; golden G13 is the reference built that way."""
+    g = golden("g13_forward_clipdim768")
+    B, C, D, bt_seed, _ = [int(v) for v in g["meta"]]
+    m, _ = create_model_and_diffusion("proxd", precision=precision, clip_dim=D, text_encoder_type="BERT")
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C, clip_dim=D))
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=bt_seed, max_cats=C, text_dim=D).items()}
+    x = T(g["x_in"]).to(DEV).clone()
+    out_cat, out = m(x, bt["mask"], T(g["t"]).long().to(DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"],
+                     fps_starts=[s.long() for s in T(g["starts"])])
+    tol = 1e-4 if precision == "f32" else 1e-3
+    assert maxabs(out_cat, g["out_cat"]) <= 1e-5 and maxabs(out, g["out"]) <= tol
+    assert maxabs(m.saved_guiding_points, g["guiding"]) <= tol and maxabs(x, g["x_mutated"]) <= tol
+    with pytest.raises(ValueError, match="clip_dim"):
+        m(x, bt["mask"], T(g["t"]).long().to(DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"][:, :512].contiguous())
+
+
+# ======================================================================================= device-RNG throughput mode
+def test_device_rng_mode_is_deterministic_in_range_and_distribution():
+    """host_rng=False ("device Philox for throughput mode"): x_T, the per-step FPS starts and the per-step noise
+    all come from the device generator -- nothing is drawn or uploaded by the host inside the loop.  Checked: same seed -> the same
+    sample bit for bit (bulk loop, strict and hoisted schedules), another seed -> another sample; the draws the loop hands to the
+    library are in range per level and have the moments of their distributions; the per-step progressive loop consumes the device
+    generator too (no host generator state is touched)."""
+    B, K = 4, 6
+    m, _ = _fresh("bf16x3")
+    diff = create_gaussian_diffusion(get_default_diffusion(), host_rng=False)
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=21).items()}
+    args = (m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"])
+    seen = []
+    orig = m._run_steps
+
+    def spy(mode, eta, x, mask, t_first, k, given_objs, given_cats, text, starts, noise, **kw):
+        seen.append((starts.clone(), noise.clone()))
+        return orig(mode, eta, x, mask, t_first, k, given_objs, given_cats, text, starts, noise, **kw)
+    m._run_steps = spy
+    host_state = torch.get_rng_state()
+    outs = {}
+    for kw_name, kw in (("invariant", {}), ("strict", {"hoist_invariants": False}), ("hoisted", {"hoist_conditioning": True})):
+        res = []
+        for seed in (7, 7, 8):
+            torch.manual_seed(seed)
+            host_after_seed = torch.get_rng_state()
+            res.append(diff.p_sample_loop(*args, clip_denoised=False, skip_timesteps=1000 - K, chunk_steps=4, **kw).clone())
+            assert torch.equal(torch.get_rng_state(), host_after_seed)          # the host generator was not consumed
+        assert torch.equal(res[0], res[1]) and not torch.equal(res[0], res[2]) and bool(torch.isfinite(res[0]).all()), kw_name
+        outs[kw_name] = res[0]
+    assert torch.equal(outs["invariant"], outs["strict"])                       # same draws, bit-identical schedules
+    m._run_steps = orig
+    torch.set_rng_state(host_state)
+    starts = torch.cat([s for s, _ in seen if s.dim() == 3]).cpu()               # (steps, 4, B*9)
+    noise = torch.cat([n for _, n in seen]).cpu()
+    assert starts.is_cuda is False and all(s.is_cuda and n.is_cuda for s, n in seen)
+    for l, n in enumerate((1024, 1024, 256, 64)):
+        v = starts[:, l].reshape(-1).float()
+        assert int(v.min()) >= 0 and int(v.max()) < n
+        assert abs(float(v.mean()) - (n - 1) / 2) <= 4 * n / (12 * v.numel()) ** 0.5 + 1       # uniform: mean within 4 sigma
+    assert abs(float(noise.mean())) <= 5 / noise.numel() ** 0.5 and abs(float(noise.var()) - 1) <= 0.01
+    # per-step path (progressive loop): device draws as well
+    torch.manual_seed(7)
+    host_after_seed = torch.get_rng_state()
+    last = [o["sample"] for o in diff.p_sample_loop_progressive(*args, clip_denoised=False, skip_timesteps=1000 - 2)][-1]
+    assert torch.equal(torch.get_rng_state(), host_after_seed) and bool(torch.isfinite(last).all())
+
+
 def test_input_validation_is_loud():
     m, diff = _fresh()
     bt = {k: v.to(DEV) for k, v in make_synthetic_batch(2, seed=3).items()}

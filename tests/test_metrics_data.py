@@ -137,6 +137,50 @@ def test_default_clip_encoder_with_stub_clip_module(monkeypatch):
         m._encode_text(["x"], 2, torch.device("cpu"))
 
 
+def test_bert_text_encoder_hook_with_stub_transformers(monkeypatch):
+    """model/sdm.py:146-149, 261-264, 279-285: text_encoder_type="BERT" -> tokenizer(list, padding=True, return_tensors='pt'), the model's
+    pooler_output (B,768); the model must be built with clip_dim=768.  The stub records what the hook hands to the third-party package."""
+    seen = {}
+    tr = types.ModuleType("transformers")
+
+    class Enc(dict):
+        def to(self, device):
+            seen["to"] = str(device)
+            return self
+
+    class Tok:
+        @staticmethod
+        def from_pretrained(name):
+            seen["tok"] = name
+            return Tok()
+
+        def __call__(self, texts, padding=False, return_tensors=None):
+            seen["call"] = (list(texts), padding, return_tensors)
+            return Enc(input_ids=torch.ones(len(texts), 5, dtype=torch.long))
+
+    class Bert(torch.nn.Module):
+        @staticmethod
+        def from_pretrained(name):
+            seen["bert"] = name
+            return Bert()
+
+        def forward(self, input_ids=None):
+            return types.SimpleNamespace(pooler_output=torch.arange(input_ids.shape[0] * 768, dtype=torch.float64).view(-1, 768))
+
+    tr.BertTokenizer, tr.BertModel = Tok, Bert
+    monkeypatch.setitem(sys.modules, "transformers", tr)
+    from lsdm_amd.model.sdm import SceneDiffusionModel
+    m = SceneDiffusionModel(clip_dim=768, pcd_dim=3, use_cuda=False, text_encoder_type="BERT")
+    assert dict(m.named_parameters())["embed_text.0.weight"].shape == (384, 768)
+    feats = m._encode_text(["a chair", "a table"], 2, torch.device("cpu"))
+    assert feats.shape == (2, 768) and feats.dtype == torch.float32
+    assert seen["tok"] == seen["bert"] == "bert-base-uncased" and seen["call"] == (["a chair", "a table"], True, "pt") and seen["to"] == "cpu"
+    with pytest.raises(ValueError, match="text_encoder_type"):
+        SceneDiffusionModel(clip_dim=512, pcd_dim=3, use_cuda=False, text_encoder_type="T5")
+    with pytest.raises(ValueError, match="clip_dim"):          # a 512-wide model cannot take the 768-wide pooler output
+        SceneDiffusionModel(clip_dim=512, pcd_dim=3, use_cuda=False, text_encoder_type="BERT")._encode_text(["x"], 1, torch.device("cpu"))
+
+
 def test_missing_clip_package_is_reported(monkeypatch):
     monkeypatch.setitem(sys.modules, "clip", None)
     from lsdm_amd.model.sdm import _default_clip_encoder

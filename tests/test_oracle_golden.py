@@ -216,6 +216,21 @@ def test_g9_loop_variants(golden):
     assert maxabs(dump[K - 1], g["dump0"]) <= 5e-5 and maxabs(dump[0], g["dump2"]) <= 5e-5      # on_step is keyed by t
 
 
+# ---------------------------------------------------------------- G13: clip_dim = 768 (the BERT pooler width)
+def test_g13_forward_with_768_wide_text_features(golden):
+    g = golden("g13_forward_clipdim768")
+    B, C, D, bt_seed, _ = [int(v) for v in g["meta"]]
+    sd = make_synthetic_state_dict(seed=0, max_cats=C, clip_dim=D)
+    assert sd["embed_text.0.weight"].shape == (D // 2, D) and sd["embed_text.2.weight"].shape == (256, D // 2)
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C, text_dim=D)
+    x = T(g["x_in"]).clone()
+    taps = {}
+    out_cat, out, guiding = cpu_ref.forward(sd, x, bt["mask"], T(g["t"]).long(), bt["given_objs"], bt["given_cats"], bt["text_features"],
+                                            fps_starts=[s.long() for s in T(g["starts"])], taps=taps)
+    assert maxabs(taps["enc"], g["enc"]) <= 1e-6 and maxabs(out_cat, g["out_cat"]) <= 1e-6
+    assert maxabs(out, g["out"]) <= 1e-5 and maxabs(guiding, g["guiding"]) <= 1e-5 and maxabs(x, g["x_mutated"]) <= 1e-5
+
+
 # ---------------------------------------------------------------- G12: the training objective and its gradients
 def g12_inputs(g):
     """Inputs of G12 regenerated from their seeds + the recorded draws (shared with the GPU training tests)."""
