@@ -376,6 +376,9 @@ __device__ __forceinline__ f32x16 xfake_mfma(const bf16x8& a, const bf16x8& b, f
 // waves drift apart, so one wave's epilogue / gather overlaps another's MFMAs (measured with tools/ubench/chain_bench.hip:
 // sixteen 16 KB panels with a barrier each cost 75 us of 272; the barriers keep all waves of a CU in the same phase and expose
 // the gather latency of every round).  conv2's padded block stays resident.  Weight traffic per point: 1 KB instead of 5 KB.
+// (Round 3: requesting the first half of the NEXT round's gather -- 24 x 16 bytes per lane -- in front of conv2 and the second half
+// next to the first half's interpolation arithmetic was measured slower, 349 vs 290 us: the 96 staging registers do not fit next
+// to the two operand sets at two waves per SIMD and part of them goes through scratch.)
 // blob: four layers [nb][s][plane][lane][8] (layer 1 in channel order, later layers in accumulator order) + conv2 zero-padded
 // to 32 channels; biases [4 x 128 | 32].
 template <int NW, int NP, int PH = 1>
@@ -431,60 +434,6 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
         if (dbg == 2) { ni[0] = ni[1] = ni[2] = (int)(wave * 4); }               // experiment: one row per wave
     };
     if (rbeg < rend) request(rbeg);
-#ifdef LSDM_X_FP1PF
-    // The first half of a round's gather (k-steps 0..3 of the three rows: 24 x 16 bytes per lane) is requested BEFORE the previous
-    // round's conv2 block, the second half at the top of the round next to the first half's interpolation arithmetic, so that
-    // neither L2 latency is waited for with an idle matrix pipe (tools/ubench/chain_bench.hip: 72 of 267 us were exposed gather
-    // latency -- both waves of a SIMD sit in the same phase).
-    f32x4 pa[4][2], pb[4][2], pd[4][2];            // the prefetched half
-    const float *r0 = nullptr, *r1 = nullptr, *r2 = nullptr;
-    float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;
-    auto rows_of = [&](long long rd) {
-        const long long c = (rd * (32 * NW) + wave * 32 + p) / N;
-        r0 = points2 + ((size_t)c * S + ni[0]) * C + 8 * h;
-        r1 = points2 + ((size_t)c * S + ni[1]) * C + 8 * h;
-        r2 = points2 + ((size_t)c * S + ni[2]) * C + 8 * h;
-        w0 = nw[0]; w1 = nw[1]; w2 = nw[2];
-    };
-    auto load_half = [&](int s0, f32x4 (&a)[4][2], f32x4 (&b)[4][2], f32x4 (&d)[4][2]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) a[s][q] = load4f(r0 + 16 * (s0 + s) + 4 * q);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) b[s][q] = load4f(r1 + 16 * (s0 + s) + 4 * q);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) d[s][q] = load4f(r2 + 16 * (s0 + s) + 4 * q);
-    };
-    if (rbeg < rend) { rows_of(rbeg); load_half(0, pa, pb, pd); }
-    for (long long rd = rbeg; rd < rend; ++rd) {
-        bf16x8 yh[KS], yl[KS], zh[KS], zl[KS];
-        {
-            f32x4 a[4][2], b[4][2], d[4][2];
-            load_half(4, a, b, d);                           // second half: in flight during the first half's arithmetic
-            const float v0 = w0, v1 = w1, v2 = w2;
-            if (rd + 1 < rend) request(rd + 1);              // (r0 .. r2 / w0 .. w2 of THIS round are in registers by now)
-            __builtin_amdgcn_sched_barrier(0);
-            auto interp = [&](int s0, f32x4 (&ga)[4][2], f32x4 (&gb)[4][2], f32x4 (&gd)[4][2]) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float v[8];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            v[4 * q + j] = __fadd_rn(__fadd_rn(__fmul_rn(ga[s][q][j], v0), __fmul_rn(gb[s][q][j], v1)), __fmul_rn(gd[s][q][j], v2));
-                    split8<NP>(v, yh[s0 + s], yl[s0 + s]);
-                }
-            };
-            interp(0, pa, pb, pd);
-            interp(4, a, b, d);
-        }
-#else
     for (long long rd = rbeg; rd < rend; ++rd) {
         const long long pt = rd * (32 * NW) + wave * 32 + p;    // this lane's point (both halves of the wave: same point)
         const long long c = pt / N;
@@ -523,7 +472,6 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
                 split8<NP>(v, yh[s0 + s], yl[s0 + s]);
             }
         }
-#endif
         // one channel block of a layer: accumulators start from the bias, MFMAs against the resident panel, ReLU + split into the
         // next layer's two k-step fragments
 #define FP_BLOCK(L, NBI, XH, XL, OH, OL)   /* channel block NBI of layer L, read from the panel that holds it */                                                                                     \
@@ -576,10 +524,6 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
 #undef FP_LAYER
 #undef FP_PANEL
 #undef FP_BLOCK
-#ifdef LSDM_X_FP1PF
-        if (rd + 1 < rend) { rows_of(rd + 1); load_half(0, pa, pb, pd); }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         // ---- conv2 (128 -> 3, rows zero-padded to one 32-channel block), direct orientation D[point][channel] -------------------
         {
             int lz = 0;

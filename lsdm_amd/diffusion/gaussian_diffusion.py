@@ -240,6 +240,10 @@ class GaussianDiffusion:
             stage = [dict(noise=th.empty(kmax, *x.shape, dtype=th.float32).pin_memory(),
                           starts=th.empty(kmax, len(FPS_RANGES), B * NUM_SLOTS, dtype=th.long).pin_memory(), ev=None) for _ in range(2)]
         chunk_i = 0
+        if hoist_conditioning and not self.host_rng and x.is_cuda:
+            # the hoisted entry point evaluates the scene conditioning once per CALL; with nothing to draw or upload on the host the whole
+            # chain is one call (the noise of 1000 steps at B = 64 is 0.8 GB of the 288 GB)
+            chunk_steps = total
         while done < total:
             k = min(int(chunk_steps), total - done)
             if stage is not None:

@@ -497,8 +497,8 @@ def test_forward_with_768_wide_text_features_vs_reference_golden(golden, precisi
     out_cat, out = m(x, bt["mask"], T(g["t"]).long().to(DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"],
                      fps_starts=[s.long() for s in T(g["starts"])])
     tol = 1e-4 if precision == "f32" else 1e-3
-    assert maxabs(out_cat, g["out_cat"]) <= 1e-5 and maxabs(out, g["out"]) <= tol
-    assert maxabs(m.saved_guiding_points, g["guiding"]) <= tol and maxabs(x, g["x_mutated"]) <= tol
+    assert maxabs(out_cat, T(g["out_cat"])) <= 1e-5 and maxabs(out, T(g["out"])) <= tol
+    assert maxabs(m.saved_guiding_points, T(g["guiding"])) <= tol and maxabs(x, T(g["x_mutated"])) <= tol
     with pytest.raises(ValueError, match="clip_dim"):
         m(x, bt["mask"], T(g["t"]).long().to(DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"][:, :512].contiguous())
 
