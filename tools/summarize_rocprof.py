@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.replace("lsdm::", "")
+    name = name.replace("lsdm::", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:90]
 
 
