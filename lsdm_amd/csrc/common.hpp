@@ -83,6 +83,27 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = b & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
+// Round schedule of a PERSISTENT kernel (grid = a multiple of 8 work-groups, `rounds` units of work).  With one contiguous chunk of
+// rounds per work-group, the work-groups of an XCD sit in 32 .. 64 different clouds at any time and the rows they gather (0.25 .. 0.5 MB
+// per cloud) evict each other from the XCD's 4 MiB L2 (round 2 PMC: fp1 fetched 2.4x, sa2 2.2x its unique input from HBM).  Here the
+// work-groups of one XCD walk ONE contiguous range of rounds together -- round i of work-group j of XCD x is x * rpx + i * wpx + j --
+// so that at any time an XCD gathers from a handful of clouds.  Results do not depend on the schedule.
+struct XcdRounds {
+    int first, stride, end;
+};
+__device__ __forceinline__ XcdRounds xcd_rounds(int rounds) {
+    const int G = (int)gridDim.x, v = xcd_remap((int)blockIdx.x, G);
+    XcdRounds r;
+    if (G & 7) {                     // not XCD-divisible: one contiguous chunk per work-group
+        const int chunk = (rounds + G - 1) / G;
+        r.first = v * chunk; r.stride = 1; r.end = r.first + chunk < rounds ? r.first + chunk : rounds;
+        return r;
+    }
+    const int wpx = G >> 3, x = v / wpx, j = v - x * wpx, rpx = (rounds + 7) >> 3;
+    r.first = x * rpx + j; r.stride = wpx; r.end = (x + 1) * rpx < rounds ? (x + 1) * rpx : rounds;
+    return r;
+}
+
 // 1-D grid of tiles_per_cloud * num_clouds work-groups -> (cloud, tile)
 __device__ __forceinline__ void xcd_cloud_tile(int tiles_per_cloud, int& cloud, int& tile) {
     const int v = xcd_remap((int)blockIdx.x, (int)gridDim.x);

@@ -420,9 +420,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
     __syncthreads();
 
     const long long rounds = total_points / (32 * NW);
-    const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
-    const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
-    const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    const XcdRounds sched = xcd_rounds((int)rounds);       // the work-groups of an XCD walk the rounds together (common.hpp)
+    const long long rbeg = sched.first, rend = sched.end, rstep = sched.stride;
     // neighbour indices / weights of a round are requested during the previous one
     int ni[3] = {0, 0, 0};
     float nw[3] = {0.0f, 0.0f, 0.0f};
@@ -434,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
         if (dbg == 2) { ni[0] = ni[1] = ni[2] = (int)(wave * 4); }               // experiment: one row per wave
     };
     if (rbeg < rend) request(rbeg);
-    for (long long rd = rbeg; rd < rend; ++rd) {
+    for (long long rd = rbeg; rd < rend; rd += rstep) {
         const long long pt = rd * (32 * NW) + wave * 32 + p;    // this lane's point (both halves of the wave: same point)
         const long long c = pt / N;
         const float* r0 = points2 + ((size_t)c * S + ni[0]) * C + 8 * h;
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) d[s][q] = load4f(r2 + 16 * (s0 + s) + 4 * q);
-            if (s0 + 4 >= KS && rd + 1 < rend) request(rd + 1);
+            if (s0 + 4 >= KS && rd + rstep < rend) request(rd + rstep);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float v[8];

@@ -217,13 +217,16 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
 
     const int total = (int)total_centroids;
     const int rounds = (total + NW - 1) / NW;
+    // (one contiguous chunk of rounds per work-group; the XCD-cooperative schedule of sa2 / fp1 was measured without effect here and
+    // in sa_w: their HBM fetch already equals the unique input)
     const int rchunk = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
     const int rbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
     const int rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    constexpr int rstep = 1;
     auto cent_of = [&](int rd) { const int ce = rd * NW + wave; return ce < total ? ce : total - 1; };
     int idx_n = 0, ci_n = 0;
     if (rbeg < rend) { const int ce = cent_of(rbeg); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
-    for (int rd = rbeg; rd < rend; ++rd) {
+    for (int rd = rbeg; rd < rend; rd += rstep) {
         const int cent = cent_of(rd);        // (a wave past the end repeats the last centroid: same values, same addresses)
         const int c = cent / S;
         const float* urow = U + ((size_t)c * NSRC + idx_n) * C1 + 8 * h;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
                 u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
-            if (rd + 1 < rend) { const int ce = cent_of(rd + 1); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
+            if (rd + rstep < rend) { const int ce = cent_of(rd + rstep); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
@@ -371,9 +374,9 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     // 32-bit index arithmetic (a 64-bit division per centroid costs ~60 instructions); the neighbour / centroid indices of a
     // centroid -- two dependent loads when they go through `remap` -- are requested one iteration ahead
     const int total = (int)total_centroids;
-    const int chunk = ((total + (int)gridDim.x - 1) / (int)gridDim.x + NW - 1) / NW * NW;
-    const int cbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk;
-    const int cend = cbeg + chunk < total ? cbeg + chunk : total;
+    const XcdRounds sched = xcd_rounds((total + NW - 1) / NW);       // a round = NW centroids, one per wave (common.hpp)
+    const int cbeg = sched.first * NW, cstep = sched.stride * NW;
+    const int cend = sched.end * NW < total ? sched.end * NW : total;
     int idx_n = 0, ci_n = 0;
     auto request = [&](int ce) {
         const int cc = ce / S;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
         if (remap) { idx_n = remap[(size_t)cc * NSRC + idx_n]; ci_n = remap[(size_t)cc * NSRC + ci_n]; }
     };
     if (cbeg + wave < cend) request(cbeg + wave);
-    for (int cent = cbeg + wave; cent < cend; cent += NW) {
+    for (int cent = cbeg + wave; cent < cend; cent += cstep) {
         const int c = cent / S;
         const int idx = idx_n, ci = ci_n;
         const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                 u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
-            if (cent + NW < cend) request(cent + NW);
+            if (cent + cstep < cend) request(cent + cstep);
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
@@ -500,6 +503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
     const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
     const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    constexpr long long rstep = 1;
     // The neighbour / centroid indices of a round are requested one round ahead and its 32 U rows (the gather: 128 registers per
     // lane) at the start of the previous round's layer 3, when x is dead -- with one wave per SIMD nothing else would hide that latency.
     int idx_n = 0, ci_n = 0, ci_c = 0;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ci_n = cent_idx[ce];
         request_u(ce / S);
     }
-    for (long long rd = rbeg; rd < rend; ++rd) {
+    for (long long rd = rbeg; rd < rend; rd += rstep) {
         const long long cent = rd * NW + wave;
         const long long c = cent / S;
         bf16x8 xh[KS], xl[KS], zh[KS], zl[KS];
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     split8u<NP>(t, xh[s0 + s], xl[s0 + s]);
                 }
             }
-            if (rd + 1 < rend) { const long long ce = (rd + 1) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
+            if (rd + rstep < rend) { const long long ce = (rd + rstep) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
         }
 #define SAW_BEGIN(Q) { if (!(dbg & 1)) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
 #define SAW_END(Q) lds_dma_wait(); if (!(dbg & 2)) __syncthreads(); }
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             SAW_END(q)
         }
         // ---- layer 3 (direct orientation): max over the 32 rows
-        if (rd + 1 < rend) request_u(((rd + 1) * NW + wave) / S);
+        if (rd + rstep < rend) request_u(((rd + rstep) * NW + wave) / S);
 #pragma unroll
         for (int q = 0; q < NB3 / PB; ++q) {
             SAW_BEGIN(NB2 / PB + q)
