@@ -483,6 +483,45 @@ def test_plain_bf16_multi_step_group_equals_single_steps():
         assert torch.equal(_chain(m, diff, bt, B, K, 8, hoist_invariants=inv)[0], loop)
 
 
+# ======================================================================================= retained A/B switches of the library
+_SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "2"}, {"LSDM_SA_REG": "0"}, {"LSDM_SA_REG": "2", "LSDM_SA_SPLIT": "0"},
+             {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
+             {"LSDM_GROUP": "3"}]
+
+
+@pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
+    """The LSDM_* switches the shipped library still reads select between IMPLEMENTATIONS of a stage (the fall-back kernels an
+    optimisation replaced); each setting must hold the same bar as the default: one forward against the reference's golden G2 in
+    bf16x3, and a 5-step chain within 1e-3 of the default build's (the switches are read when a context is created)."""
+    g = golden("g2_forward_c13")
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(3, seed=5).items()}
+    starts = [s.long() for s in T(g["starts"])]
+    bt4 = {k: v.to(DEV) for k, v in make_synthetic_batch(4, seed=33).items()}
+
+    def run():
+        m, diff = _fresh("bf16x3")
+        x = T(g["x_in"]).clone().to(DEV)
+        out_cat, out = m(x, bt["mask"], T(g["t"]).long().to(DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=starts)
+        chain = _chain(m, diff, bt4, 4, 5, 17)
+        return out_cat.clone(), out.clone(), x, m.saved_guiding_points.clone(), chain
+    base = run()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        got = run()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    assert maxabs(got[0], T(g["out_cat"])) <= 1e-5 and maxabs(got[1], T(g["out"])) <= 1e-3
+    assert maxabs(got[2], T(g["x_mut"])) <= 1e-3 and maxabs(got[3], T(g["guiding"])) <= 1e-3
+    for a, b in zip(got[4], base[4]):
+        assert maxabs(a, b) <= 1e-3
+
+
 # ======================================================================================= clip_dim = 768 (BERT pooler width)
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_forward_with_768_wide_text_features_vs_reference_golden(golden, precision):
