@@ -503,8 +503,8 @@ def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
         m, diff = _fresh("bf16x3")
         x = T(g["x_in"]).clone().to(DEV)
         out_cat, out = m(x, bt["mask"], T(g["t"]).long().to(DEV), bt["given_objs"], bt["given_cats"], y=bt["text_features"], fps_starts=starts)
-        chain = _chain(m, diff, bt4, 4, 5, 17)
-        return out_cat.clone(), out.clone(), x, m.saved_guiding_points.clone(), chain
+        fwd = (out_cat.clone(), out.clone(), x, m.saved_guiding_points.clone())
+        return fwd + (_chain(m, diff, bt4, 4, 5, 17),)
     base = run()
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

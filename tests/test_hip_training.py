@@ -224,3 +224,36 @@ def test_train_cli_steps_the_optimizer_and_the_loss_goes_down(tmp_path, capsys):
     assert len(moved) > 150
     model, diffusion = create_model_and_diffusion("proxd", device=0)
     model.load_state_dict(ck["model_state_dict"])
+
+
+def test_train_cli_forward_only_reports_the_eval_objective(tmp_path, capsys):
+    """--forward_only: model.eval(), no optimizer, no graph -- the per-batch objective and the validation report; parameters unchanged."""
+    import run.train_sdm as cli
+    torch.manual_seed(6)
+    np.random.seed(6)
+    rc = cli.main(["--train_data_dir", str(tmp_path / "tr"), "--valid_data_dir", str(tmp_path / "va"), "--synthetic", "4", "--epochs", "1",
+                   "--batch_size", "2", "--forward_only", "--valid_skip_timesteps", "998", "--device", "cuda:0"])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert out.count("====> Total_train_loss") == 1 and "====>Recon_loss_semantics" in out
+    assert not (tmp_path / "training").exists()
+
+
+def test_training_step_at_the_reference_batch_size_and_beyond():
+    """B = 6 (run/train_sdm.py:247) and B = 24 (1.77 M grouped rows in sa1: row tiles beyond the 65 535 limit of a grid's y dimension):
+    finite losses and gradients, every live parameter receives one."""
+    for B in (6, 24):
+        model, diffusion = _model(train=True)
+        bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=50 + B, num_objects=8).items()}
+        target_cat = torch.zeros(B, 13, device=DEV)
+        target_cat[:, 2] = 1
+        torch.manual_seed(B)
+        terms = diffusion.training_losses(model, bt["given_objs"][:, 1].clone(), bt["mask"], torch.randint(0, 1000, (B,), device=DEV), bt["given_objs"],
+                                          bt["given_cats"], target_cat, y=bt["text_features"])
+        terms["loss"].backward()
+        assert bool(torch.isfinite(terms["loss"])) and float(terms["mse"]) > 0
+        missing = [n for n, p in model.named_parameters() if p.grad is None and not n.startswith("attn_layer.v_proj") and not n.startswith("attn_layer.out_proj")]
+        assert not missing, missing
+        assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+        assert float(dict(model.named_parameters())["pcd_backbone.sa1.mlp_convs.0.weight"].grad.abs().max()) > 0
+        del model._train_session
