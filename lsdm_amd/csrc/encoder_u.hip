@@ -877,6 +877,8 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
         hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg);
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;
+        // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
+        // issue-bound -- MFMA and VALU time add -- not latency-bound)
         hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
