@@ -13,7 +13,8 @@ with every activation kept, then the reverse sweep -- hand-written HIP kernels, 
 ``model.training`` selects the reference's ``model.train()`` behaviour on this path: batch-statistics BatchNorm in PointNet++ (running
 statistics updated in place, ``num_batches_tracked`` incremented) and the Dropout(0.5) of the encoder head; ``model.eval()`` uses the
 running statistics and no dropout.  RNG (host generator, reference order on CPU): ``randn_like(x_start)`` when ``noise`` is None, the
-four FPS start draws (pointnet2_utils.py:72), then the dropout mask (``empty_like(h).bernoulli_(0.5)``, what ``F.dropout`` draws).
+four FPS start draws (pointnet2_utils.py:72), then the dropout mask (``empty_like(h).bernoulli_(0.5)``, what ``F.dropout`` draws);
+with ``create_gaussian_diffusion(..., host_rng=False)`` all three come from the device generator (throughput mode).
 
 Only ``terms["loss"]`` carries the graph (the library differentiates mse + cat_loss as one scalar); ``mse`` / ``cat_loss`` are values.
 """
@@ -145,13 +146,19 @@ def training_losses(diffusion, model, x_start, mask, t, given_objs, given_cats, 
     qa = torch.from_numpy(diffusion.sqrt_alphas_cumprod)[t_host].float()                 # _extract_into_tensor: gather in f64, cast
     qb = torch.from_numpy(diffusion.sqrt_one_minus_alphas_cumprod)[t_host].float()
     text = model._encode_text(y, B, dev)
+    # draws: host generator in the reference's CPU order (parity), or -- diffusion.host_rng False -- the device generator (the 7 M-element
+    # dropout mask of a B = 6 batch costs ~25 ms on the host and nothing on the device)
+    on_device = not getattr(diffusion, "host_rng", True)
     if fps_starts is None:
-        fps_starts = [torch.randint(0, n, (B * NUM_SLOTS,), dtype=torch.long) for n in FPS_RANGES]
-    starts = torch.stack([s.reshape(-1) for s in fps_starts]).long()
-    model._check_starts(starts, B * NUM_SLOTS)
+        fps_starts = [torch.randint(0, n, (B * NUM_SLOTS,), dtype=torch.long, device=dev if on_device else None) for n in FPS_RANGES]
+        starts = torch.stack([s.reshape(-1) for s in fps_starts]).long()
+    else:
+        starts = torch.stack([s.reshape(-1) for s in fps_starts]).long()
+        model._check_starts(starts, B * NUM_SLOTS)
     training = bool(model.training)
     if training and dropout_keep is None:
-        dropout_keep = torch.empty(B * NUM_SLOTS, 128, 1024).bernoulli_(0.5)
+        dropout_keep = (torch.empty(B * NUM_SLOTS, 128, 1024, device=dev).bernoulli_(0.5).to(torch.uint8) if on_device
+                        else torch.empty(B * NUM_SLOTS, 128, 1024).bernoulli_(0.5))
     if not training:
         dropout_keep = None
     session = getattr(model, "_train_session", None)

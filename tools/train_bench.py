@@ -16,9 +16,13 @@ from lsdm_amd.util.model_util import create_model_and_diffusion  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=6)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--device-rng", action="store_true", help="draws (noise, FPS starts, dropout mask) from the device generator")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 model, diffusion = create_model_and_diffusion("proxd", device=0)
+if a.device_rng:
+    from lsdm_amd.util.model_util import create_gaussian_diffusion, get_default_diffusion
+    diffusion = create_gaussian_diffusion(get_default_diffusion(), host_rng=False)
 model.load_state_dict(make_synthetic_state_dict(seed=0))
 model.requires_grad_(True)
 model.train()
