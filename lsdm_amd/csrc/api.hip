@@ -151,6 +151,10 @@ struct lsdm_ctx {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-phase marker)
+    std::vector<int> prof_w;    // steps the launch(es) of the interval cover (a dense stage batched over the steps of a group counts as that many)
+    // level features of a whole GROUP of steps (group-batched encoder stages of the loop-invariant bf16x3 schedule): allocated on first use
+    struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}; std::vector<void*> allocs; } gws;
+    int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
     size_t prof_cur = 0;
 };
 
@@ -203,15 +207,17 @@ const double kKernelMacs[K_COUNT] = {0.24e6, 16.8e6, 7.2e6, 0, 0, 0, 0, 0,
     1024.0 * (320 * 256 + 256 * 128), 1024.0 * (3 * 128 * 128 + 128 * 128 + 128 * 3), 0.0009e9 / 9,
     1024.0 * (512 * 256 + 256 * 128 + 2 * (3 * 64 + 64 * 128 + 256 * 192 + 192 * 128 + 128 * 64 + 64 * 3)), 0};
 
-void prof_mark(lsdm_ctx* c, int id, hipStream_t st) {
+void prof_mark(lsdm_ctx* c, int id, hipStream_t st, int weight = 1) {
     if (!c->prof_on) return;
     if (c->prof_cur >= c->prof_ev.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { c->prof_on = false; return; }
         c->prof_ev.push_back(e);
         c->prof_id.push_back(id);
+        c->prof_w.push_back(weight);
     }
     c->prof_id[c->prof_cur] = id;
+    c->prof_w[c->prof_cur] = weight;
     (void)hipEventRecord(c->prof_ev[c->prof_cur++], st);
 }
 
@@ -592,6 +598,82 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     else launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
 }
 
+// Group-batched encoder stages (loop-invariant schedule, bf16x3, default kernels).  Nothing in the scene encoder reads x or anything a
+// step produces: like the geometry, the stages of the g steps of a group are independent of each other.  Measured per stage at B = 64
+// (all seven stages batched over the group against one step at a time, us per step): level-1 re-ordering 27.7 -> 12.2, sa2 290 -> 284,
+// fp4 85 -> 61 (576 tiles on 512 slots per step: a second, nearly empty round every step), fp1 272 -> 268 -- but sa3 309 -> 318, sa4
+// 329 -> 352, fp3 160 -> 166, fp2 333 -> 339: a stage whose input was just written by its producer (U / V, Y: 75 .. 300 MB per step) finds it
+// in the 256 MB Infinity Cache one step at a time and in HBM when seven steps' worth lies between them.  So the group runs
+//   batched : level-1 re-ordering, sa2, fp4   (small or invariant inputs; tails and launches amortised over the group)
+//   per step: sa3, sa4 (producer -> consumer through the cache), then fp3, fp2, fp1 + head
+// with the per-call invariants (inv_F1, sa2's U / V in source order) read modulo the clouds of one step and the level features of the
+// group in c->gws.  Same kernels, same per-cloud arithmetic: bit-identical to the step-by-step form (LSDM_BATCH_ENC=0).
+bool group_batched(const lsdm_ctx* c) {
+    return c->batch_enc && inv_in_source_order(c) && c->sa_split >= 3 && c->sa_reg >= 3 && c->fp_pre >= 2 && c->fuse_y && c->fp4_pre && c->fp1_reg;
+}
+
+bool ensure_group_ws(lsdm_ctx* c, int B) {
+    lsdm_ctx::GroupWs& g = c->gws;
+    if (g.cap_B >= B) return true;
+    for (void* p : g.allocs) (void)hipFree(p);
+    g.allocs.clear();
+    g.cap_B = 0;
+    constexpr size_t G = lsdm_ctx::kGroup;
+    const size_t nc = (size_t)B * kO * G;
+    auto al = [&](size_t n) -> float* {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) { fail(c, LSDM_ERR_HIP, "group workspace: hipMalloc of %zu bytes failed", n * sizeof(float)); return nullptr; }
+        g.allocs.push_back(p);
+        return static_cast<float*>(p);
+    };
+    bool ok = true;
+    for (int l = 1; l < 4 && ok; ++l) ok = (g.feat[l] = al(nc * kS[l] * kFeatC[l])) != nullptr;
+    ok = ok && (g.ybuf[0] = al(nc * 64 * 256)) && (g.ybuf[2] = al(nc * 16 * 256));
+    if (ok) g.cap_B = B;
+    return ok;
+}
+
+// front half of the group: everything up to fp4 (which also writes fp3's pre-multiplied operand for every step of the group)
+void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds, int B, int steps, hipStream_t st) {
+    const lsdm_ctx::GroupWs& g = c->gws;
+    const int nc1 = B * kO, nc = nc1 * steps;
+    prof_mark(c, K_REMAP, st, steps);
+    launch_l1_remap(nc, c->inv_F1, 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], clouds, nullptr, f.nn_idx[3], f.nn_w[3], st, nc1);
+    prof_mark(c, K_SA1 + 1, st, steps);
+    launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
+    for (int j = 0; j < steps; ++j) {
+        const FrontSet fj = c->fset(j, B);
+        float* const f1 = g.feat[1] + (size_t)j * nc1 * 256 * 128;
+        float* const f2 = g.feat[2] + (size_t)j * nc1 * 64 * 256;
+        float* const f3 = g.feat[3] + (size_t)j * nc1 * 16 * 512;
+        prof_mark(c, K_SA1 + 2, st);
+        launch_lin_u(2, nc1 * 256, f1, fj.xyz[1], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
+        launch_sa_u(2, nc1, c->sa_U[0], c->sa_V[0], fj.idx[2], fj.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+        prof_mark(c, K_SA1 + 3, st);
+        launch_lin_u(3, nc1 * 64, f2, fj.xyz[2], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
+        launch_sa_u(3, nc1, c->sa_U[1], c->sa_V[1], fj.idx[3], fj.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+    }
+    prof_mark(c, K_FP4, st, steps);
+    // (fp4 / fp3 store only the next finer stage's pre-multiplied operand inside a multi-step call: keep_out = false, `out` unused)
+    launch_fp_pre(4, nc, g.feat[2], nullptr, g.feat[3], c->fp_y[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], nullptr, false,
+                  c->fp_y[0], g.ybuf[0], false, st);
+    prof_mark(c, -1, st);
+}
+
+// back half, one step: fp3 (its pre-multiplied operand came from the group's fp4 launch), fp2, fp1 + head -> c->pcd
+void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, hipStream_t st) {
+    const lsdm_ctx::GroupWs& g = c->gws;
+    const int nc1 = B * kO;
+    prof_mark(c, K_FP3, st);
+    launch_fp_pre(3, nc1, g.feat[1] + (size_t)j * nc1 * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + (size_t)j * nc1 * 64 * 256, fj.nn_idx[1], fj.nn_w[1],
+                  c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], c->fp_ybuf[1], false, st);
+    prof_mark(c, K_FP2, st);
+    launch_fp_pre(2, nc1, static_cast<const float*>(c->inv_F1), fj.idx[0], nullptr, c->fp_y[1], c->fp_ybuf[1], fj.nn_idx[2], fj.nn_w[2], c->fp_a[1], c->fp_h[2][1],
+                  c->fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
+    prof_mark(c, K_FP1, st);
+    launch_fp_s(nc1, c->fpo2, fj.nn_idx[3], fj.nn_w[3], c->fp1_s.w, c->fp1_s.b, c->pcd, st);
+}
+
 int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
     run_geometry(c, c->fs0, clouds, starts, nc, 1, st);
     run_encoder_dense(c, c->fs0, clouds, nc, out, st);
@@ -731,6 +813,7 @@ int lsdm_destroy(lsdm_ctx* c) {
         for (void* p : c->sched_allocs) (void)hipFree(p);
         for (void* p : c->ws_allocs) (void)hipFree(p);
         for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+        for (void* p : c->gws.allocs) (void)hipFree(p);
     }
     delete c;
     return LSDM_OK;
@@ -1224,9 +1307,26 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
         run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st, /*shared=*/true);
         run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
+        const bool grp = inv && g > 1 && group_batched(c);
+        if (grp) {
+            if (!ensure_group_ws(c, B)) return LSDM_ERR_HIP;
+            run_encoder_group_front(c, c->fs0, given_objs, B, g, st);
+        }
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
             const lsdm_ctx::FrontSet f = c->fset_steps(j, B);
+            if (grp) {
+                // the rest of the step's encoder, scene attention and denoiser (run_back without the level-1 re-ordering)
+                const bool skip_guiding = c->den_reg && k != K - 1;
+                run_encoder_group_step(c, f, B, j, st);
+                prof_mark(c, K_SATTN, st);
+                launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
+                run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)k * xn, out_x0, skip_guiding ? nullptr : out_guiding, nxt, st, 1, c->shared_t());
+                rc = check_launch(c, "sample step");
+                if (rc) return rc;
+                float* tmp = cur; cur = nxt; nxt = tmp;
+                continue;
+            }
             // saved_guiding_points is defined by the LAST forward of the call (Q12): the loop-invariant schedule runs the denoiser's
             // guiding-point pass only there (every other step's result would be overwritten unseen); the strict schedule keeps the
             // reference's literal work and runs it every step
@@ -1381,7 +1481,7 @@ int lsdm_profile_end(lsdm_ctx* c, int capacity, double* total_ms, int64_t* launc
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
         total_ms[id] += ms;
-        launches[id] += 1;
+        launches[id] += c->prof_w[i];
     }
     return K_COUNT;
 }

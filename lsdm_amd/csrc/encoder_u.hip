@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                                                          const int* __restrict__ cent_idx, const int* __restrict__ ball,
                                                          const int* __restrict__ remap, int NSRC, int S, long long total_centroids,
                                                          const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, int src_mod) {
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
     constexpr int W2E = NB2 * KS2 * NP * 512, W3E = NB3 * KS3 * NP * 512;
@@ -386,7 +386,8 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     };
     if (cbeg + wave < cend) request(cbeg + wave);
     for (int cent = cbeg + wave; cent < cend; cent += cstep) {
-        const int c = cent / S;
+        // (src_mod > 0: a launch over the clouds of several steps whose U / V are per-CALL tensors in source order)
+        const int c = src_mod > 0 ? (cent / S) % src_mod : cent / S;
         const int idx = idx_n, ci = ci_n;
         const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
         const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 8 * h;
@@ -645,7 +646,7 @@ template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4>
 __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                         const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
-                                                        float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out) {
+                                                        float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out, int p1_mod) {
     constexpr int TM = TM_, NW = NW_, NP = 2, NT = NW * 64;
     static_assert(NT == 4 * TM, "four threads per fine point in the interpolation phase");
     // fp32 tile row (floats): 68 quads, and the quad index of an access is XORed with (row / 4) & 3 -- the 16-lane phases of both the
@@ -674,7 +675,8 @@ __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(cons
         for (int it = 0; it < XIT; ++it) {
             const int e = tid + it * NT;
             const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
-            gx[it] = load4f(points1 + ((size_t)c * N + p1_remap[(size_t)c * N + n0 + row]) * D1 + 4 * c4);
+            // (p1_mod > 0: a launch over the clouds of several steps; points1 is the per-CALL tensor in source order, cloud c % p1_mod)
+            gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? c % p1_mod : c) * N + p1_remap[(size_t)c * N + n0 + row]) * D1 + 4 * c4);
         }
     } else {
 #pragma unroll
@@ -827,14 +829,14 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
 // fuse fp2's Y = out x wb_next^T into this launch; `out` itself is then stored only when keep_out.
 void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
-                   bool keep_out, hipStream_t st) {
+                   bool keep_out, hipStream_t st, int p1_mod) {
     const int S = which == 2 ? 256 : (which == 3 ? 64 : 16);
     const DenseH none{nullptr, nullptr};
     if (which == 4) {
         // fp4: 64 fine <- 16 coarse points per cloud, D1 = 256, the coarse features are 512 wide
         hipLaunchKernelGGL((lin_u_kernel<512, 256, false>), dim3((nc * 16 + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, nc * 16, wb, nullptr, ybuf, nullptr);
         hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16, l1a, l2,
-                           out, wb_next, ynext, keep_out ? 1 : 0);
+                           out, wb_next, ynext, keep_out ? 1 : 0, p1_mod);
         return;
     }
     if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
@@ -845,17 +847,17 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
         constexpr int dbg = 0;
 #endif
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
-                           none, nullptr, 1 | (dbg << 1));
+                           none, nullptr, 1 | (dbg << 1), p1_mod);
     }
     else if (ynext) {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
         // each other's gather and barrier phases)
         hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
-                           out, wb_next, ynext, keep_out ? 1 : 0);
+                           out, wb_next, ynext, keep_out ? 1 : 0, p1_mod);
     }
     else
         hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out,
-                           none, nullptr, 1);
+                           none, nullptr, 1, p1_mod);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -867,7 +869,7 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
 }
 
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
-                 const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st) {
+                 const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod) {
     if (level == 3) {
 #ifdef LSDM_TIMING_EXPERIMENTS   // `make TIMING=1` only: results are wrong with these (1 no panel copy, 2 no barrier)
         static const int dbg = getenv("LSDM_DBG_SAW") ? atoi(getenv("LSDM_DBG_SAW")) : 0;
@@ -879,7 +881,7 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
         const long long tot = (long long)nc * 256;
         // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
         // issue-bound -- MFMA and VALU time add -- not latency-bound)
-        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out);
+        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out, src_mod);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
         hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);

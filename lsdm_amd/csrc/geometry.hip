@@ -802,12 +802,13 @@ __global__ __launch_bounds__(256) void nn8_kernel(const float* __restrict__ clou
 __global__ __launch_bounds__(256) void l1_remap_kernel(const unsigned char* __restrict__ F1, int row_bytes, const int* __restrict__ idx1,
                                                        const float* __restrict__ nn8_d, const int* __restrict__ nn8_i,
                                                        const float* __restrict__ l1_xyz, const float* __restrict__ clouds,
-                                                       unsigned char* __restrict__ feat1, int* __restrict__ nn_idx, float* __restrict__ nn_w) {
+                                                       unsigned char* __restrict__ feat1, int* __restrict__ nn_idx, float* __restrict__ nn_w, int inv_mod) {
     constexpr int N = kPoints, NT = 256;
     __shared__ unsigned short pos[N];
     __shared__ float4 pts[N];
     __shared__ int missing;
     const int c = blockIdx.x, tid = threadIdx.x;
+    const int ci = inv_mod > 0 ? c % inv_mod : c;       // cloud of the per-call inputs (a launch may cover the clouds of several steps)
     const int* id = idx1 + (size_t)c * N;
     for (int e = tid; e < N; e += NT) pos[e] = 0xFFFFu;
     if (tid == 0) missing = 0;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void l1_remap_kernel(const unsigned char* __re
         if (pos[e] == 0xFFFFu) missing = 1;
     // feature rows (16-byte pieces; row_bytes = 256 fp32 / 128 bf16)
     const int ppr = row_bytes / 16;
-    const unsigned char* fsrc = F1 + (size_t)c * N * row_bytes;
+    const unsigned char* fsrc = F1 + (size_t)ci * N * row_bytes;
     unsigned char* fdst = feat1 + (size_t)c * N * row_bytes;
     if (feat1) {   // (NULL: the consumers read F1 through idx1 themselves)
         for (int e = tid; e < N * ppr; e += NT) {
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void l1_remap_kernel(const unsigned char* __re
     // candidate is strictly farther than the chosen third (otherwise more ties than candidates: exhaustive path below)
     if (!missing) {
         for (int n = tid; n < N; n += NT) {
-            const size_t o8 = ((size_t)c * N + n) * 8;
+            const size_t o8 = ((size_t)ci * N + n) * 8;
             float d[8];
             int ps[8];
 #pragma unroll
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(256) void l1_remap_kernel(const unsigned char* __re
         pts[p] = make_float4(x, y, z, sumsq3(x, y, z));
     }
     __syncthreads();
-    const float* cl = clouds + (size_t)c * N * 3;
+    const float* cl = clouds + (size_t)ci * N * 3;
     for (int n = tid; n < N; n += NT) {
         const float ax = cl[n * 3 + 0], ay = cl[n * 3 + 1], az = cl[n * 3 + 2];
         const float a2 = sumsq3(ax, ay, az);
@@ -897,9 +898,9 @@ void launch_nn8(int nc, const float* clouds, float* out_d, int* out_i, hipStream
 }
 
 void launch_l1_remap(int nc, const void* F1, int row_bytes, const int* idx1, const float* nn8_d, const int* nn8_i, const float* l1_xyz,
-                     const float* clouds, void* feat1, int* nn_idx, float* nn_w, hipStream_t st) {
+                     const float* clouds, void* feat1, int* nn_idx, float* nn_w, hipStream_t st, int inv_mod) {
     hipLaunchKernelGGL(l1_remap_kernel, dim3(nc), dim3(256), 0, st, static_cast<const unsigned char*>(F1), row_bytes, idx1, nn8_d, nn8_i,
-                       l1_xyz, clouds, static_cast<unsigned char*>(feat1), nn_idx, nn_w);
+                       l1_xyz, clouds, static_cast<unsigned char*>(feat1), nn_idx, nn_w, inv_mod);
 }
 
 // ---------------------------------------------------------------------------------------------

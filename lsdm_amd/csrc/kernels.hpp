@@ -84,8 +84,9 @@ void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int
                      hipStream_t st);
 // level-1 loop-invariant work translated into the step's FPS order (lsdm_sample_steps_invariant): feature rows + 3-NN positions
 void launch_nn8(int num_clouds, const float* clouds, float* out_d, int* out_i, hipStream_t st);
+// inv_mod > 0: a launch over the clouds of several steps -- the per-call inputs (F1, nn8_*, clouds) are those of cloud c % inv_mod
 void launch_l1_remap(int num_clouds, const void* F1, int row_bytes, const int* idx1, const float* nn8_d, const int* nn8_i,
-                     const float* l1_xyz, const float* clouds, void* feat1, int* nn_idx, float* nn_w, hipStream_t st);
+                     const float* l1_xyz, const float* clouds, void* feat1, int* nn_idx, float* nn_w, hipStream_t st, int inv_mod = 0);
 // encoder.hip
 void launch_sa(int level, int num_clouds, const float* src_xyz, const float* src_feat, const float* new_xyz, const int* ball,
                const Dense* l, float* out, hipStream_t st);
@@ -108,15 +109,16 @@ void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const 
 // point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
 // ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
 void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
+// src_mod > 0 (level 1 with remap, a launch over the clouds of several steps): U / V are per-CALL tensors, those of cloud c % src_mod
 void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
-                 const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st);
+                 const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod = 0);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
 // p1_remap (optional): row i of a cloud's points1 is points1[p1_remap[i]]
 // y_ready: ybuf was written by the coarser stage's fused extra layer; wb_next / ynext (which = 3, optional): this launch also writes
 // fp2's pre-multiplied operand ynext = out x wb_next^T, and stores `out` itself only when keep_out (parity taps)
 void launch_fp_pre(int which, int num_clouds, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
-                   bool keep_out, hipStream_t st);
+                   bool keep_out, hipStream_t st, int p1_mod = 0);      // p1_mod > 0 (with p1_remap): points1 is a per-CALL tensor, cloud c % p1_mod
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,
