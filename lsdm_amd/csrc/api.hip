@@ -155,6 +155,9 @@ struct lsdm_ctx {
     // level features of a whole GROUP of steps (group-batched encoder stages of the loop-invariant bf16x3 schedule): allocated on first use
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}; std::vector<void*> allocs; } gws;
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
+    // experiment: the producer -> consumer chains of a step in this many cloud slices (each slice's intermediate then fits the Infinity Cache)
+    int split_sa = getenv("LSDM_SPLIT_SA") ? atoi(getenv("LSDM_SPLIT_SA")) : 1;
+    int split_fp = getenv("LSDM_SPLIT_FP") ? atoi(getenv("LSDM_SPLIT_FP")) : 1;
     size_t prof_cur = 0;
 };
 
@@ -641,17 +644,21 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     launch_l1_remap(nc, c->inv_F1, 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], clouds, nullptr, f.nn_idx[3], f.nn_w[3], st, nc1);
     prof_mark(c, K_SA1 + 1, st, steps);
     launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
+    const int PS = (c->split_sa > 1 && nc1 % c->split_sa == 0) ? c->split_sa : 1, ncp = nc1 / PS;
     for (int j = 0; j < steps; ++j) {
         const FrontSet fj = c->fset(j, B);
-        float* const f1 = g.feat[1] + (size_t)j * nc1 * 256 * 128;
-        float* const f2 = g.feat[2] + (size_t)j * nc1 * 64 * 256;
-        float* const f3 = g.feat[3] + (size_t)j * nc1 * 16 * 512;
-        prof_mark(c, K_SA1 + 2, st);
-        launch_lin_u(2, nc1 * 256, f1, fj.xyz[1], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
-        launch_sa_u(2, nc1, c->sa_U[0], c->sa_V[0], fj.idx[2], fj.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
-        prof_mark(c, K_SA1 + 3, st);
-        launch_lin_u(3, nc1 * 64, f2, fj.xyz[2], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-        launch_sa_u(3, nc1, c->sa_U[1], c->sa_V[1], fj.idx[3], fj.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+        for (int h = 0; h < PS; ++h) {
+            const size_t o = (size_t)h * ncp;      // first cloud of the slice
+            float* const f1 = g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128;
+            float* const f2 = g.feat[2] + ((size_t)j * nc1 + o) * 64 * 256;
+            float* const f3 = g.feat[3] + ((size_t)j * nc1 + o) * 16 * 512;
+            prof_mark(c, K_SA1 + 2, st);
+            launch_lin_u(2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
+            launch_sa_u(2, ncp, c->sa_U[0], c->sa_V[0], fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+            prof_mark(c, K_SA1 + 3, st);
+            launch_lin_u(3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
+            launch_sa_u(3, ncp, c->sa_U[1], c->sa_V[1], fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+        }
     }
     prof_mark(c, K_FP4, st, steps);
     // (fp4 / fp3 store only the next finer stage's pre-multiplied operand inside a multi-step call: keep_out = false, `out` unused)
@@ -664,14 +671,18 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
 void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, hipStream_t st) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = B * kO;
-    prof_mark(c, K_FP3, st);
-    launch_fp_pre(3, nc1, g.feat[1] + (size_t)j * nc1 * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + (size_t)j * nc1 * 64 * 256, fj.nn_idx[1], fj.nn_w[1],
-                  c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], c->fp_ybuf[1], false, st);
-    prof_mark(c, K_FP2, st);
-    launch_fp_pre(2, nc1, static_cast<const float*>(c->inv_F1), fj.idx[0], nullptr, c->fp_y[1], c->fp_ybuf[1], fj.nn_idx[2], fj.nn_w[2], c->fp_a[1], c->fp_h[2][1],
-                  c->fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
-    prof_mark(c, K_FP1, st);
-    launch_fp_s(nc1, c->fpo2, fj.nn_idx[3], fj.nn_w[3], c->fp1_s.w, c->fp1_s.b, c->pcd, st);
+    const int PS = (c->split_fp > 1 && nc1 % c->split_fp == 0) ? c->split_fp : 1, ncp = nc1 / PS;
+    for (int h = 0; h < PS; ++h) {
+        const size_t o = (size_t)h * ncp;
+        prof_mark(c, K_FP3, st);
+        launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
+                      fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], c->fp_ybuf[1], false, st);
+        prof_mark(c, K_FP2, st);
+        launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], c->fp_ybuf[1], fj.nn_idx[2] + o * 1024 * 3,
+                      fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], c->fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
+        prof_mark(c, K_FP1, st);
+        launch_fp_s(ncp, c->fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, c->pcd + o * kN * 3, st);
+    }
 }
 
 int run_scene_encoder(lsdm_ctx* c, const float* clouds, const int64_t* starts, int nc, float* out, hipStream_t st) {
