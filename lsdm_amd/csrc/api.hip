@@ -155,9 +155,6 @@ struct lsdm_ctx {
     // level features of a whole GROUP of steps (group-batched encoder stages of the loop-invariant bf16x3 schedule): allocated on first use
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}; std::vector<void*> allocs; } gws;
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
-    // experiment: the producer -> consumer chains of a step in this many cloud slices (each slice's intermediate then fits the Infinity Cache)
-    int split_sa = getenv("LSDM_SPLIT_SA") ? atoi(getenv("LSDM_SPLIT_SA")) : 1;
-    int split_fp = getenv("LSDM_SPLIT_FP") ? atoi(getenv("LSDM_SPLIT_FP")) : 1;
     size_t prof_cur = 0;
 };
 
@@ -644,7 +641,11 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     launch_l1_remap(nc, c->inv_F1, 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], clouds, nullptr, f.nn_idx[3], f.nn_w[3], st, nc1);
     prof_mark(c, K_SA1 + 1, st, steps);
     launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
-    const int PS = (c->split_sa > 1 && nc1 % c->split_sa == 0) ? c->split_sa : 1, ncp = nc1 / PS;
+    // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were
+    // measured: fp2 337 -> 323 us, but fp1 275 -> 295, fp3 165 -> 190, sa3 / sa4 slower as well -- the extra launch ramps and tails cost
+    // more than the cache residency gains)
+    constexpr int PS = 1;
+    const int ncp = nc1;
     for (int j = 0; j < steps; ++j) {
         const FrontSet fj = c->fset(j, B);
         for (int h = 0; h < PS; ++h) {
@@ -671,7 +672,8 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
 void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, hipStream_t st) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = B * kO;
-    const int PS = (c->split_fp > 1 && nc1 % c->split_fp == 0) ? c->split_fp : 1, ncp = nc1 / PS;
+    constexpr int PS = 1;
+    const int ncp = nc1;
     for (int h = 0; h < PS; ++h) {
         const size_t o = (size_t)h * ncp;
         prof_mark(c, K_FP3, st);
