@@ -473,6 +473,9 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
 // chains, issued alternately -- a single dependent chain leaves the matrix pipe idle a quarter of the time at one wave per SIMD
 // (tools/ubench/mfma_clock: 1.59 vs 2.08 PFLOP/s).
 // blob: build_chain_blob({conv1 256 x 256, conv2 512 x 256}, identity first map): [nb][s = 0..15][plane][lane][8]; biases [256 | 512].
+// (Round 3: the epilogue of panel Q - 1 software-pipelined against panel Q's 96 matrix instructions on a second accumulator set, as in
+// sa_p_kernel, measured no change -- 353 vs 353-355 us: at one wave per SIMD this kernel waits for its 64 KB weight panels, not for
+// its epilogues; skipping the panel copies gives 317 us.)
 template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
