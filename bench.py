@@ -43,10 +43,12 @@ GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
 # them separately (profiles/r01_*_kernel_stats.md), the HIP-event interval of the stage covers both.
 STAGE_KERNELS_BF16X3 = {
     "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64> (once per call in the loop-invariant schedule)",
-    "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128>",
+    "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128> "
+                               "(ONE launch per group of 7 steps in the loop-invariant schedule; avg_launch_ms is per step covered)",
     "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_p_kernel<128,128,256,12> (epilogues software-pipelined against the next block's MFMAs)",
     "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_w_kernel",
-    "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y)",
+    "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y); one launch per "
+                      "group of 7 steps in the loop-invariant schedule",
     "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
     "fp_kernel<fp2>": "fp_pre_kernel<64,256,128>",
     "fp_kernel<fp1+head>": "fp_s_kernel<8,2>",
@@ -373,6 +375,8 @@ def main():
                      "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                      "frac": dom["tflops"] / peak, "frac_of_attainable": dom["tflops"] / peak * (3.0 if a.precision == "bf16x3" else 1.0),
                      "traffic": traffic, "avg_launch_ms": dom["avg_ms"],
+                     "avg_launch_ms_is": "HIP-event time of the stage per STEP covered (a stage batched over the steps of a group counts as that many "
+                                         "launches; the dominant stage runs one launch per step)",
                      "algorithmic_gflop_per_launch": dom["gflop"],
                      "peak_note": {"f32": "dense f32-input MFMA (v_mfma_f32_32x32x2_f32)",
                                    "bf16x3": "dense bf16 MFMA; 3 MFMAs per algorithmic product -> attainable frac 0.333",
