@@ -153,8 +153,9 @@ struct lsdm_ctx {
     std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-phase marker)
     std::vector<int> prof_w;    // steps the launch(es) of the interval cover (a dense stage batched over the steps of a group counts as that many)
     // level features of a whole GROUP of steps (group-batched encoder stages of the loop-invariant bf16x3 schedule): allocated on first use
-    struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}; std::vector<void*> allocs; } gws;
+    struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr; std::vector<void*> allocs; } gws;
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
+    int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
 };
 
@@ -629,6 +630,7 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
     bool ok = true;
     for (int l = 1; l < 4 && ok; ++l) ok = (g.feat[l] = al(nc * kS[l] * kFeatC[l])) != nullptr;
     ok = ok && (g.ybuf[0] = al(nc * 64 * 256)) && (g.ybuf[2] = al(nc * 16 * 256));
+    ok = ok && (g.pcd = al(nc * kN * 3)) && (g.o12 = al(nc * 12));
     if (ok) g.cap_B = B;
     return ok;
 }
@@ -669,7 +671,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
 }
 
 // back half, one step: fp3 (its pre-multiplied operand came from the group's fp4 launch), fp2, fp1 + head -> c->pcd
-void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, hipStream_t st) {
+void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float* pcd_out, hipStream_t st) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = B * kO;
     constexpr int PS = 1;
@@ -683,7 +685,7 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, hipSt
         launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], c->fp_ybuf[1], fj.nn_idx[2] + o * 1024 * 3,
                       fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], c->fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
         prof_mark(c, K_FP1, st);
-        launch_fp_s(ncp, c->fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, c->pcd + o * kN * 3, st);
+        launch_fp_s(ncp, c->fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st);
     }
 }
 
@@ -1325,13 +1327,32 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             if (!ensure_group_ws(c, B)) return LSDM_ERR_HIP;
             run_encoder_group_front(c, c->fs0, given_objs, B, g, st);
         }
+        if (grp && c->batch_den && c->den_reg && c->prec != LSDM_PREC_F32) {
+            // Nothing of the encoder reads x: the rest of the encoder of every step of the group first (each step's output into its own
+            // slot of gws.pcd), then the scene attention of the group in one launch and its denoiser steps in ONE launch -- a wave keeps
+            // its 32 points' x on chip between the steps and forms each step's guidance from that step's slot (denoise_reg.hip); the
+            // launch ramp, the weight-panel prologue and the tail are paid once per group instead of once per step.
+            const lsdm_ctx::GroupWs& gw = c->gws;
+            const size_t pstep = (size_t)nc * kN * 3, ostep = (size_t)nc * 12;
+            for (int j = 0; j < g; ++j) run_encoder_group_step(c, c->fset_steps(j, B), B, j, gw.pcd + (size_t)j * pstep, st);
+            prof_mark(c, K_SATTN, st, g);
+            launch_scene_attn(c->sattn, gw.pcd, c->fs0.w, c->fs0.tr, B, gw.o12, st, g);
+            prof_mark(c, K_DENOISE, st, g);
+            launch_denoise_r(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_r, c->den_h.pwt, c->sched, mode, eta, B, g, 0, cur, c->fs0.tbuf, mask, gw.pcd, c->fs0.w,
+                             gw.o12, c->hm, c->ctext, c->ct_time, noise + (size_t)k0 * xn, c->s_stash, out_x0, k0 + g < K ? nullptr : out_guiding, nullptr,
+                             c->fps_slots / 16, st, (long long)pstep, (long long)ostep);
+            prof_mark(c, -1, st);
+            rc = check_launch(c, "sample steps (group)");
+            if (rc) return rc;
+            continue;
+        }
         for (int j = 0; j < g; ++j) {
             const int k = k0 + j;
             const lsdm_ctx::FrontSet f = c->fset_steps(j, B);
             if (grp) {
-                // the rest of the step's encoder, scene attention and denoiser (run_back without the level-1 re-ordering)
+                // (LSDM_BATCH_DEN=0) the rest of the step's encoder, scene attention and denoiser, one step at a time
                 const bool skip_guiding = c->den_reg && k != K - 1;
-                run_encoder_group_step(c, f, B, j, st);
+                run_encoder_group_step(c, f, B, j, c->pcd, st);
                 prof_mark(c, K_SATTN, st);
                 launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
                 run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)k * xn, out_x0, skip_guiding ? nullptr : out_guiding, nxt, st, 1, c->shared_t());

@@ -359,15 +359,16 @@ __device__ __forceinline__ float scrambled_P(const float* __restrict__ pcd_b, co
 }
 
 __global__ __launch_bounds__(256) void scene_attn_kernel(SceneAttnParams P, const float* __restrict__ pcd, const float* __restrict__ w,
-                                                         const float* __restrict__ tr, float* __restrict__ o_out) {
+                                                         const float* __restrict__ tr, float* __restrict__ o_out, int B) {
     __shared__ float q2[12], redm[4][12], reds[4][24], fin[24], osum[12];
-    const int bo = blockIdx.x, b = bo / kSlots, op = bo - b * kSlots;
+    // (a launch over several steps of a group: block bo = (step * B + b) * 9 + op; w / tr are per SAMPLE, pcd / o per (step, sample))
+    const int bo = blockIdx.x, b = bo / kSlots, op = bo - b * kSlots, bs = b % B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pcd_b = pcd + (size_t)b * kSlots * kPoints * 3;
-    const float* w_b = w + (size_t)b * kSlots;
+    const float* w_b = w + (size_t)bs * kSlots;
     if (tid < 12) {
         float s = 0.0f;
-        for (int k = 0; k < 12; ++k) s = fmaf(tr[(size_t)bo * 12 + k], P.wq[tid * 12 + k], s);
+        for (int k = 0; k < 12; ++k) s = fmaf(tr[((size_t)bs * kSlots + op) * 12 + k], P.wq[tid * 12 + k], s);
         q2[tid] = s + P.inb[tid];   // head_dim 1 -> scale 1
     }
     __syncthreads();
@@ -440,8 +441,8 @@ void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, co
     else if (np == 1) hipLaunchKernelGGL((upsample12_kernel<1, 128>), dim3(rows * 2), block, 0, st, e0, c_off, up0, up2, h2p);
     else hipLaunchKernelGGL((upsample12_kernel<2, 128>), dim3(rows * 2), block, 0, st, e0, c_off, up0, up2, h2p);
 }
-void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st) {
-    hipLaunchKernelGGL(scene_attn_kernel, dim3(B * kSlots), dim3(256), 0, st, P, pcd, w, tr, o);
+void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st, int steps) {
+    hipLaunchKernelGGL(scene_attn_kernel, dim3(steps * B * kSlots), dim3(256), 0, st, P, pcd, w, tr, o, B);
 }
 
 }  // namespace lsdm

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                                                        const float* __restrict__ ctext, const float* __restrict__ ctime,
                                                        const float* __restrict__ noise, float* __restrict__ stash,
                                                        float* __restrict__ out_x0, float* __restrict__ out_guiding,
-                                                       float* __restrict__ out_sample) {
+                                                       float* __restrict__ out_sample, long long pcd_step, long long o12_step) {
     using L = RL<NP>;
     constexpr int NSLOT = 4;                                   // panel ring: the panel consumed now + three in flight
     __shared__ __attribute__((aligned(16))) __bf16 wl[NSLOT][L::PANEL * 512];
@@ -138,11 +138,14 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
     for (int e = tid; e < L::F2_KS * NP * 64; e += NT)
         *reinterpret_cast<bf16x8*>(wf2 + (size_t)e * 8) = gload<bf16x8>(blob_w + (size_t)L::OFF_F2 * 512 + (size_t)e * 8);
     for (int e = tid; e < B_TOTAL; e += NT) bl[e] = blob_b[e];
-    float* zt = fsm[wave];            // mutated x of the wave's 32 points (x 3)
-    float* gt = zt + 96;              // guidance / guiding points
-    float* xs = gt + 96;              // current sample between steps
-    float* res = xs + 96;             // denoiser output
-    float* oterm = res + 96;          // W15[c, 3:15] . o[b, o', :]   (27 values)
+    // (explicitly LDS-typed: with the guidance inside the step loop the compiler no longer proved these generic pointers to be LDS
+    // and its flat-address fallback does not assemble -- "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+    using LF = __attribute__((address_space(3))) float;
+    LF* zt = (LF*)&fsm[wave][0];      // mutated x of the wave's 32 points (x 3)
+    LF* gt = zt + 96;                 // guidance / guiding points
+    LF* xs = gt + 96;                 // current sample between steps
+    LF* res = xs + 96;                // denoiser output
+    LF* oterm = res + 96;             // W15[c, 3:15] . o[b, o', :]   (27 values)
 
     const int total = B * (kPoints / 32);                       // 32-point blocks
     const int rounds = (total + NW - 1) / NW;
@@ -170,10 +173,13 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
         if (++q_step >= nsteps) { q_step = 0; ++q_round; }
     };
     // the panel consumed now (the request for the one three ahead goes into the slot the previous barrier released)
-    auto panel_begin = [&]() -> const __bf16* {
+    // (lzo: the opaque zero itself, for the bias reads of the same phase -- as an int, not as a difference of LDS pointers, which
+    // the compiler takes through generic addresses)
+    auto panel_begin = [&](int& lzo) -> const __bf16* {
         request_next();
         int lz = 0;
         asm volatile("" : "+v"(lz));      // opaque zero: the (step-invariant) LDS reads stay inside the loops
+        lzo = lz;
         return &wl[pc % NSLOT][0] + lz;
     };
     // the NEXT panel must have landed: everything but the copies of the two panels behind it may still be in flight (loads return
@@ -198,33 +204,14 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
         const float* pcd_b = pcd + (size_t)b * kSlots * kPoints * 3;
         const float* w_b = w + (size_t)b * kSlots;
         const size_t g0 = ((size_t)b * kPoints + n0) * 3;       // first element of the wave's (32, 3) tile
-        // ---- guidance g (fp32): depends on the scene conditioning only ----------------------------------------------------
-        if (lane < kSlots * 3) {
-            const int op = lane / 3, c = lane - op * 3;
-            float s = 0.0f;
-            for (int k = 0; k < 12; ++k) s = fmaf(o12[((size_t)b * kSlots + op) * 12 + k], pwt.w[c * 15 + 3 + k], s);
-            oterm[lane] = s;
-        }
-        wave_sync();
 #pragma unroll 1
-        for (int i = lane; i < 96; i += 64) {
-            const int row = i / 3, c = i - row * 3, n = n0 + row;
-            float acc = 0.0f;
-            for (int op = 0; op < kSlots; ++op) {
-                const float p0 = scrambled_r(pcd_b, w_b, op, n, 0), p1 = scrambled_r(pcd_b, w_b, op, n, 1), p2 = scrambled_r(pcd_b, w_b, op, n, 2);
-                float s = fmaf(p2, pwt.w[c * 15 + 2], fmaf(p1, pwt.w[c * 15 + 1], p0 * pwt.w[c * 15]));
-                s = gelu_fast(s + oterm[op * 3 + c] + pwt.b[c]);
-                // (N,-1,B,O) view: the multiplier of flat element f is mask.flatten()[f % (B*O)]  (Q2)
-                const long long f = (((long long)b * kSlots + op) * kPoints + n) * 3 + c;
-                acc += s * mask[f % ((long long)B * kSlots)];
-            }
-            gt[i] = (acc + hm[g0 + i]) / 2.0f;
-            xs[i] = x[g0 + i];
-        }
+        for (int i = lane; i < 96; i += 64) xs[i] = x[g0 + i];
         wave_sync();
+        // the human branch's rows of the tile (per call): element lane and, for the lower half-wave, 64 + lane
+        const float hm0 = hm[g0 + lane], hm1 = lane < 32 ? hm[g0 + 64 + lane] : 0.0f;
 
         // one denoiser pass on the (32, 3) tile zsrc (LDS) -> res; consumes S in place (panels 3 .. 11)
-        auto pass = [&](const float* zsrc, f32x16 (&S)[6]) {
+        auto pass = [&](const LF* zsrc, f32x16 (&S)[6]) {
             // pose_embedding.0: 3 -> 64 sigmoid (K = 3: VALU) straight into the K = 64 operand: k-slot (s, h, j) = channel 16 s + 8 h + j
             bf16x8 ah[4], al[4];
             {
@@ -245,8 +232,9 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             // ---- panel 3: pose2 64 -> 128 sigmoid ------------------------------------------------------------------------------
             bf16x8 ph[8], pl[8];
             {
-                const __bf16* W = panel_begin();
-                const float* bz = bl + (W - &wl[pc % NSLOT][0]);
+                int lzp;
+                const __bf16* W = panel_begin(lzp);
+                const float* bz = bl + lzp;
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
                     f32x16 acc;
@@ -261,7 +249,8 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             bf16x8 ch[12], cl[12];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const __bf16* W = panel_begin();
+                int lzp;
+                const __bf16* W = panel_begin(lzp);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int nb = 2 * q + u;
@@ -275,8 +264,9 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             bf16x8 dh[8], dl[8];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const __bf16* W = panel_begin();
-                const float* bz = bl + (W - &wl[pc % NSLOT][0]);
+                int lzp;
+                const __bf16* W = panel_begin(lzp);
+                const float* bz = bl + lzp;
                 f32x16 acc;
                 acc_from_bias(acc, bz + B_CEX2 + 32 * nb, h);
                 mma_t<12, NP>(acc, W, 0, ch, cl, lane);
@@ -286,8 +276,8 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             // ---- panel 11: fin0 128 -> 64 GELU; then pose_final.2 (resident): 64 -> 3 GELU, direct orientation ---------------------
             bf16x8 fh[4], fl[4];
             {
-                const __bf16* W = panel_begin();
-                const int lzi = (int)(W - &wl[pc % NSLOT][0]);
+                int lzi;
+                const __bf16* W = panel_begin(lzi);
                 const float* bz = bl + lzi;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
@@ -323,6 +313,35 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
 #pragma unroll 1
         for (int step = 0; step < nsteps; ++step) {
             const bool last = step == nsteps - 1;
+            // ---- guidance g (fp32): depends on the scene conditioning only.  pcd_step / o12_step != 0: the launch covers the steps of a
+            // loop-invariant group, every step with its own encoder output (step-major) -- g is formed at the top of each step; 0: one
+            // conditioning for all steps of the launch (single step, hoisted groups)
+            if (step == 0 || pcd_step != 0) {
+                const float* pcd_s = pcd_b + (size_t)step * pcd_step;
+                const float* o12_s = o12 + (size_t)step * o12_step;
+                if (lane < kSlots * 3) {
+                    const int op = lane / 3, c = lane - op * 3;
+                    float s = 0.0f;
+                    for (int k = 0; k < 12; ++k) s = fmaf(o12_s[((size_t)b * kSlots + op) * 12 + k], pwt.w[c * 15 + 3 + k], s);
+                    oterm[lane] = s;
+                }
+                wave_sync();
+#pragma unroll 1
+                for (int i = lane; i < 96; i += 64) {
+                    const int row = i / 3, c = i - row * 3, n = n0 + row;
+                    float acc = 0.0f;
+                    for (int op = 0; op < kSlots; ++op) {
+                        const float p0 = scrambled_r(pcd_s, w_b, op, n, 0), p1 = scrambled_r(pcd_s, w_b, op, n, 1), p2 = scrambled_r(pcd_s, w_b, op, n, 2);
+                        float s = fmaf(p2, pwt.w[c * 15 + 2], fmaf(p1, pwt.w[c * 15 + 1], p0 * pwt.w[c * 15]));
+                        s = gelu_fast(s + oterm[op * 3 + c] + pwt.b[c]);
+                        // (N,-1,B,O) view: the multiplier of flat element f is mask.flatten()[f % (B*O)]  (Q2)
+                        const long long f = (((long long)b * kSlots + op) * kPoints + n) * 3 + c;
+                        acc += s * mask[f % ((long long)B * kSlots)];
+                    }
+                    gt[i] = (acc + (i < 64 ? hm0 : hm1)) / 2.0f;
+                }
+                wave_sync();
+            }
             // in-place update of x (Q5); the caller's tensor sees it when the launch is a single step
 #pragma unroll 1
             for (int i = lane; i < 96; i += 64) {
@@ -365,8 +384,9 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             f32x16 S[6];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const __bf16* W = panel_begin();
-                const float* bz = bl + (W - &wl[pc % NSLOT][0]);
+                int lzp;
+                const __bf16* W = panel_begin(lzp);
+                const float* bz = bl + lzp;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int nb = 2 * q + u;
@@ -449,15 +469,15 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
 void launch_denoise_r(int np, const DenseH& blob, const Lin& pwt, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int ctime_per_sample,
                       float* x, const int64_t* t, const float* mask, const float* pcd, const float* w, const float* o12, const float* hm,
                       const float* ctext, const float* ctime, const float* noise, float* stash, float* out_x0, float* out_guiding,
-                      float* out_sample, int num_cus, hipStream_t st) {
+                      float* out_sample, int num_cus, hipStream_t st, long long pcd_step, long long o12_step) {
     const int rounds = (B * (kPoints / 32) + NW - 1) / NW;
     const int grid = rounds < num_cus ? rounds : num_cus;
     if (np == 2)
         hipLaunchKernelGGL(denoise_r_kernel<2>, dim3(grid), dim3(NT), 0, st, blob.w, blob.b, pwt, sc, mode, eta, B, nsteps, ctime_per_sample, x, t, mask, pcd,
-                           w, o12, hm, ctext, ctime, noise, stash, out_x0, out_guiding, out_sample);
+                           w, o12, hm, ctext, ctime, noise, stash, out_x0, out_guiding, out_sample, pcd_step, o12_step);
     else
         hipLaunchKernelGGL(denoise_r_kernel<1>, dim3(grid), dim3(NT), 0, st, blob.w, blob.b, pwt, sc, mode, eta, B, nsteps, ctime_per_sample, x, t, mask, pcd,
-                           w, o12, hm, ctext, ctime, noise, stash, out_x0, out_guiding, out_sample);
+                           w, o12, hm, ctext, ctime, noise, stash, out_x0, out_guiding, out_sample, pcd_step, o12_step);
 }
 
 }  // namespace lsdm

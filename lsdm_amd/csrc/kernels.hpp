@@ -131,7 +131,8 @@ constexpr int kPosaWsPerSample = 16 + 16 * 24 + 11 * 24;
 // np = 0: fp32 operand for denoise_kernel (all 256 channels of e0 per row); 1 / 2: bf16 planes for denoise_h_kernel /
 // ctext_kernel, the 128 channels from c_off (0: timestep half, one row per (step, sample); 128: text half, one row per sample)
 void launch_upsample12(int np, const float* e0, Lin up0, const float* up2_wp, const float* up2_b, int rows, int c_off, void* h2p, hipStream_t st);
-void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st);
+void launch_scene_attn(const SceneAttnParams& P, const float* pcd, const float* w, const float* tr, int B, float* o, hipStream_t st, int steps = 1);
+// (steps > 1: pcd / o hold that many steps of B samples, step-major; w / tr are the call's B sample rows)
 // denoise.hip
 void launch_denoise(const DenoiseParams& P, const StepCoefs& sc, int mode, float eta, int B, float* x, const int64_t* t,
                     const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const float* h2p,
@@ -160,6 +161,7 @@ void launch_fp4_y(int nc, const float* points1, const float* points2, const int*
 void launch_denoise_r(int np, const DenseH& blob, const Lin& pwt, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int ctime_per_sample,
                       float* x, const int64_t* t, const float* mask, const float* pcd, const float* w, const float* o12, const float* hm,
                       const float* ctext, const float* ctime, const float* noise, float* stash, float* out_x0, float* out_guiding,
-                      float* out_sample, int num_cus, hipStream_t st);
+                      float* out_sample, int num_cus, hipStream_t st, long long pcd_step = 0, long long o12_step = 0);
+// (pcd_step / o12_step != 0: step s of the launch reads pcd + s * pcd_step, o12 + s * o12_step -- the steps of a loop-invariant group)
 
 }  // namespace lsdm

@@ -486,7 +486,8 @@ def test_plain_bf16_multi_step_group_equals_single_steps():
 # ======================================================================================= retained A/B switches of the library
 _SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "2"}, {"LSDM_SA_REG": "0"}, {"LSDM_SA_REG": "2", "LSDM_SA_SPLIT": "0"},
              {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
-             {"LSDM_GROUP": "3"}, {"LSDM_BATCH_ENC": "0"}]
+             {"LSDM_GROUP": "3"}, {"LSDM_BATCH_ENC": "0"}, {"LSDM_BATCH_DEN": "0"}]
+_SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN")      # launch shapes only: bit-identical results
 
 
 @pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
@@ -520,6 +521,8 @@ def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
     assert maxabs(got[2], T(g["x_mut"])) <= 1e-3 and maxabs(got[3], T(g["guiding"])) <= 1e-3
     for a, b in zip(got[4], base[4]):
         assert maxabs(a, b) <= 1e-3
+        if all(k in _SAME_ARITHMETIC for k in env):
+            assert torch.equal(a, b), env
 
 
 # ======================================================================================= clip_dim = 768 (BERT pooler width)
