@@ -356,7 +356,7 @@ def main():
         "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "sample_steps_per_s": world * B * K / dt,
         "config": {"workload": "BASELINE configs[2]: B=%d chains/GPU, 8 objects + human x 1024 pts (8192-pt scene cloud), C=13, random CLIP-text "
-                               "features, cosine T=1000, p_sample steps t=%d..%d in ONE %s call, host-replayed RNG, one stream; %s"
+                               "features, cosine T=1000, p_sample steps t=%d..%d in ONE %s call on one caller stream, host-replayed RNG; %s"
                                % (B, T - 1 - W, T - W - K, "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
                                   "per-step recompute of the conditioning MLPs and of PointNet++ (FPS with fresh starts, levels 2-4, all FP "
                                   "stages); the FPS-order-independent level-1 work (balls, sa1 features, 3-NN candidates) is evaluated once "
@@ -376,7 +376,10 @@ def main():
                      "frac": dom["tflops"] / peak, "frac_of_attainable": dom["tflops"] / peak * (3.0 if a.precision == "bf16x3" else 1.0),
                      "traffic": traffic, "avg_launch_ms": dom["avg_ms"],
                      "avg_launch_ms_is": "HIP-event time of the stage per STEP covered (a stage batched over the steps of a group counts as that many "
-                                         "launches; the dominant stage runs one launch per step)",
+                                         "launches; the dominant stage runs one launch per step), taken in a pass of the same call with the stages in "
+                                         "sequence on one stream -- the timed region itself runs the dense chains of alternate steps of a group on a side "
+                                         "stream of the library (LSDM_STREAMS=%s), where two kernels share the chip and a per-kernel duration is not defined; "
+                                         "profiles/ are recorded with LSDM_STREAMS=1 for the same reason" % os.environ.get("LSDM_STREAMS", "2"),
                      "algorithmic_gflop_per_launch": dom["gflop"],
                      "peak_note": {"f32": "dense f32-input MFMA (v_mfma_f32_32x32x2_f32)",
                                    "bf16x3": "dense bf16 MFMA; 3 MFMAs per algorithmic product -> attainable frac 0.333",

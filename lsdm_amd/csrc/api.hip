@@ -153,7 +153,16 @@ struct lsdm_ctx {
     std::vector<int> prof_id;   // kernel id of the interval starting at event i (-1 = end-of-phase marker)
     std::vector<int> prof_w;    // steps the launch(es) of the interval cover (a dense stage batched over the steps of a group counts as that many)
     // level features of a whole GROUP of steps (group-batched encoder stages of the loop-invariant bf16x3 schedule): allocated on first use
-    struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr; std::vector<void*> allocs; } gws;
+    // (alt_*: a second set of the per-step scratch tensors of the dense chain -- sa3 / sa4's U and V, fp2's pre-multiplied operand, fp2's
+    // output -- for the steps that run on the side stream)
+    struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr;
+                     struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3]; std::vector<void*> allocs; } gws;
+    // side stream of a loop-invariant group: the dense chains of its steps are independent of each other, odd steps run next to even ones
+    int streams = getenv("LSDM_STREAMS") ? atoi(getenv("LSDM_STREAMS")) : 2;         // A/B switch: 1 = everything on the caller's stream
+    static constexpr int kMaxSide = 3;
+    hipStream_t side[kMaxSide] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
+    int nside() const { return streams - 1 < kMaxSide ? streams - 1 : kMaxSide; }
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
@@ -631,14 +640,46 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
     for (int l = 1; l < 4 && ok; ++l) ok = (g.feat[l] = al(nc * kS[l] * kFeatC[l])) != nullptr;
     ok = ok && (g.ybuf[0] = al(nc * 64 * 256)) && (g.ybuf[2] = al(nc * 16 * 256));
     ok = ok && (g.pcd = al(nc * kN * 3)) && (g.o12 = al(nc * 12));
+    if (ok && c->streams > 1) {
+        const size_t n1 = (size_t)B * kO;
+        for (int k = 0; k < c->nside() && ok; ++k) {
+            lsdm_ctx::GroupWs::Alt& a = g.alt[k];
+            ok = (a.U[0] = al(n1 * 256 * 128)) && (a.V[0] = al(n1 * 256 * 128)) && (a.U[1] = al(n1 * 64 * 256)) && (a.V[1] = al(n1 * 64 * 256)) &&
+                 (a.ybuf1 = al(n1 * 256 * 256)) && (a.fpo2 = al(n1 * 1024 * 128));
+            if (ok && !c->side[k])
+                ok = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) == hipSuccess;
+        }
+        if (ok && !c->ev_fork) ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+        if (!ok) fail(c, LSDM_ERR_HIP, "group workspace: side stream");
+    }
     if (ok) g.cap_B = B;
     return ok;
 }
 
 // front half of the group: everything up to fp4 (which also writes fp3's pre-multiplied operand for every step of the group)
-void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds, int B, int steps, hipStream_t st) {
+// Side streams (LSDM_STREAMS = 1 + their number): step j of the group runs on lane j % LSDM_STREAMS, lane 0 being the caller's stream and every other
+// lane a stream of the context with its own scratch set (gws.alt), so that the chains of consecutive steps run side by side -- the
+// persistent one-work-group-per-CU kernels of one chain fill the ramps, tails and barrier phases of the other (two whole calls side by
+// side: 2.16 -> 2.10 ms per chain-step, tools/two_stream_probe.py).  Same kernels on the same data: bit-identical.  Per-stage event
+// timing (lsdm_profile_*) needs the stages in sequence and keeps everything on one stream.
+static int lanes(const lsdm_ctx* c) { return (c->streams > 1 && c->side[0] != nullptr && !c->prof_on) ? 1 + c->nside() : 1; }
+static void stream_fork(lsdm_ctx* c, hipStream_t st) {
+    (void)hipEventRecord(c->ev_fork, st);
+    for (int k = 0; k < c->nside(); ++k) (void)hipStreamWaitEvent(c->side[k], c->ev_fork, 0);
+}
+static void stream_join(lsdm_ctx* c, hipStream_t st) {
+    for (int k = 0; k < c->nside(); ++k) {
+        (void)hipEventRecord(c->ev_join[k], c->side[k]);
+        (void)hipStreamWaitEvent(st, c->ev_join[k], 0);
+    }
+}
+
+void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds, int B, int steps, hipStream_t st0) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = B * kO, nc = nc1 * steps;
+    const int nl = lanes(c);
+    const bool two = nl > 1;
+    hipStream_t st = st0;
     prof_mark(c, K_REMAP, st, steps);
     launch_l1_remap(nc, c->inv_F1, 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], clouds, nullptr, f.nn_idx[3], f.nn_w[3], st, nc1);
     prof_mark(c, K_SA1 + 1, st, steps);
@@ -648,21 +689,30 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     // more than the cache residency gains)
     constexpr int PS = 1;
     const int ncp = nc1;
+    if (two) stream_fork(c, st0);
     for (int j = 0; j < steps; ++j) {
         const FrontSet fj = c->fset(j, B);
+        const int ln = j % nl;                 // lane of the step
+        st = ln ? c->side[ln - 1] : st0;
+        float* const U0 = ln ? g.alt[ln - 1].U[0] : c->sa_U[0];
+        float* const V0 = ln ? g.alt[ln - 1].V[0] : c->sa_V[0];
+        float* const U1 = ln ? g.alt[ln - 1].U[1] : c->sa_U[1];
+        float* const V1 = ln ? g.alt[ln - 1].V[1] : c->sa_V[1];
         for (int h = 0; h < PS; ++h) {
             const size_t o = (size_t)h * ncp;      // first cloud of the slice
             float* const f1 = g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128;
             float* const f2 = g.feat[2] + ((size_t)j * nc1 + o) * 64 * 256;
             float* const f3 = g.feat[3] + ((size_t)j * nc1 + o) * 16 * 512;
             prof_mark(c, K_SA1 + 2, st);
-            launch_lin_u(2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
-            launch_sa_u(2, ncp, c->sa_U[0], c->sa_V[0], fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+            launch_lin_u(2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], U0, V0, st);
+            launch_sa_u(2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
             prof_mark(c, K_SA1 + 3, st);
-            launch_lin_u(3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-            launch_sa_u(3, ncp, c->sa_U[1], c->sa_V[1], fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+            launch_lin_u(3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], U1, V1, st);
+            launch_sa_u(3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
         }
     }
+    st = st0;
+    if (two) stream_join(c, st0);
     prof_mark(c, K_FP4, st, steps);
     // (fp4 / fp3 store only the next finer stage's pre-multiplied operand inside a multi-step call: keep_out = false, `out` unused)
     launch_fp_pre(4, nc, g.feat[2], nullptr, g.feat[3], c->fp_y[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], nullptr, false,
@@ -671,21 +721,24 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
 }
 
 // back half, one step: fp3 (its pre-multiplied operand came from the group's fp4 launch), fp2, fp1 + head -> c->pcd
-void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float* pcd_out, hipStream_t st) {
+// (lane > 0: the step runs on side stream lane - 1 with that lane's scratch set)
+void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float* pcd_out, hipStream_t st, int lane) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = B * kO;
+    float* const ybuf1 = lane ? g.alt[lane - 1].ybuf1 : c->fp_ybuf[1];
+    float* const fpo2 = lane ? g.alt[lane - 1].fpo2 : c->fpo2;
     constexpr int PS = 1;
     const int ncp = nc1;
     for (int h = 0; h < PS; ++h) {
         const size_t o = (size_t)h * ncp;
         prof_mark(c, K_FP3, st);
         launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
-                      fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], c->fp_ybuf[1], false, st);
+                      fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], ybuf1, false, st);
         prof_mark(c, K_FP2, st);
-        launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], c->fp_ybuf[1], fj.nn_idx[2] + o * 1024 * 3,
-                      fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], c->fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
+        launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], ybuf1, fj.nn_idx[2] + o * 1024 * 3,
+                      fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
         prof_mark(c, K_FP1, st);
-        launch_fp_s(ncp, c->fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st);
+        launch_fp_s(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st);
     }
 }
 
@@ -829,6 +882,9 @@ int lsdm_destroy(lsdm_ctx* c) {
         for (void* p : c->ws_allocs) (void)hipFree(p);
         for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
         for (void* p : c->gws.allocs) (void)hipFree(p);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        for (hipEvent_t e : c->ev_join) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t q : c->side) if (q) (void)hipStreamDestroy(q);
     }
     delete c;
     return LSDM_OK;
@@ -1334,7 +1390,13 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             // launch ramp, the weight-panel prologue and the tail are paid once per group instead of once per step.
             const lsdm_ctx::GroupWs& gw = c->gws;
             const size_t pstep = (size_t)nc * kN * 3, ostep = (size_t)nc * 12;
-            for (int j = 0; j < g; ++j) run_encoder_group_step(c, c->fset_steps(j, B), B, j, gw.pcd + (size_t)j * pstep, st);
+            const int nl = lanes(c);
+            if (nl > 1) stream_fork(c, st);
+            for (int j = 0; j < g; ++j) {
+                const int ln = j % nl;
+                run_encoder_group_step(c, c->fset_steps(j, B), B, j, gw.pcd + (size_t)j * pstep, ln ? c->side[ln - 1] : st, ln);
+            }
+            if (nl > 1) stream_join(c, st);
             prof_mark(c, K_SATTN, st, g);
             launch_scene_attn(c->sattn, gw.pcd, c->fs0.w, c->fs0.tr, B, gw.o12, st, g);
             prof_mark(c, K_DENOISE, st, g);
@@ -1352,7 +1414,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             if (grp) {
                 // (LSDM_BATCH_DEN=0) the rest of the step's encoder, scene attention and denoiser, one step at a time
                 const bool skip_guiding = c->den_reg && k != K - 1;
-                run_encoder_group_step(c, f, B, j, c->pcd, st);
+                run_encoder_group_step(c, f, B, j, c->pcd, st, 0);
                 prof_mark(c, K_SATTN, st);
                 launch_scene_attn(c->sattn, c->pcd, f.w, f.tr, B, c->o12, st);
                 run_denoise(c, f, mode, eta, B, cur, f.tbuf, mask, noise + (size_t)k * xn, out_x0, skip_guiding ? nullptr : out_guiding, nxt, st, 1, c->shared_t());

@@ -5,6 +5,7 @@ P=${1:-bf16x3}; TAG=${2:-$P}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
+export LSDM_STREAMS=1    # counters per kernel: no overlapping kernels (see round_profile.sh)
 CMD="python $R/bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-others --no-parity --no-hoisted"
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
