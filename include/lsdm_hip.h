@@ -11,7 +11,10 @@
  *     Nothing throws across the boundary.
  *   - the caller allocates every input/output (raw device pointers, e.g. tensor.data_ptr()); the library owns only
  *     its parameter arena and a workspace inside the context (sized by lsdm_reserve).
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous.  Everything a call does is ordered
+ *     on `stream`: lsdm_sample_steps_invariant also runs the dense encoder chains of alternate steps on a side stream of the context
+ *     (forked from `stream` by an event and joined back before the call's last launches; LSDM_STREAMS=1 keeps one stream) -- work the
+ *     caller enqueues on `stream` after the call sees all of its results.
  *   - one context per (process, device); a context is not thread-safe; different contexts are independent.
  *   - all floating-point tensors are fp32, dense, row-major; timesteps / FPS starts are int64 (torch.long),
  *     internal index outputs are int32.
