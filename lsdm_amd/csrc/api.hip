@@ -87,7 +87,10 @@ struct lsdm_ctx {
     // Everything a step computes WITHOUT x (conditioning vectors + PointNet++ geometry) lives in a FrontSet.  There are
     // kGroup of them, carved out of contiguous allocations [kGroup][...], so that lsdm_sample_steps can evaluate the
     // geometry of up to kGroup consecutive steps in ONE launch per stage (the fronts do not depend on x or on each other).
-    static constexpr int kGroup = 8;
+#ifndef LSDM_KGROUP
+#define LSDM_KGROUP 32
+#endif
+    static constexpr int kGroup = LSDM_KGROUP;
     // loop-invariant level-1 work of lsdm_sample_steps_invariant: ball query + sa1 feature of every point as a centroid, the
     // 8 nearest points of every point (geometry.hip::l1_remap_kernel turns them into the step's level-1 order)
     int* inv_ball = nullptr;
@@ -164,6 +167,7 @@ struct lsdm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
     int nside() const { return streams - 1 < kMaxSide ? streams - 1 : kMaxSide; }
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
+    int fp_slices = getenv("LSDM_FP_SLICES") ? atoi(getenv("LSDM_FP_SLICES")) : 1;   // experiment: fp3 / fp2 / fp1 of a step in cloud slices
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
 };
@@ -727,10 +731,14 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
     const int nc1 = B * kO;
     float* const ybuf1 = lane ? g.alt[lane - 1].ybuf1 : c->fp_ybuf[1];
     float* const fpo2 = lane ? g.alt[lane - 1].fpo2 : c->fpo2;
-    constexpr int PS = 1;
-    const int ncp = nc1;
-    for (int h = 0; h < PS; ++h) {
-        const size_t o = (size_t)h * ncp;
+    // cloud slices (c->fp_slices > 1): fp2's output of a slice stays in the Infinity Cache until fp1 has read it; slices are multiples of 64
+    // clouds where possible, so that fp1's persistent work-groups get whole rounds
+    const int PS = c->fp_slices > 1 && nc1 >= 128 ? c->fp_slices : 1;
+    int per = (nc1 + PS - 1) / PS;
+    if (per % 64) per += 64 - per % 64;
+    for (int o0 = 0; o0 < nc1; o0 += per) {
+        const size_t o = (size_t)o0;
+        const int ncp = nc1 - o0 < per ? nc1 - o0 : per;
         prof_mark(c, K_FP3, st);
         launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
                       fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], ybuf1, false, st);
@@ -1352,7 +1360,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
     int gmax = 65535 / nc < lsdm_ctx::kGroup ? (65535 / nc < 1 ? 1 : 65535 / nc) : lsdm_ctx::kGroup;
     // FPS runs one wave per cloud at 16 waves per CU (register-bound): a group whose clouds fit the chip in ONE round of waves
     // avoids a second, nearly empty round (B = 64: 7 steps = 4032 clouds on 4096 slots rather than 8 = 4608)
-    if (c->fps_slots / nc >= 4 && c->fps_slots / nc < gmax) gmax = c->fps_slots / nc;
+    if (c->fps_slots / nc >= 4 && c->fps_slots / nc < gmax) gmax = gmax / (c->fps_slots / nc) * (c->fps_slots / nc);
     if (c->group_cap > 0 && gmax > c->group_cap) gmax = c->group_cap;
     if (inv) {
         // once per call: everything of encoder level 1 that does not depend on the FPS order (geometry.hip::l1_remap_kernel)

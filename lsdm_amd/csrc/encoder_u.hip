@@ -646,12 +646,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // re-read of `out` (which is then stored only when keep_out: the parity taps of the stage entry points).
 // TM_ x NW_: 64 rows x 4 waves, two work-groups per CU; or 128 rows x 8 waves, one per CU (half the weight stream per row).
 template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4>
-__global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
+__global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                         const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
                                                         float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out, int p1_mod) {
     constexpr int TM = TM_, NW = NW_, NP = 2, NT = NW * 64;
-    static_assert(NT == 4 * TM, "four threads per fine point in the interpolation phase");
+    constexpr int TPP = NT / TM;                               // threads per fine point in the interpolation phase
+    static_assert(TPP == 4 || TPP == 8, "four or eight threads per fine point in the interpolation phase");
     // fp32 tile row (floats): 68 quads, and the quad index of an access is XORed with (row / 4) & 3 -- the 16-lane phases of both the
     // interpolation stores (rows r .. r+3 x four consecutive quads) and the accumulator loads (16 consecutive rows x one quad) then
     // cover 16 distinct bank quads (with the plain C1 + 4 rows the stores were 4-way conflicted: 26 % of the LDS cycles)
@@ -687,28 +688,36 @@ __global__ __launch_bounds__(NW_ * 64, NW_ == 4 ? 2 : 1) void fp_pre_kernel(cons
     }
     // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
     {
-        const int row = tid >> 2, sub = tid & 3;
+        const int row = tid / TPP, sub = tid % TPP;
         const size_t o = ((size_t)c * N + n0 + row) * 3;
         const int dbg = keep_out >> 1;                       // timing experiments (LSDM_DBG_FP2): 1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs
         const float* r0 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 0]) * C1;
         const float* r1 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 1]) * C1;
         const float* r2 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 2]) * C1;
         const float w0 = nn_w[o + 0], w1 = nn_w[o + 1], w2 = nn_w[o + 2];
-        constexpr int PIECES = C1 / 16;                      // per thread
+        constexpr int PIECES = C1 / (4 * TPP);               // per thread
+        // piece k of thread `sub` of a row: consecutive pieces of a thread are ADJACENT 16-byte quads in pairs, so that the TPP threads of
+        // a row read one whole 128-byte line per pair of requests (with piece k at quad sub + TPP k every line was requested in two
+        // separate iterations, far enough apart to be fetched from L2 twice)
+#ifdef LSDM_FP_CH_OLD
+#define FP_CH(sub, k) (4 * ((sub) + TPP * (k)))
+#else
+#define FP_CH(sub, k) (4 * (2 * (sub) + ((k) & 1) + 2 * TPP * ((k) >> 1)))
+#endif
         // GB pieces x 3 rows in flight per batch: the phase is a chain of L2 round trips, so fewer, larger batches (registers
         // permitting: 12 GB VGPRs) shorten it
-        constexpr int GB = PIECES >= 8 ? 8 : 4;
+        constexpr int GB = (PIECES >= 8 && TPP == 4) ? 8 : 4;
 #pragma unroll 1
         for (int k0 = 0; k0 < PIECES; k0 += GB) {
             f32x4 a[GB], b[GB], d[GB];
 #pragma unroll
             for (int k = 0; k < GB; ++k) {
-                const int ch = 4 * (sub + 4 * (k0 + k));
+                const int ch = FP_CH(sub, k0 + k);
                 a[k] = load4f(r0 + ch); b[k] = load4f(r1 + ch); d[k] = load4f(r2 + ch);
             }
 #pragma unroll
             for (int k = 0; k < GB; ++k) {
-                const int ch = 4 * (sub + 4 * (k0 + k));
+                const int ch = FP_CH(sub, k0 + k);
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(a[k][j], w0), __fmul_rn(b[k][j], w1)), __fmul_rn(d[k][j], w2));
@@ -830,6 +839,15 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
 
 // y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):
 // fuse fp2's Y = out x wb_next^T into this launch; `out` itself is then stored only when keep_out.
+#ifndef LSDM_FP2_NW
+#define LSDM_FP2_NW 4
+#endif
+#ifndef LSDM_FP3_NW
+#define LSDM_FP3_NW 4
+#endif
+#ifndef LSDM_FP4_NW
+#define LSDM_FP4_NW 4
+#endif
 void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
                    bool keep_out, hipStream_t st, int p1_mod) {
@@ -838,7 +856,7 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
     if (which == 4) {
         // fp4: 64 fine <- 16 coarse points per cloud, D1 = 256, the coarse features are 512 wide
         hipLaunchKernelGGL((lin_u_kernel<512, 256, false>), dim3((nc * 16 + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, nc * 16, wb, nullptr, ybuf, nullptr);
-        hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16, l1a, l2,
+        hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true, 64, LSDM_FP4_NW>), dim3(64 / 64 * nc), dim3(LSDM_FP4_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16, l1a, l2,
                            out, wb_next, ynext, keep_out ? 1 : 0, p1_mod);
         return;
     }
@@ -849,13 +867,13 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
 #else
         constexpr int dbg = 0;
 #endif
-        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
+        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, LSDM_FP2_NW>), dim3(1024 / 64 * nc), dim3(LSDM_FP2_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
                            none, nullptr, 1 | (dbg << 1), p1_mod);
     }
     else if (ynext) {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
         // each other's gather and barrier phases)
-        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
+        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 64, LSDM_FP3_NW>), dim3(256 / 64 * nc), dim3(LSDM_FP3_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
                            out, wb_next, ynext, keep_out ? 1 : 0, p1_mod);
     }
     else
