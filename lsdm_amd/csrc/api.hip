@@ -167,7 +167,6 @@ struct lsdm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
     int nside() const { return streams - 1 < kMaxSide ? streams - 1 : kMaxSide; }
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
-    int fp_slices = getenv("LSDM_FP_SLICES") ? atoi(getenv("LSDM_FP_SLICES")) : 1;   // experiment: fp3 / fp2 / fp1 of a step in cloud slices
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
 };
@@ -731,14 +730,11 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
     const int nc1 = B * kO;
     float* const ybuf1 = lane ? g.alt[lane - 1].ybuf1 : c->fp_ybuf[1];
     float* const fpo2 = lane ? g.alt[lane - 1].fpo2 : c->fpo2;
-    // cloud slices (c->fp_slices > 1): fp2's output of a slice stays in the Infinity Cache until fp1 has read it; slices are multiples of 64
-    // clouds where possible, so that fp1's persistent work-groups get whole rounds
-    const int PS = c->fp_slices > 1 && nc1 >= 128 ? c->fp_slices : 1;
-    int per = (nc1 + PS - 1) / PS;
-    if (per % 64) per += 64 - per % 64;
-    for (int o0 = 0; o0 < nc1; o0 += per) {
-        const size_t o = (size_t)o0;
-        const int ncp = nc1 - o0 < per ? nc1 - o0 : per;
+    // (fp3 / fp2 / fp1 in two or three cloud slices, so that fp2's 302 MB output stays in the Infinity Cache until fp1 has read it, were
+    // measured: fp2 329 us either way, fp3 164 -> 186 -- not kept)
+    {
+        const size_t o = 0;
+        const int ncp = nc1;
         prof_mark(c, K_FP3, st);
         launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
                       fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], ybuf1, false, st);
