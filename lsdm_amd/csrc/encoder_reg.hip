@@ -378,7 +378,11 @@ __device__ __forceinline__ f32x16 xfake_mfma(const bf16x8& a, const bf16x8& b, f
 // the gather latency of every round).  conv2's padded block stays resident.  Weight traffic per point: 1 KB instead of 5 KB.
 // (Round 3: requesting the first half of the NEXT round's gather -- 24 x 16 bytes per lane -- in front of conv2 and the second half
 // next to the first half's interpolation arithmetic was measured slower, 349 vs 290 us: the 96 staging registers do not fit next
-// to the two operand sets at two waves per SIMD and part of them goes through scratch.)
+// to the two operand sets at two waves per SIMD and part of them goes through scratch.  The two half-work-groups OUT OF PHASE -- waves
+// 0-3 gathering while waves 4-7 run the layers and vice versa, so that each SIMD's matrix pipe always has exactly one wave feeding it and
+// the other wave's loads and interpolation arithmetic issue in its gaps; panels streamed once per phase -- was measured slower as well,
+// 294 vs 271 us, 318 with the round's 48 row requests issued at once: a SIMD's pipe is fed better by two waves that both issue MFMAs and
+// drift apart inside a layer than by one wave with dependent accumulator chains and block-placed epilogues.)
 // blob: four layers [nb][s][plane][lane][8] (layer 1 in channel order, later layers in accumulator order) + conv2 zero-padded
 // to 32 channels; biases [4 x 128 | 32].
 template <int NW, int NP, int PH = 1>
