@@ -386,14 +386,15 @@ __device__ __forceinline__ f32x16 xfake_mfma(const bf16x8& a, const bf16x8& b, f
 // blob: four layers [nb][s][plane][lane][8] (layer 1 in channel order, later layers in accumulator order) + conv2 zero-padded
 // to 32 channels; biases [4 x 128 | 32].
 template <int NW, int NP, int PH = 1>
-__global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx,
+__global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, long long total_points,
                                                         const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
                                                         float* __restrict__ out, int dbg) {
     constexpr int C = 128, NT = NW * 64, KS = C / 16, NB = C / 32, F = KS * NP;
     constexpr int NL = 4, FL = NB * F;                       // fragments (1 KiB) per layer
     constexpr int FPN = FL / PH, NBP = NB / PH;              // PH panels per layer: fragments / channel blocks per panel
-    static_assert(FPN % NW == 0 && NB % PH == 0 && (NL * PH) % 2 == 0, "panel split");
+    static_assert(NB % PH == 0 && (NL * PH) % 2 == 0, "panel split");
+    constexpr int GK = NW > 8 ? 2 : 4;                       // k-steps per batch of gather requests (staging registers)
     __shared__ __attribute__((aligned(16))) __bf16 wl[2][FPN * 512];
     // conv2's padded block: resident in LDS, or (PH > 1: two work-groups share a CU's LDS) read from global memory through the L1
     __shared__ __attribute__((aligned(16))) __bf16 w5[PH == 1 ? F * 512 : 8];
@@ -414,9 +415,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
     auto fetch = [&](int q) {
         const __bf16* src = opaque_ptr(blob_w + (size_t)q * FPN * 512);   // (round-invariant: keep the copy inside the loop)
 #pragma unroll
-        for (int i = 0; i < FPN / NW; ++i) {
+        for (int i = 0; i < (FPN + NW - 1) / NW; ++i) {
             const int fr = wave + i * NW;
-            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
+            if (FPN % NW == 0 || fr < FPN)
+                lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
         }
     };
     fetch(0);
@@ -447,25 +449,25 @@ __global__ __launch_bounds__(NW * 64, 2) void fp_s_kernel(const float* __restric
         bf16x8 yh[KS], yl[KS], zh[KS], zl[KS];
         // ---- interpolated operand, k-step s = channels 16 s + 8 h .. + 7 of this lane's point (four k-steps per batch of loads)
 #pragma unroll
-        for (int s0 = 0; s0 < KS; s0 += 4) {
-            f32x4 a[4][2], b[4][2], d[4][2];
+        for (int s0 = 0; s0 < KS; s0 += GK) {
+            f32x4 a[GK][2], b[GK][2], d[GK][2];
             // (row-major request order: the four 16-byte pieces a lane pair takes from one 128-byte line are consecutive
             // instructions, so the line is still in the L1 when its last piece is asked for)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < GK; ++s)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) a[s][q] = load4f(r0 + 16 * (s0 + s) + 4 * q);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < GK; ++s)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) b[s][q] = load4f(r1 + 16 * (s0 + s) + 4 * q);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < GK; ++s)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) d[s][q] = load4f(r2 + 16 * (s0 + s) + 4 * q);
-            if (s0 + 4 >= KS && rd + rstep < rend) request(rd + rstep);
+            if (s0 + GK >= KS && rd + rstep < rend) request(rd + rstep);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < GK; ++s) {
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -563,6 +565,8 @@ void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* n
     constexpr int dbg = 0;
 #endif
     const long long tot = (long long)nc * 1024;
+    // (12 waves -- three per SIMD, as sa3 runs -- do not fit: two 128-channel operand sets + accumulators + fragments need ~172 VGPRs against
+    // the 168 of that occupancy and the build spills 95 of them)
     hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
 }
 
