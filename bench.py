@@ -226,8 +226,28 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    log("timing %d steps (%s, %s)" % (K, a.precision, a.mode))
+    # Per-stage HIP events (lsdm_profile_*: one event between consecutive stages, recorded on the launch stream) of the SAME call --
+    # same inputs, same RNG draws, from the same x -- in a pass of its own between the warm-up and the timed region, on every rank:
+    # per-kernel durations need the kernels one at a time, so under instrumentation the library keeps every stage on the caller's
+    # stream (its default runs the dense chains of alternate steps of a group on a side stream, where two kernels share the chip and
+    # a per-kernel duration is not defined), and ~25 event records per step are not part of the product's work.  The roofline leg
+    # comes from this pass; its wall time is reported beside `value`.  (It runs BEFORE the timed region, not after: a 5-step warm-up
+    # is 11 ms of work and leaves the chip's clocks below their steady state -- tools/first_call_probe.py: first 20-step call after
+    # it 2.22 ms/step, after 20 warm steps 2.16, every later repeat 2.15.)
     x_start = r.x.clone()
+    xi = x_start.clone()
+    torch.cuda.synchronize()
+    r.ctx.profile_begin()
+    t1 = time.perf_counter()
+    r.run(T - 1 - W, W, K, x=xi, invariant=inv)
+    torch.cuda.synchronize()
+    dt_instr = time.perf_counter() - t1
+    prof = r.ctx.profile_end()
+    x_instr = xi
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    log("timing %d steps (%s, %s)" % (K, a.precision, a.mode))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
     r.run(T - 1 - W, W, K, invariant=inv)
@@ -282,24 +302,11 @@ def main():
                            "evaluated once per call with pinned FPS starts, included in the timed call; equals the reference only with "
                            "its per-step FPS re-draw pinned (tests: g6_hoisted golden)"}
 
-    # Per-stage HIP events (lsdm_profile_*: one event between consecutive stages, recorded on the launch stream) of the SAME call --
-    # same inputs, same RNG draws, from the same x -- in a pass of its own right after the timed region: per-kernel durations need the
-    # kernels one at a time, so under instrumentation the library keeps every stage on the caller's stream (its default runs the dense
-    # chains of alternate steps of a group on a side stream, where two kernels share the chip and a per-kernel duration is not
-    # defined), and ~25 event records per step are not part of the product's work.  The roofline leg below comes from this pass; its
-    # wall time is reported beside `value`.
-    xi = x_start.clone()
-    torch.cuda.synchronize()
-    r.ctx.profile_begin()
-    t1 = time.perf_counter()
-    r.run(T - 1 - W, W, K, x=xi, invariant=inv)
-    torch.cuda.synchronize()
-    dt_instr = time.perf_counter() - t1
-    prof = r.ctx.profile_end()
     instrumented = {"ms_per_step": dt_instr / K * 1e3, "value": K / dt_instr, "steps": K,
-                    "final_sample_bit_identical_to_timed_region": bool(torch.equal(xi, x_final)),
-                    "note": "the timed call repeated with lsdm_profile_begin: per-stage HIP events, every stage on one stream (the source of `roofline`)"}
-    del xi
+                    "final_sample_bit_identical_to_timed_region": bool(torch.equal(x_instr, x_final)),
+                    "order": "warm-up (%d steps) -> this pass -> barrier + synchronize -> timed region" % W,
+                    "note": "the timed call with lsdm_profile_begin: per-stage HIP events, every stage on one stream (the source of `roofline`)"}
+    del x_instr
 
     # The same K steps again: five more times through the headline entry point (run-to-run spread), once through the OTHER entry
     # point; all final samples must be bit-identical (the invariant mode only moves FPS-order-independent work out of the loop).

@@ -485,6 +485,7 @@ T* ws_alloc(lsdm_ctx* c, const char* name, size_t count) {
     void* d = nullptr;
     if (hipMalloc(&d, count * sizeof(T)) != hipSuccess) { fail(c, LSDM_ERR_HIP, "hipMalloc workspace %s (%zu bytes)", name, count * sizeof(T)); return nullptr; }
     c->ws_allocs.push_back(d);
+    (void)hipMemset(d, 0, count * sizeof(T));        // (set-up time: every page touched once)
     c->ws_named[name] = {d, (int64_t)count};
     return static_cast<T*>(d);
 }
@@ -637,6 +638,7 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
         void* p = nullptr;
         if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) { fail(c, LSDM_ERR_HIP, "group workspace: hipMalloc of %zu bytes failed", n * sizeof(float)); return nullptr; }
         g.allocs.push_back(p);
+        (void)hipMemset(p, 0, n * sizeof(float));      // touch every page once, at set-up: a group larger than any before it must not meet cold pages
         return static_cast<float*>(p);
     };
     bool ok = true;
