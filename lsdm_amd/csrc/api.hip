@@ -167,6 +167,7 @@ struct lsdm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
     int nside() const { return streams - 1 < kMaxSide ? streams - 1 : kMaxSide; }
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
+    int inv_side = getenv("LSDM_INV_SIDE") ? atoi(getenv("LSDM_INV_SIDE")) : 1;      // A/B switch: 0 = the per-call level-1 work on the caller's stream
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
 };
@@ -1360,31 +1361,48 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
     // avoids a second, nearly empty round (B = 64: 7 steps = 4032 clouds on 4096 slots rather than 8 = 4608)
     if (c->fps_slots / nc >= 4 && c->fps_slots / nc < gmax) gmax = gmax / (c->fps_slots / nc) * (c->fps_slots / nc);
     if (c->group_cap > 0 && gmax > c->group_cap) gmax = c->group_cap;
+    bool inv_pending = false;
     if (inv) {
-        // once per call: everything of encoder level 1 that does not depend on the FPS order (geometry.hip::l1_remap_kernel)
+        // once per call: everything of encoder level 1 that does not depend on the FPS order (geometry.hip::l1_remap_kernel).  With a side
+        // stream it runs THERE, next to the conditioning and the geometry of the first group on the caller's stream (neither reads the
+        // other's results); the caller's stream waits for it before the first stage that does (inv_pending).
+        if (K > 1 && group_batched(c) && !ensure_group_ws(c, B)) return LSDM_ERR_HIP;
+        hipStream_t si = st;
+        if (K > 1 && group_batched(c) && lanes(c) > 1 && c->inv_side) {
+            stream_fork(c, st);
+            si = c->side[0];
+        }
         const float r2 = (float)(kRadius[0] * kRadius[0]);
-        prof_mark(c, K_BALL1, st);
-        launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2, c->inv_ball, 0, st);
-        prof_mark(c, K_SA1, st);
+        prof_mark(c, K_BALL1, si);
+        launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2, c->inv_ball, 0, si);
+        prof_mark(c, K_SA1, si);
         if (c->prec == LSDM_PREC_F32) {
-            launch_sa(0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), st);
+            launch_sa(0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), si);
         } else {
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
-            if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, st);
-            else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, st);
+            if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
+            else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, si);
         }
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
-            launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
-        prof_mark(c, K_NN1, st);
-        launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, st);
-        prof_mark(c, -1, st);
+            launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
+        prof_mark(c, K_NN1, si);
+        launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, si);
+        prof_mark(c, -1, si);
+        if (si != st) {
+            (void)hipEventRecord(c->ev_join[0], si);
+            inv_pending = true;
+        }
     }
+    auto need_invariants = [&]() {
+        if (inv_pending) { (void)hipStreamWaitEvent(st, c->ev_join[0], 0); inv_pending = false; }
+    };
     for (int k0 = 0; k0 < K; k0 += gmax) {
         const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
         run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st, /*shared=*/true);
         run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
         const bool grp = inv && g > 1 && group_batched(c);
+        need_invariants();
         if (grp) {
             if (!ensure_group_ws(c, B)) return LSDM_ERR_HIP;
             run_encoder_group_front(c, c->fs0, given_objs, B, g, st);
