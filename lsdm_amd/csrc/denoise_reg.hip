@@ -315,7 +315,8 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             const bool last = step == nsteps - 1;
             // ---- guidance g (fp32): depends on the scene conditioning only.  pcd_step / o12_step != 0: the launch covers the steps of a
             // loop-invariant group, every step with its own encoder output (step-major) -- g is formed at the top of each step; 0: one
-            // conditioning for all steps of the launch (single step, hoisted groups)
+            // conditioning for all steps of the launch (single step, hoisted groups).  (The group's guidance from a launch of its own, read
+            // here as one coalesced row per step, was measured: 59 -> 57 us per step -- not kept.)
             if (step == 0 || pcd_step != 0) {
                 const float* pcd_s = pcd_b + (size_t)step * pcd_step;
                 const float* o12_s = o12 + (size_t)step * o12_step;
