@@ -41,7 +41,7 @@ constexpr float kBnEps = 1e-5f, kGnEps = 1e-5f;
 // C(m, n) (+)= sum_k A(m, k) B(k, n) [+ bias(n)], every operand through explicit element strides (a transposed or column-sliced view
 // costs nothing), batched over blockIdx.z / ksplit, the reduction optionally split over `ksplit` work-groups that add their partial
 // tiles atomically (weight gradients: tiny M x N, hundreds of thousands of rows to reduce over).  64 x 64 x 16 tiles through LDS,
-// 4 x 4 outputs per thread, fp32 FMAs.
+// one 32 x 32 quadrant per wave on the exact-fp32 matrix instruction, the next k-block requested while this one is multiplied.
 struct Gemm {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K;
@@ -52,55 +52,68 @@ struct Gemm {
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
+    // k-major tiles: the MFMA operands of k-pair (2 kk, 2 kk + 1) are rows 2 kk + (lane >> 5) at column (lane & 31) of the wave's quadrant
     __shared__ float As[16][64 + 4], Bs[16][64 + 4];
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int batch = blockIdx.z / g.ksplit, ks = blockIdx.z - batch * g.ksplit;
     const float* A = g.A + (long long)batch * g.bA;
     const float* B = g.B + (long long)batch * g.bB;
     float* C = g.C + (long long)batch * g.bC;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;      // (row tiles on x: up to millions of rows)
     const int k_lo = ks * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
-    float acc[4][4] = {};
     const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m, k;
-            if (a_kfast) { k = t & 15; m = (t >> 4) + 16 * i; } else { m = t & 63; k = (t >> 6) + 4 * i; }
-            const int gm = m0 + m, gk = k0 + k;
-            As[k][m] = (gm < g.M && gk < k_hi) ? A[gm * g.sam + gk * g.sak] : 0.0f;
-            int n, kb;
-            if (b_nfast) { n = t & 63; kb = (t >> 6) + 4 * i; } else { kb = t & 15; n = (t >> 4) + 16 * i; }
-            const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < g.N && gkb < k_hi) ? B[gkb * g.sbk + gn * g.sbn] : 0.0f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[k][tx * 4]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
+    // the four A and four B elements this thread moves per k-block: tile coordinates and global addresses (advanced by 16 k per block)
+    int am[4], ak[4], bn[4], bk[4];
+    const float* pa[4];
+    const float* pb[4];
+    bool va[4], vb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int gm = m0 + ty * 4 + i;
-        if (gm >= g.M) continue;
+        if (a_kfast) { ak[i] = t & 15; am[i] = (t >> 4) + 16 * i; } else { am[i] = t & 63; ak[i] = (t >> 6) + 4 * i; }
+        if (b_nfast) { bn[i] = t & 63; bk[i] = (t >> 6) + 4 * i; } else { bk[i] = t & 15; bn[i] = (t >> 4) + 16 * i; }
+        va[i] = m0 + am[i] < g.M;
+        vb[i] = n0 + bn[i] < g.N;
+        pa[i] = A + (long long)(m0 + am[i]) * g.sam + (long long)(k_lo + ak[i]) * g.sak;
+        pb[i] = B + (long long)(k_lo + bk[i]) * g.sbk + (long long)(n0 + bn[i]) * g.sbn;
+    }
+    const long long da = 16 * g.sak, db = 16 * g.sbk;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gn = n0 + tx * 4 + j;
-            if (gn >= g.N) continue;
-            float v = acc[i][j];
-            if (g.bias && ks == 0) v += g.bias[gn];
-            float* dst = C + gm * g.scm + gn * g.scn;
-            if (g.mode == 0) *dst = v;
-            else if (g.mode == 1) *dst += v;
-            else atomicAdd(dst, v);
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (va[i] && k0 + ak[i] < k_hi) ? *pa[i] : 0.0f;
+            rb[i] = (vb[i] && k0 + bk[i] < k_hi) ? *pb[i] : 0.0f;
+            pa[i] += da; pb[i] += db;
         }
+    };
+    // exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain over k): wave w owns the 32 x 32 quadrant
+    // (w & 1, w >> 1) of the 64 x 64 tile; the next k-block's elements are in flight while this one is multiplied
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32, p = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
+        __syncthreads();
+        if (k0 + 16 < k_hi) fetch(k0 + 16);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + h][wm + p], Bs[2 * kk + h][wn + p], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int gn = n0 + wn + p;
+    if (gn >= g.N) return;
+    const float bv = (g.bias && ks == 0) ? g.bias[gn] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm + acc_row(r, lane);
+        if (gm >= g.M) continue;
+        const float v = acc[r] + bv;
+        float* dst = C + (long long)gm * g.scm + (long long)gn * g.scn;
+        if (g.mode == 0) *dst = v;
+        else if (g.mode == 1) *dst += v;
+        else atomicAdd(dst, v);
     }
 }
 
