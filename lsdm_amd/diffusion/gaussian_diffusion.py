@@ -296,7 +296,7 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                       denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
                       init_image=None, randomize_class=False, cond_fn_with_grad=False, dump_steps=None,
-                      const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=True):
+                      const_noise=False, *, hoist_conditioning=False, chunk_steps=56, hoist_invariants=True):
         """Reference signature (gaussian_diffusion.py:611-632) + keyword-only extensions: ``hoist_invariants`` (default on: evaluate the
         loop-invariant level-1 encoder work once per library call -- bit-identical results, lsdm_sample_steps_invariant; off = every
         stage recomputed every step, lsdm_sample_steps), ``chunk_steps`` (steps per
@@ -358,7 +358,7 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
                          skip_timesteps=0, init_image=None, randomize_class=False, cond_fn_with_grad=False,
-                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=50, hoist_invariants=True):
+                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=56, hoist_invariants=True):
         """Argument list of the reference's ``ddim_sample_loop`` (gaussian_diffusion.py:957-1000) with the conditioning
         arguments threaded.  ``dump_steps`` behaves as in ``p_sample_loop`` (:661-680); ``const_noise`` is accepted for
         signature compatibility -- the reference's DDIM step has no such argument (``ddim_sample`` :761-775 draws
