@@ -42,6 +42,7 @@ constexpr float kBnEps = 1e-5f, kGnEps = 1e-5f;
 // costs nothing), batched over blockIdx.z / ksplit, the reduction optionally split over `ksplit` work-groups that add their partial
 // tiles atomically (weight gradients: tiny M x N, hundreds of thousands of rows to reduce over).  64 x 64 x 16 tiles through LDS,
 // one 32 x 32 quadrant per wave on the exact-fp32 matrix instruction, the next k-block requested while this one is multiplied.
+constexpr int kStatCopies = 32;
 struct Gemm {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K;
@@ -49,6 +50,11 @@ struct Gemm {
     long long bA, bB, bC;                         // batch strides
     int ksplit, kchunk;                           // reduction split (kchunk = K range of one work-group, multiple of 16)
     int mode;                                     // 0 store, 1 add (read-modify-write, exclusive), 2 atomic add
+    // optional by-products (NULL = none):
+    double* csum; double* csq;                    // += per-column sum / sum of squares of the values stored to C (mode 0: BatchNorm statistics),
+                                                  //    kStatCopies private copies [copy][N] (copy = row tile % kStatCopies: the atomics of a column
+                                                  //    of a million-row layer would otherwise queue on one address)
+    float* asum;                                  // += sum_k A(m, k) per row m of A (the bias gradient next to dW = dZ^T X)
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
@@ -92,28 +98,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float arow = 0.0f;
     if (k_lo < k_hi) fetch(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
         __syncthreads();
         if (k0 + 16 < k_hi) fetch(k0 + 16);
+        if (g.asum && blockIdx.y == 0 && t < 64) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) arow += As[k][t];       // (rows / k beyond the operand are zero-filled)
+        }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + h][wm + p], Bs[2 * kk + h][wn + p], acc, 0, 0, 0);
         __syncthreads();
     }
+    if (g.asum && blockIdx.y == 0 && t < 64 && m0 + t < g.M) atomicAdd(g.asum + m0 + t, arow);
     const int gn = n0 + wn + p;
-    if (gn >= g.N) return;
-    const float bv = (g.bias && ks == 0) ? g.bias[gn] : 0.0f;
+    const bool col_ok = gn < g.N;
+    const float bv = (col_ok && g.bias && ks == 0) ? g.bias[gn] : 0.0f;
+    double cs = 0.0, cq = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gm = m0 + wm + acc_row(r, lane);
-        if (gm >= g.M) continue;
+        if (gm >= g.M || !col_ok) continue;
         const float v = acc[r] + bv;
         float* dst = C + (long long)gm * g.scm + (long long)gn * g.scn;
         if (g.mode == 0) *dst = v;
         else if (g.mode == 1) *dst += v;
         else atomicAdd(dst, v);
+        cs += (double)v; cq += (double)v * (double)v;
+    }
+    if (g.csum) {      // (wave-uniform; both half-waves hold 16 rows of the same 32 columns)
+        cs += __shfl_xor(cs, 32); cq += __shfl_xor(cq, 32);
+        const size_t cp = (size_t)(blockIdx.x % kStatCopies) * g.N;
+        if (h == 0 && col_ok) { atomicAdd(g.csum + cp + gn, cs); atomicAdd(g.csq + cp + gn, cq); }
     }
 }
 
@@ -167,29 +186,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 
 // ---- BatchNorm over the rows of Z (rows, C), fused with ReLU --------------------------------------------------------------------------
-// per-channel sum and sum of squares in double (batch statistics)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ Z, long long rows, int C, double* __restrict__ sum, double* __restrict__ sq) {
-    __shared__ double ps[4][64], pq[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const long long chunk = (rows + gridDim.y - 1) / gridDim.y, lo = blockIdx.y * chunk, hi = min(rows, lo + chunk);
-    double s = 0.0, s2 = 0.0;
-    if (c < C) for (long long r = lo + q; r < hi; r += 4) { const double v = Z[r * C + c]; s += v; s2 += v * v; }
-    ps[q][threadIdx.x & 63] = s; pq[q][threadIdx.x & 63] = s2;
-    __syncthreads();
-    if (q == 0 && c < C) {
-        const int l = threadIdx.x;
-        atomicAdd(sum + c, ps[0][l] + ps[1][l] + ps[2][l] + ps[3][l]);
-        atomicAdd(sq + c, pq[0][l] + pq[1][l] + pq[2][l] + pq[3][l]);
-    }
-}
+// (batch statistics -- per-channel sum and sum of squares in double -- are a by-product of the GEMM that produces Z: Gemm::csum / csq)
 // mean / invstd of the normalisation; training mode also updates the running statistics (momentum 0.1, unbiased variance)
 __global__ void bn_finish_kernel(const double* sum, const double* sq, long long rows, int C, int training, float* running_mean, float* running_var,
                                  float* mean, float* invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (training) {
-        const double m = sum[c] / (double)rows;
-        double var = sq[c] / (double)rows - m * m;
+        double sm = 0.0, sqq = 0.0;
+        for (int k = 0; k < kStatCopies; ++k) { sm += sum[(size_t)k * C + c]; sqq += sq[(size_t)k * C + c]; }
+        const double m = sm / (double)rows;
+        double var = sqq / (double)rows - m * m;
         if (var < 0.0) var = 0.0;
         mean[c] = (float)m;
         invstd[c] = (float)(1.0 / sqrt(var + (double)kBnEps));
@@ -729,9 +736,10 @@ Par par(lsdm_train* s, const std::string& name, int64_t numel) {
 }
 
 void gemm(lsdm_train* s, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long scm, long long scn,
-          int M, int N, int K, const float* bias, int mode, int batch = 1, long long bA = 0, long long bB = 0, long long bC = 0, int ksplit = 1) {
+          int M, int N, int K, const float* bias, int mode, int batch = 1, long long bA = 0, long long bB = 0, long long bC = 0, int ksplit = 1,
+          double* csum = nullptr, double* csq = nullptr, float* asum = nullptr) {
     if (s->failed || M <= 0 || N <= 0) return;
-    Gemm g{A, B, C, bias, M, N, K, sam, sak, sbk, sbn, scm, scn, bA, bB, bC, ksplit, 0, mode};
+    Gemm g{A, B, C, bias, M, N, K, sam, sak, sbk, sbn, scm, scn, bA, bB, bC, ksplit, 0, mode, csum, csq, asum};
     g.kchunk = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
     g.ksplit = (K + g.kchunk - 1) / g.kchunk;
     if (g.ksplit < 1) g.ksplit = 1;
@@ -739,8 +747,9 @@ void gemm(lsdm_train* s, const float* A, long long sam, long long sak, const flo
 }
 
 // Y = X W^T + b on (rows, K) -> (rows, N) views
-void linear_fwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const Ten& Z) {
-    gemm(s, X.d, X.ld, 1, W.w, 1, X.C, Z.d, Z.ld, 1, (int)X.rows, Z.C, X.C, b.w, 0);
+// (csum / csq: the per-channel sum and sum of squares of Z in double, accumulated by the same launch -- batch statistics)
+void linear_fwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const Ten& Z, double* csum = nullptr, double* csq = nullptr) {
+    gemm(s, X.d, X.ld, 1, W.w, 1, X.C, Z.d, Z.ld, 1, (int)X.rows, Z.C, X.C, b.w, 0, 1, 0, 0, 0, 1, csum, csq);
 }
 // dX += dZ W ; dW += dZ^T X ; db += colsum(dZ)      (dZ dense (rows, N))
 void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const float* dZ, int N, bool need_dx = true) {
@@ -748,10 +757,11 @@ void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const f
     const int rows = (int)X.rows, K = X.C;
     if (need_dx && X.g) gemm(s, dZ, N, 1, W.w, K, 1, X.g, X.ld, 1, rows, K, N, nullptr, 1);
     if (W.g) {
+        // (the bias gradient = row sums of the A operand dZ^T: a by-product of the same launch)
         const int ksplit = rows > 4096 ? (rows + 4095) / 4096 : 1;
-        gemm(s, dZ, 1, N, X.d, X.ld, 1, W.g, K, 1, N, K, rows, nullptr, 2, 1, 0, 0, 0, ksplit);
+        gemm(s, dZ, 1, N, X.d, X.ld, 1, W.g, K, 1, N, K, rows, nullptr, 2, 1, 0, 0, 0, ksplit, nullptr, nullptr, b.g);
     }
-    if (b.g) {
+    if (b.g && !W.g) {
         const int ry = rows > 2048 ? (rows + 2047) / 2048 : 1;
         hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ry), dim3(256), 0, s->st, dZ, (long long)N, (long long)rows, N, b.g);
     }
@@ -789,11 +799,12 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
     float* mean = talloc<float>(s, N);
     float* invstd = talloc<float>(s, N);
     Ten Zt; Zt.d = Z; Zt.rows = rows; Zt.C = N; Zt.ld = N;
-    linear_fwd(s, X, W, b, Zt);
     const int ry = rows > 2048 ? (int)((rows + 2047) / 2048) : 1;
-    double* st2 = talloc<double>(s, 2 * (size_t)N, true);
-    if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3((N + 63) / 64, ry), dim3(256), 0, s->st, Z, rows, N, st2, st2 + N);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, st2, st2 + N, rows, N, training, const_cast<float*>(rm.w), const_cast<float*>(rv.w),
+    double* st2 = talloc<double>(s, 2 * (size_t)N * kStatCopies, true);
+    if (!st2) return Y;
+    double* const stq = st2 + (size_t)N * kStatCopies;
+    linear_fwd(s, X, W, b, Zt, training ? st2 : nullptr, training ? stq : nullptr);      // batch statistics: by-product of the GEMM
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, st2, stq, rows, N, training, const_cast<float*>(rm.w), const_cast<float*>(rv.w),
                        mean, invstd);
     hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblk(rows * N)), dim3(256), 0, s->st, Z, mean, invstd, gam.w, bet.w, Y.d, Y.ld, rows, N, keep);
     s->tape.push_back([=]() {
