@@ -212,38 +212,60 @@ __global__ void bn_finish_kernel(const double* sum, const double* sq, long long 
 __global__ void bn_relu_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ Y, long long ldy, long long rows,
                                    int C, const unsigned char* __restrict__ keep) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C) return;
-    const long long r = i / C; const int c = (int)(i - r * C);
-    float v = (Z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    v = v > 0.0f ? v : 0.0f;
-    if (keep) v = keep[((r >> 10) * C + c) * 1024 + (r & 1023)] ? v * 2.0f : 0.0f;
-    Y[r * ldy + c] = v;
+    // four channels per thread (C and ldy are multiples of 4: conv_bn_relu checks)
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = C >> 2;
+    if (i4 >= rows * q) return;
+    const long long r = i4 / q; const int c = (int)(i4 - r * q) * 4;
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = (z[j] - mu[j]) * is[j] * ga[j] + be[j];
+        v = v > 0.0f ? v : 0.0f;
+        if (keep) v = keep[((r >> 10) * C + c + j) * 1024 + (r & 1023)] ? v * 2.0f : 0.0f;
+        y[j] = v;
+    }
+    *reinterpret_cast<f32x4*>(Y + r * ldy + c) = y;
 }
-// first backward pass: dA = dY [* 2 keep] * (Y > 0)  ->  sum_r dA (d beta) and sum_r dA xhat (d gamma), in double
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, long long ldg, const float* __restrict__ Y, long long ldy,
-                                                            const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            long long rows, int C, const unsigned char* __restrict__ keep, double* __restrict__ dbeta,
-                                                            double* __restrict__ dgamma) {
-    __shared__ double ps[4][64], pq[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    const long long chunk = (rows + gridDim.y - 1) / gridDim.y, lo = blockIdx.y * chunk, hi = min(rows, lo + chunk);
-    double s = 0.0, s2 = 0.0;
-    if (c < C) {
-        const float mu = mean[c], is = invstd[c];
-        for (long long r = lo + q; r < hi; r += 4) {
-            float d = Y[r * ldy + c] > 0.0f ? dY[r * ldg + c] : 0.0f;
-            if (keep) d *= 2.0f;     // (a dropped element has Y = 0 already)
-            s += d;
-            s2 += (double)d * (double)((Z[r * C + c] - mu) * is);
+// first backward pass: dA = dY [* 2 keep] * (Y > 0)  ->  sum_r dA (d beta) and sum_r dA xhat (d gamma), in double.
+// Four channels per thread (16-byte loads of dY, Y and Z: the three tensors are dense (rows, C), C a multiple of 4), 256 / (C / 4) rows per
+// pass of the work-group, the row slots of a channel quad combined through LDS, one atomic per channel and work-group.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ Z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, long long rows, int C,
+                                                            int keep, double* __restrict__ dbeta, double* __restrict__ dgamma) {
+    __shared__ double part[256][8];
+    const int tpr = C >> 2, rpi = 256 / tpr, t = threadIdx.x;
+    const int slot = t / tpr, c4 = (t - slot * tpr) * 4;
+    const long long chunk = (rows + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * chunk, hi = min(rows, lo + chunk);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    if (slot < rpi) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4), is = *reinterpret_cast<const f32x4*>(invstd + c4);
+        const float ks = keep ? 2.0f : 1.0f;       // (a dropped element has Y = 0 already)
+#pragma unroll 2
+        for (long long r = lo + slot; r < hi; r += rpi) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dY + r * C + c4), y = *reinterpret_cast<const f32x4*>(Y + r * C + c4);
+            const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * C + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = y[j] > 0.0f ? g[j] * ks : 0.0f;
+                s[j] += d;
+                q[j] += (double)d * (double)((z[j] - mu[j]) * is[j]);
+            }
         }
     }
-    ps[q][threadIdx.x & 63] = s; pq[q][threadIdx.x & 63] = s2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { part[t][j] = s[j]; part[t][4 + j] = q[j]; }
     __syncthreads();
-    if (q == 0 && c < C) {
-        const int l = threadIdx.x;
-        atomicAdd(dbeta + c, ps[0][l] + ps[1][l] + ps[2][l] + ps[3][l]);
-        atomicAdd(dgamma + c, pq[0][l] + pq[1][l] + pq[2][l] + pq[3][l]);
+    if (t < tpr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < rpi; ++k) v += part[k * tpr + t][j];
+            atomicAdd((j < 4 ? dbeta : dgamma) + c4 + (j & 3), v);
+        }
     }
 }
 // second pass: dZ.  training: gamma invstd (dA - (d beta + xhat d gamma) / rows);  eval: gamma invstd dA
@@ -251,17 +273,26 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, long long ldg,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const double* __restrict__ dbeta, const double* __restrict__ dgamma, long long rows, int C, int training,
                                     const unsigned char* __restrict__ keep, float* __restrict__ dZ) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C) return;
-    const long long r = i / C; const int c = (int)(i - r * C);
-    float d = Y[r * ldy + c] > 0.0f ? dY[r * ldg + c] : 0.0f;
-    if (keep) d *= 2.0f;
-    const float is = invstd[c];
-    if (training) {
-        const float xh = (Z[i] - mean[c]) * is;
-        d -= (float)((dbeta[c] + (double)xh * dgamma[c]) / (double)rows);
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = C >> 2;
+    if (i4 >= rows * q) return;
+    const long long r = i4 / q; const int c = (int)(i4 - r * q) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dY + r * ldg + c), y = *reinterpret_cast<const f32x4*>(Y + r * ldy + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c), ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f}, mu = z;
+    if (training) { z = *reinterpret_cast<const f32x4*>(Z + r * C + c); mu = *reinterpret_cast<const f32x4*>(mean + c); }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float d = y[j] > 0.0f ? g[j] : 0.0f;
+        if (keep) d *= 2.0f;
+        if (training) {
+            const float xh = (z[j] - mu[j]) * is[j];
+            d -= (float)((dbeta[c + j] + (double)xh * dgamma[c + j]) / (double)rows);
+        }
+        o[j] = d * ga[j] * is[j];
     }
-    dZ[i] = d * gamma[c] * is;
+    *reinterpret_cast<f32x4*>(dZ + r * C + c) = o;
 }
 __global__ void add_f64_to_f32_kernel(const double* src, float* dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -794,6 +825,7 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
     const Par rm = par(s, bn + ".running_mean", N), rv = par(s, bn + ".running_var", N);
     Ten Y = make(s, X.rows, N);
     if (s->failed) return Y;
+    if (N % 4 != 0 || N > 1024 || 256 % (N / 4) != 0) { tfail(s, LSDM_ERR_ARG, "training: BatchNorm width %d (a power of two in 32 .. 1024 expected)", N); return Y; }
     const long long rows = X.rows;
     float* Z = talloc<float>(s, (size_t)rows * N);
     float* mean = talloc<float>(s, N);
@@ -806,13 +838,13 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
     linear_fwd(s, X, W, b, Zt, training ? st2 : nullptr, training ? stq : nullptr);      // batch statistics: by-product of the GEMM
     hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, st2, stq, rows, N, training, const_cast<float*>(rm.w), const_cast<float*>(rv.w),
                        mean, invstd);
-    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblk(rows * N)), dim3(256), 0, s->st, Z, mean, invstd, gam.w, bet.w, Y.d, Y.ld, rows, N, keep);
+    hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Z, mean, invstd, gam.w, bet.w, Y.d, Y.ld, rows, N, keep);
     s->tape.push_back([=]() {
         float* dZ = talloc<float>(s, (size_t)rows * N);
         double* red = talloc<double>(s, 2 * (size_t)N, true);
         if (!dZ || !red) return;
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((N + 63) / 64, ry), dim3(256), 0, s->st, Y.g, Y.ld, Y.d, Y.ld, Z, mean, invstd, rows, N, keep, red, red + N);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(rows * N)), dim3(256), 0, s->st, Y.g, Y.ld, Y.d, Y.ld, Z, mean, invstd, gam.w, red, red + N, rows, N,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ry), dim3(256), 0, s->st, Y.g, Y.d, Z, mean, invstd, rows, N, keep ? 1 : 0, red, red + N);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Y.g, Y.ld, Y.d, Y.ld, Z, mean, invstd, gam.w, red, red + N, rows, N,
                            training, keep, dZ);
         if (bet.g) hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, red, bet.g, N);
         if (gam.g) hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, red + N, gam.g, N);
