@@ -51,6 +51,10 @@ def build_parser():
     p.add_argument("--objs_dir", type=str, default=None)
     p.add_argument("--batch_size", type=int, default=6, help="run/train_sdm.py:247 hard-codes 6")
     p.add_argument("--valid_skip_timesteps", type=int, default=0)
+    p.add_argument('--host_rng', action='store_true',
+                   help='draw the noise, the FPS starts and the dropout mask on the host in the order a CPU run of the reference draws them (parity with '
+                        'the oracle; the 7 M-element dropout mask of a B = 6 batch costs ~65 ms per step).  Default: the device generator, as the '
+                        'reference does when it trains on a GPU')
     return p
 
 
@@ -127,6 +131,7 @@ def main(argv=None):
     train_loader = DataLoader(mkds(train_dir, objs), batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
     valid_loader = DataLoader(mkds(valid_dir, objs_v), batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
     model, diffusion = create_model_and_diffusion(args.datatype, device=device.index or 0)
+    diffusion.host_rng = bool(args.host_rng)
     if args.load_ckpt is not None:
         model.load_state_dict(torch.load(args.load_ckpt, map_location="cpu")['model_state_dict'])
     elif args.synthetic:
