@@ -75,7 +75,9 @@ int lsdm_finalize_params(lsdm_ctx* ctx, int max_cats);
  * alphas_cumprod, alphas_cumprod_prev   (gaussian_diffusion.py:166-202, cast to fp32 as _extract_into_tensor :1594) */
 int lsdm_set_schedule(lsdm_ctx* ctx, int T, const float* coef1, const float* coef2, const float* logvar,
                       const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* acp, const float* acp_prev);
-/* allocates the workspace for batches up to max_batch samples */
+/* allocates the workspace for batches up to max_batch samples (≈ 35 MB per chain for the single-step entry points; the first multi-step
+ * call of the loop-invariant schedule adds the group workspace -- per-step slots of 32 steps' level features and geometry, ≈ 130 MB per
+ * chain: 8 GB at B = 64 of the 288 GB) */
 int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
 
 /* ---- the hot path ---------------------------------------------------------------------------------------- */
@@ -99,7 +101,7 @@ int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* 
 
 /* K consecutive ancestral steps t = t_first, t_first-1, ... with device-resident RNG draws; `x` ping-pongs with
  * an internal buffer and holds the final sample on return.  The x-independent PointNet++ geometry (FPS, ball queries,
- * 3-NN) and conditioning MLPs of up to 8 consecutive steps are evaluated in one launch per stage ahead of those steps;
+ * 3-NN) and conditioning MLPs of up to 32 consecutive steps are evaluated in one launch per stage ahead of those steps;
  * results are identical to K single-step calls.  Replaces the loop body of
  * p_sample_loop_progressive (gaussian_diffusion.py:736-759) for a fixed batch.
  *   fps_start_steps (K,4,B*9) int64 ; noise_steps (K,B,1024,3) */
