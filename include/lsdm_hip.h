@@ -75,9 +75,9 @@ int lsdm_finalize_params(lsdm_ctx* ctx, int max_cats);
  * alphas_cumprod, alphas_cumprod_prev   (gaussian_diffusion.py:166-202, cast to fp32 as _extract_into_tensor :1594) */
 int lsdm_set_schedule(lsdm_ctx* ctx, int T, const float* coef1, const float* coef2, const float* logvar,
                       const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* acp, const float* acp_prev);
-/* allocates the workspace for batches up to max_batch samples (≈ 35 MB per chain for the single-step entry points; the first multi-step
- * call of the loop-invariant schedule adds the group workspace -- per-step slots of 32 steps' level features and geometry, ≈ 130 MB per
- * chain: 8 GB at B = 64 of the 288 GB) */
+/* allocates the workspace for batches up to max_batch samples (stage tensors + the geometry sets of 32 steps: ≈ 115 MB per chain; the
+ * first multi-step call of the loop-invariant schedule adds the group workspace -- per-step slots of 32 steps' level features, ≈ 97 MB per
+ * chain: 13.7 GB in all at B = 64, measured) */
 int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
 
 /* ---- the hot path ---------------------------------------------------------------------------------------- */
