@@ -483,6 +483,25 @@ def test_plain_bf16_multi_step_group_equals_single_steps():
         assert torch.equal(_chain(m, diff, bt, B, K, 8, hoist_invariants=inv)[0], loop)
 
 
+def test_chain_on_a_caller_stream_with_work_queued_behind_it():
+    """The loop-invariant schedule forks a side stream off the caller's stream and joins it back (api.hip::stream_fork / stream_join): a
+    chain launched on a non-default torch stream, with a consumer of its result enqueued right behind it on the same stream and no
+    host synchronisation in between, gives the default-stream result bit for bit -- twice in a row (the events are re-used)."""
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(4, seed=41).items()}
+    m, diff = _fresh("bf16x3")
+    want = _chain(m, diff, bt, 4, 9, 23)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            got = _chain(m, diff, bt, 4, 9, 23)
+            checksum = got[0].double().sum() + got[1].double().sum()      # queued behind the chain on the same stream
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+            assert float(checksum) == float(want[0].double().sum() + want[1].double().sum())
+    torch.cuda.current_stream().wait_stream(side)
+
+
 # ======================================================================================= retained A/B switches of the library
 _SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "2"}, {"LSDM_SA_REG": "0"}, {"LSDM_SA_REG": "2", "LSDM_SA_SPLIT": "0"},
              {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
