@@ -655,10 +655,13 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     constexpr int TM = TM_, NW = NW_, NP = 2, NT = NW * 64;
     constexpr int TPP = NT / TM;                               // threads per fine point in the interpolation phase
     static_assert(TPP == 4 || TPP == 8, "four or eight threads per fine point in the interpolation phase");
-    // fp32 tile row (floats): 68 quads, and the quad index of an access is XORed with (row / 4) & 3 -- the 16-lane phases of both the
-    // interpolation stores (rows r .. r+3 x four consecutive quads) and the accumulator loads (16 consecutive rows x one quad) then
-    // cover 16 distinct bank quads (with the plain C1 + 4 rows the stores were 4-way conflicted: 26 % of the LDS cycles)
-    constexpr int LDT = C1 + 16;
+    // fp32 tile row: C1 floats, no padding (a row is a whole number of bank rounds), and the quad index of an access is XORed with
+    // tile_swz(row) = row bit 0 -> quad bit 0, row bit 1 -> quad bit 3, row bits 2-3 -> quad bits 1-2.  The 16-lane phases of the
+    // interpolation stores (rows r .. r+3 x quads {0, 2, 4, 6} + const, see FP_CH) and of the accumulator loads (16 consecutive rows x one
+    // quad) then both cover 16 distinct bank quads.
+    constexpr int LDT = C1;
+    static_assert(C1 % 64 == 0, "tile rows: whole bank rounds");
+    auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
     constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB, LDC = ldh(C2), PC = TM * LDC;
     constexpr int BYTES = imax(imax(imax(TM * LDT * 4, NP * PX * 2), NP * PB * 2), FUSE ? NP * PC * 2 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char region[BYTES];
@@ -701,11 +704,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         // piece k of thread `sub` of a row: consecutive pieces of a thread are ADJACENT 16-byte quads in pairs, so that the TPP threads of
         // a row read one whole 128-byte line per pair of requests (with piece k at quad sub + TPP k every line was requested in two
         // separate iterations, far enough apart to be fetched from L2 twice)
-#ifdef LSDM_FP_CH_OLD
-#define FP_CH(sub, k) (4 * ((sub) + TPP * (k)))
-#else
 #define FP_CH(sub, k) (4 * (2 * (sub) + ((k) & 1) + 2 * TPP * ((k) >> 1)))
-#endif
         // GB pieces x 3 rows in flight per batch: the phase is a chain of L2 round trips, so fewer, larger batches (registers
         // permitting: 12 GB VGPRs) shorten it
         constexpr int GB = (PIECES >= 8 && TPP == 4) ? 8 : 4;
@@ -723,7 +722,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(a[k][j], w0), __fmul_rn(b[k][j], w1)), __fmul_rn(d[k][j], w2));
-                *reinterpret_cast<f32x4*>(tile + row * LDT + (ch ^ (((row >> 2) & 3) << 2))) = v;
+                *reinterpret_cast<f32x4*>(tile + row * LDT + (ch ^ tile_swz(row))) = v;
             }
         }
     }
@@ -741,7 +740,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         for (int rb = 0; rb < RB1; ++rb)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ (((p >> 2) & 3) << 2)));
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = t[j];
             }
