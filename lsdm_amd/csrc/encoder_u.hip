@@ -679,13 +679,27 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     // (loop-invariant schedule: the level-1 features stay in SOURCE order, the step's FPS order is the index list)
     constexpr int XIT = TM * (D1 / 4) / NT;
     f32x4 gx[XIT];
+    // Every INDEX the tile needs is requested before any row that depends on one: the p1 row numbers (p1_remap) together with the
+    // three neighbour indices and weights of phase A -- one L2 round trip for all of them, then the p1 rows and the Y rows go out
+    // back to back.  (With the p1 rows fetched through their indices first, phase A's indices waited a whole round trip behind them:
+    // fp2 333 us in the loop-invariant schedule against 303 in the strict one, whose p1 rows are contiguous.)
+    const int arow = tid / TPP, sub = tid % TPP;
+    const size_t ao = ((size_t)c * N + n0 + arow) * 3;
+    const int dbg = keep_out >> 1;                       // timing experiments (LSDM_DBG_FP2): 1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs
+    int xrow[XIT];
+    if (p1_remap) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)c * N + n0 + (tid + it * NT) / (D1 / 4)];
+    }
+    const int i0 = (dbg & 1) ? 0 : nn_idx[ao + 0], i1 = (dbg & 1) ? 0 : nn_idx[ao + 1], i2 = (dbg & 1) ? 0 : nn_idx[ao + 2];
+    const float w0 = nn_w[ao + 0], w1 = nn_w[ao + 1], w2 = nn_w[ao + 2];
     if (p1_remap) {
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int e = tid + it * NT;
             const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
             // (p1_mod > 0: a launch over the clouds of several steps; points1 is the per-CALL tensor in source order, cloud c % p1_mod)
-            gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? c % p1_mod : c) * N + p1_remap[(size_t)c * N + n0 + row]) * D1 + 4 * c4);
+            gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? c % p1_mod : c) * N + xrow[it]) * D1 + 4 * c4);
         }
     } else {
 #pragma unroll
@@ -693,13 +707,10 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     }
     // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
     {
-        const int row = tid / TPP, sub = tid % TPP;
-        const size_t o = ((size_t)c * N + n0 + row) * 3;
-        const int dbg = keep_out >> 1;                       // timing experiments (LSDM_DBG_FP2): 1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs
-        const float* r0 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 0]) * C1;
-        const float* r1 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 1]) * C1;
-        const float* r2 = yb + (size_t)((dbg & 1) ? 0 : nn_idx[o + 2]) * C1;
-        const float w0 = nn_w[o + 0], w1 = nn_w[o + 1], w2 = nn_w[o + 2];
+        const int row = arow;
+        const float* r0 = yb + (size_t)i0 * C1;
+        const float* r1 = yb + (size_t)i1 * C1;
+        const float* r2 = yb + (size_t)i2 * C1;
         constexpr int PIECES = C1 / (4 * TPP);               // per thread
         // piece k of thread `sub` of a row: consecutive pieces of a thread are ADJACENT 16-byte quads in pairs, so that the TPP threads of
         // a row read one whole 128-byte line per pair of requests (with piece k at quad sub + TPP k every line was requested in two
