@@ -512,12 +512,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr long long rstep = 1;
     // The neighbour / centroid indices of a round are requested one round ahead and its 32 U rows (the gather: 128 registers per
     // lane) at the start of the previous round's layer 3, when x is dead -- with one wave per SIMD nothing else would hide that latency.
-    int idx_n = 0, ci_n = 0, ci_c = 0;
-    f32x4 un0[KS], un1[KS];
+    // (The centroid's V row -- the same 1 KB for all 32 rows of the wave -- travels with them: one 16-byte piece per lane, parked in LDS at
+    // the top of the round and read from there; fetched at the top of the round it cost two exposed L2 round trips per round.)
+    __shared__ __attribute__((aligned(16))) float vl[NW][C1];
+    int idx_n = 0, ci_n = 0;
+    f32x4 un0[KS], un1[KS], vn;
     auto request_u = [&](long long cc) {
         const float* urow = U + ((size_t)cc * NSRC + idx_n) * C1 + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) { un0[s] = load4f(urow + 16 * s); un1[s] = load4f(urow + 16 * s + 4); }
+        vn = load4f(V + ((size_t)cc * NSRC + ci_n) * C1 + 4 * lane);
     };
     if (rbeg < rend) {
         const long long ce = rbeg * NW + wave;
@@ -527,16 +531,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     for (long long rd = rbeg; rd < rend; rd += rstep) {
         const long long cent = rd * NW + wave;
-        const long long c = cent / S;
         bf16x8 xh[KS], xl[KS], zh[KS], zl[KS];
-        ci_c = ci_n;
         {
-            const float* vrow = V + ((size_t)c * NSRC + ci_c) * C1 + 8 * h;
+            *reinterpret_cast<f32x4*>(&vl[wave][4 * lane]) = vn;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const float* vrow = &vl[wave][8 * h];
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += 8) {
                 f32x4 v0[8], v1[8];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) { v0[s] = load4f(vrow + 16 * (s0 + s)); v1[s] = load4f(vrow + 16 * (s0 + s) + 4); }
+                for (int s = 0; s < 8; ++s) { v0[s] = *reinterpret_cast<const f32x4*>(vrow + 16 * (s0 + s)); v1[s] = *reinterpret_cast<const f32x4*>(vrow + 16 * (s0 + s) + 4); }
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const f32x4 u0 = un0[s0 + s], u1 = un1[s0 + s];
