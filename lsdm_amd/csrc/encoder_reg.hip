@@ -383,6 +383,8 @@ __device__ __forceinline__ f32x16 xfake_mfma(const bf16x8& a, const bf16x8& b, f
 // the other wave's loads and interpolation arithmetic issue in its gaps; panels streamed once per phase -- was measured slower as well,
 // 294 vs 271 us, 318 with the round's 48 row requests issued at once: a SIMD's pipe is fed better by two waves that both issue MFMAs and
 // drift apart inside a layer than by one wave with dependent accumulator chains and block-placed epilogues.)
+// (The gather as four batches of two k-steps with two batches in flight -- the L2 round trips of consecutive batches overlapping --
+// measured the same as two batches of four: 276 vs 275 us.)
 // blob: four layers [nb][s][plane][lane][8] (layer 1 in channel order, later layers in accumulator order) + conv2 zero-padded
 // to 32 channels; biases [4 x 128 | 32].
 template <int NW, int NP, int PH = 1>
