@@ -159,7 +159,11 @@ struct lsdm_ctx {
     // (alt_*: a second set of the per-step scratch tensors of the dense chain -- sa3 / sa4's U and V, fp2's pre-multiplied operand, fp2's
     // output -- for the steps that run on the side stream)
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr;
-                     struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3]; std::vector<void*> allocs; } gws;
+                     struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3];
+                     // memo of sa2 (geometry.hip: memo_src_kernel): r = 0.2 balls of the source points, flags, F2 rows, work lists, counters
+                     int *memo_ball2 = nullptr, *memo_src_list = nullptr, *memo_list = nullptr, *memo_cnt = nullptr, *memo_ident = nullptr;
+                     unsigned char* memo_unc = nullptr; float* memo_F2 = nullptr;
+                     std::vector<void*> allocs; } gws;
     // side stream of a loop-invariant group: the dense chains of its steps are independent of each other, odd steps run next to even ones
     int streams = getenv("LSDM_STREAMS") ? atoi(getenv("LSDM_STREAMS")) : 2;         // A/B switch: 1 = everything on the caller's stream
     static constexpr int kMaxSide = 3;
@@ -167,6 +171,8 @@ struct lsdm_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSide] = {};
     int nside() const { return streams - 1 < kMaxSide ? streams - 1 : kMaxSide; }
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
+    int sa2_memo = getenv("LSDM_SA2_MEMO") ? atoi(getenv("LSDM_SA2_MEMO")) : 1;      // A/B switch: 0 = every sa2 centroid through the stage every step
+    bool memo_ready = false;                  // this call's F2 / flags are in place (set by the per-call block, read by the groups)
     int inv_side = getenv("LSDM_INV_SIDE") ? atoi(getenv("LSDM_INV_SIDE")) : 1;      // A/B switch: 0 = the per-call level-1 work on the caller's stream
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
@@ -658,6 +664,22 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
         if (ok && !c->ev_fork) ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
         if (!ok) fail(c, LSDM_ERR_HIP, "group workspace: side stream");
     }
+    if (ok && c->sa2_memo) {
+        const size_t n1 = (size_t)B * kO;
+        g.memo_ball2 = reinterpret_cast<int*>(al(n1 * kN * 32));
+        g.memo_src_list = reinterpret_cast<int*>(al(n1 * kN));
+        g.memo_list = reinterpret_cast<int*>(al(nc * 256));
+        g.memo_cnt = reinterpret_cast<int*>(al(4));
+        g.memo_ident = reinterpret_cast<int*>(al(n1 * kN));
+        g.memo_unc = reinterpret_cast<unsigned char*>(al((n1 * kN + 3) / 4));
+        g.memo_F2 = al(n1 * kN * 128);
+        ok = g.memo_ball2 && g.memo_src_list && g.memo_list && g.memo_cnt && g.memo_ident && g.memo_unc && g.memo_F2;
+        if (ok) {
+            std::vector<int> ident(n1 * kN);
+            for (size_t i = 0; i < ident.size(); ++i) ident[i] = (int)(i % kN);
+            ok = hipMemcpy(g.memo_ident, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+        }
+    }
     if (ok) g.cap_B = B;
     return ok;
 }
@@ -689,7 +711,14 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     prof_mark(c, K_REMAP, st, steps);
     launch_l1_remap(nc, c->inv_F1, 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], clouds, nullptr, f.nn_idx[3], f.nn_w[3], st, nc1);
     prof_mark(c, K_SA1 + 1, st, steps);
-    launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
+    if (c->memo_ready) {
+        // (centroids with fewer than 32 points within r copy the call's F2 row of their source point; the others are the launch's work list)
+        (void)hipMemsetAsync(g.memo_cnt + 1, 0, sizeof(int), st);
+        launch_memo_cent(nc, f.idx[0], f.idx[1], g.memo_unc, g.memo_F2, nc1, g.feat[1], g.memo_list, g.memo_cnt + 1, st);
+        launch_sa_u_list(256, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1, g.memo_list,
+                         g.memo_cnt + 1);
+    } else
+        launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
     // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were
     // measured: fp2 337 -> 323 us, but fp1 275 -> 295, fp3 165 -> 190, sa3 / sa4 slower as well -- the extra launch ramps and tails cost
     // more than the cache residency gains)
@@ -1385,6 +1414,20 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         }
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
             launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
+        // memo of sa2 (geometry.hip::memo_src_kernel): the stage's output of every source point with fewer than 32 points within r, once
+        c->memo_ready = false;
+        if (K > 1 && group_batched(c) && c->sa2_memo && c->gws.memo_F2) {
+            const lsdm_ctx::GroupWs& gw = c->gws;
+            const float r2b = (float)(kRadius[1] * kRadius[1]);
+            prof_mark(c, K_BALL1 + 1, si);
+            (void)hipMemsetAsync(gw.memo_cnt, 0, 2 * sizeof(int), si);
+            launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si);
+            launch_memo_src(gw.memo_ball2, (long long)nc * kN, gw.memo_unc, gw.memo_src_list, gw.memo_cnt, si);
+            prof_mark(c, K_SA1 + 1, si);
+            launch_sa_u_list(1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
+                             gw.memo_src_list, gw.memo_cnt);
+            c->memo_ready = true;
+        }
         prof_mark(c, K_NN1, si);
         launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, si);
         prof_mark(c, -1, si);

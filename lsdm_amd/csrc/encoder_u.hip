@@ -357,7 +357,10 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                                                          const int* __restrict__ cent_idx, const int* __restrict__ ball,
                                                          const int* __restrict__ remap, int NSRC, int S, long long total_centroids,
                                                          const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
-                                                         float* __restrict__ out, int src_mod) {
+                                                         float* __restrict__ out, int src_mod, const int* __restrict__ list,
+                                                         const int* __restrict__ list_count) {
+    // list (optional): the launch covers the centroids list[0 .. *list_count) (global centroid numbers, any order) instead of
+    // 0 .. total_centroids -- the loop-invariant schedule's memo of sa2 (api.hip: run_sa2_memo)
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
     constexpr int W2E = NB2 * KS2 * NP * 512, W3E = NB3 * KS3 * NP * 512;
@@ -375,19 +378,22 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     const int p = lane & 31, h = lane >> 5;
     // 32-bit index arithmetic (a 64-bit division per centroid costs ~60 instructions); the neighbour / centroid indices of a
     // centroid -- two dependent loads when they go through `remap` -- are requested one iteration ahead
-    const int total = (int)total_centroids;
+    const int total = list ? *list_count : (int)total_centroids;
     const XcdRounds sched = xcd_rounds((total + NW - 1) / NW);       // a round = NW centroids, one per wave (common.hpp)
     const int cbeg = sched.first * NW, cstep = sched.stride * NW;
     const int cend = sched.end * NW < total ? sched.end * NW : total;
-    int idx_n = 0, ci_n = 0;
-    auto request = [&](int ce) {
+    int idx_n = 0, ci_n = 0, cent_n = 0;
+    auto request = [&](int k) {
+        const int ce = list ? list[k] : k;
         const int cc = ce / S;
+        cent_n = ce;
         idx_n = ball[(size_t)ce * kNSample + p];
         ci_n = cent_idx[ce];
         if (remap) { idx_n = remap[(size_t)cc * NSRC + idx_n]; ci_n = remap[(size_t)cc * NSRC + ci_n]; }
     };
     if (cbeg + wave < cend) request(cbeg + wave);
-    for (int cent = cbeg + wave; cent < cend; cent += cstep) {
+    for (int kk = cbeg + wave; kk < cend; kk += cstep) {
+        const int cent = cent_n;
         // (src_mod > 0: a launch over the clouds of several steps whose U / V are per-CALL tensors in source order)
         const int c = src_mod > 0 ? (cent / S) % src_mod : cent / S;
         const int idx = idx_n, ci = ci_n;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                 u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
-            if (cent + cstep < cend) request(cent + cstep);
+            if (kk + cstep < cend) request(kk + cstep);
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
@@ -906,6 +912,13 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
     else hipLaunchKernelGGL((lin_u_kernel<256, 256>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
 }
 
+// sa2 (the level-1 kernel) over a LIST of centroids: S centroids per cloud in the numbering of the list, list_count on the device
+void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
+                      const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count) {
+    hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, S, 0LL, blob_w, blob_b, out, src_mod,
+                       list, list_count);
+}
+
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod) {
     if (level == 3) {
@@ -919,7 +932,8 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
         const long long tot = (long long)nc * 256;
         // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
         // issue-bound -- MFMA and VALU time add -- not latency-bound)
-        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out, src_mod);
+        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out, src_mod,
+                           nullptr, nullptr);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
         hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);

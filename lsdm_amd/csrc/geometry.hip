@@ -907,6 +907,72 @@ void launch_l1_remap(int nc, const void* F1, int row_bytes, const int* idx1, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Memo of sa2 in the loop-invariant schedule (api.hip::run_sa2_memo).  sa2's source set is the WHOLE cloud (level 1 = all 1024
+// points in a step-dependent order) and its ball keeps the first 32 points, in level-1 order, with NOT(d > r^2).  When a point has
+// FEWER than 32 points within r, its ball is all of them whatever the order (the padding repeats one of them) and the max over the
+// ball -- the stage's output for that centroid -- depends only on WHICH point the centroid is: it is evaluated once per call for
+// every such point (F2) and copied per step.  Only centroids with >= 32 points within r ("crowded": the order decides which 32) go
+// through the stage each step.  Exact: per row the same arithmetic on the same operands; max is order-free.
+//
+// memo_src_kernel (per call): ball2 = the r-ball of every source point as a centroid, first 32 in SOURCE order, padded with its
+// first entry (launch_ball_query).  Entries are strictly increasing, so a padded last slot == the first entry  <=>  count <= 31.
+__global__ __launch_bounds__(256) void memo_src_kernel(const int* __restrict__ ball2, long long total, unsigned char* __restrict__ unc,
+                                                       int* __restrict__ list, int* __restrict__ count) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool u = false;
+    if (e < total) {
+        u = ball2[e * kNSample + kNSample - 1] == ball2[e * kNSample];
+        unc[e] = u ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(u);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (u) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)e;
+}
+
+// memo_cent_kernel (per group; one work-group per (step, cloud), one thread per level-2 centroid): uncrowded centroids copy their F2
+// row, crowded ones are appended to the work list of the stage.  A cloud whose level-1 index list is not a permutation (duplicated
+// points made FPS re-draw an index: the level-1 multiset is then not the cloud) sends all its centroids to the list.
+__global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ idx0, const int* __restrict__ idx1, const unsigned char* __restrict__ unc,
+                                                        const float* __restrict__ F2, int nc1, float* __restrict__ out, int* __restrict__ list,
+                                                        int* __restrict__ count) {
+    constexpr int N = kPoints, S = 256, C = 128;
+    __shared__ unsigned char seen[N];
+    __shared__ int missing;
+    __shared__ int srow[S];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int ci = c % nc1;
+    const int* i0 = idx0 + (size_t)c * N;
+    for (int e = tid; e < N; e += 256) seen[e] = 0;
+    if (tid == 0) missing = 0;
+    __syncthreads();
+    for (int e = tid; e < N; e += 256) seen[i0[e]] = 1;
+    __syncthreads();
+    for (int e = tid; e < N; e += 256)
+        if (!seen[e]) missing = 1;
+    __syncthreads();
+    const int src = i0[idx1[(size_t)c * S + tid]];
+    const bool crowded = missing || !unc[(size_t)ci * N + src];
+    srow[tid] = crowded ? -1 : src;
+    const unsigned long long m = __ballot(crowded);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (crowded) list[base + __popcll(m & ((1ull << lane) - 1ull))] = c * S + tid;
+    __syncthreads();
+    // copies: 32 threads x 16 bytes per row, eight rows per pass
+    const int sub = tid & 31;
+    for (int r = tid >> 5; r < S; r += 8) {
+        const int sr = srow[r];
+        if (sr < 0) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(F2 + ((size_t)ci * N + sr) * C + 4 * sub);
+        *reinterpret_cast<f32x4*>(out + ((size_t)c * S + r) * C + 4 * sub) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],
@@ -929,6 +995,14 @@ void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, i
         case 256: hipLaunchKernelGGL(ball_query_kernel<256>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
         case 64: hipLaunchKernelGGL(ball_query_kernel<64>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
     }
+}
+
+void launch_memo_src(const int* ball2, long long total, unsigned char* unc, int* list, int* count, hipStream_t st) {
+    hipLaunchKernelGGL(memo_src_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ball2, total, unc, list, count);
+}
+void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsigned char* unc, const float* F2, int nc1, float* out, int* list, int* count,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(memo_cent_kernel, dim3(clouds), dim3(256), 0, st, idx0, idx1, unc, F2, nc1, out, list, count);
 }
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,

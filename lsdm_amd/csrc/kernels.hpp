@@ -110,6 +110,12 @@ void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const 
 // ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
 void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
 // src_mod > 0 (level 1 with remap, a launch over the clouds of several steps): U / V are per-CALL tensors, those of cloud c % src_mod
+// memo of sa2 (geometry.hip): per call the uncrowded source points (flags + list), per group the copies / the crowded centroids' list
+void launch_memo_src(const int* ball2, long long total, unsigned char* unc, int* list, int* count, hipStream_t st);
+void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsigned char* unc, const float* F2, int nc1, float* out, int* list, int* count,
+                      hipStream_t st);
+void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
+                      const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count);
 void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod = 0);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
