@@ -162,7 +162,7 @@ struct lsdm_ctx {
                      struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3];
                      // memo of sa2 (geometry.hip: memo_src_kernel): r = 0.2 balls of the source points, flags, F2 rows, work lists, counters
                      int *memo_ball2 = nullptr, *memo_src_list = nullptr, *memo_list = nullptr, *memo_cnt = nullptr, *memo_ident = nullptr;
-                     unsigned char* memo_unc = nullptr; float* memo_F2 = nullptr;
+                     unsigned char *memo_unc = nullptr, *memo_crowd = nullptr; float* memo_F2 = nullptr;
                      std::vector<void*> allocs; } gws;
     // side stream of a loop-invariant group: the dense chains of its steps are independent of each other, odd steps run next to even ones
     int streams = getenv("LSDM_STREAMS") ? atoi(getenv("LSDM_STREAMS")) : 2;         // A/B switch: 1 = everything on the caller's stream
@@ -509,7 +509,9 @@ typedef lsdm_ctx::FrontSet FrontSet;
 // PointNet++ geometry of `g` consecutive steps x `nc` clouds into front sets f, f+1, ..., f+g-1 (contiguous memory):
 // FPS chain, 4 ball queries, 4 three-NN searches -- one launch each for the whole group (x-independent work).
 // `starts` is the (g,4,nc) slice of the per-step start draws.
-void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, int g, hipStream_t st, bool skip_l1 = false) {
+// skip_sa2_ball: the level-2 ball query is left to the caller (sa2 memo: it runs for the crowded centroids only, after their classification)
+void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* starts, int nc, int g, hipStream_t st, bool skip_l1 = false,
+                  bool skip_sa2_ball = false) {
     const int tot = nc * g;
     prof_mark(c, K_FPS, st);
     launch_fps_chain(clouds, starts, tot, nc, f.idx, f.xyz, st);
@@ -518,6 +520,7 @@ void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* 
         // radius ** 2 is a double in the reference and is compared against fp32 distances (Q13)
         const float r2 = (float)(kRadius[l] * kRadius[l]);
         if (l == 0 && skip_l1) continue;   // level-1 balls are step-invariant (lsdm_sample_steps_invariant)
+        if (l == 1 && skip_sa2_ball) continue;
         prof_mark(c, K_BALL1 + l, st);
         launch_ball_query(lvl_xyz[l], lvl_xyz[l + 1], tot, kSrcN[l], kS[l], r2, f.ball[l], l == 0 ? nc : 0, st);
     }
@@ -673,7 +676,8 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
         g.memo_ident = reinterpret_cast<int*>(al(n1 * kN));
         g.memo_unc = reinterpret_cast<unsigned char*>(al((n1 * kN + 3) / 4));
         g.memo_F2 = al(n1 * kN * 128);
-        ok = g.memo_ball2 && g.memo_src_list && g.memo_list && g.memo_cnt && g.memo_ident && g.memo_unc && g.memo_F2;
+        g.memo_crowd = reinterpret_cast<unsigned char*>(al((nc * 256 + 3) / 4));
+        ok = g.memo_crowd && g.memo_ball2 && g.memo_src_list && g.memo_list && g.memo_cnt && g.memo_ident && g.memo_unc && g.memo_F2;
         if (ok) {
             std::vector<int> ident(n1 * kN);
             for (size_t i = 0; i < ident.size(); ++i) ident[i] = (int)(i % kN);
@@ -714,7 +718,10 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     if (c->memo_ready) {
         // (centroids with fewer than 32 points within r copy the call's F2 row of their source point; the others are the launch's work list)
         (void)hipMemsetAsync(g.memo_cnt + 1, 0, sizeof(int), st);
-        launch_memo_cent(nc, f.idx[0], f.idx[1], g.memo_unc, g.memo_F2, nc1, g.feat[1], g.memo_list, g.memo_cnt + 1, st);
+        launch_memo_cent(nc, f.idx[0], f.idx[1], g.memo_unc, g.memo_F2, nc1, g.feat[1], g.memo_list, g.memo_cnt + 1, g.memo_crowd, st);
+        prof_mark(c, K_BALL1 + 1, st, steps);
+        launch_ball_query(f.xyz[0], f.xyz[1], nc, 1024, 256, (float)(kRadius[1] * kRadius[1]), f.ball[1], 0, st, g.memo_crowd);
+        prof_mark(c, K_SA1 + 1, st, steps);
         launch_sa_u_list(256, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1, g.memo_list,
                          g.memo_cnt + 1);
     } else
@@ -1421,7 +1428,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             const float r2b = (float)(kRadius[1] * kRadius[1]);
             prof_mark(c, K_BALL1 + 1, si);
             (void)hipMemsetAsync(gw.memo_cnt, 0, 2 * sizeof(int), si);
-            launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si);
+            launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si, nullptr, /*scan=*/true);
             launch_memo_src(gw.memo_ball2, (long long)nc * kN, gw.memo_unc, gw.memo_src_list, gw.memo_cnt, si);
             prof_mark(c, K_SA1 + 1, si);
             launch_sa_u_list(1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
@@ -1443,8 +1450,8 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
         run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st, /*shared=*/true);
-        run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv);
         const bool grp = inv && g > 1 && group_batched(c);
+        run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv, grp && c->memo_ready);
         need_invariants();
         if (grp) {
             if (!ensure_group_ws(c, B)) return LSDM_ERR_HIP;

@@ -382,7 +382,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // lane's two points are two conflict-free ds_read_b128.
 template <int N>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
-                                                         int S, float r2, int* __restrict__ out, int src_mod) {
+                                                         int S, float r2, int* __restrict__ out, int src_mod,
+                                                         const unsigned char* __restrict__ only) {
+    // only (optional, one flag per centroid): centroids whose flag is 0 are skipped, their `out` rows left alone (sa2 memo)
     constexpr int CPW = 4;
     constexpr bool PAIRED = N >= 128;
     constexpr int NPAIR = PAIRED ? N / 128 : 1;
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
     for (int q = 0; q < CPW; ++q) {
         const int s = (tile * 4 + wave) * CPW + q;
         if (s >= S) break;  // wave-uniform
+        if (only && !only[(size_t)c * S + s]) continue;   // wave-uniform
         const float* cp = new_xyz + ((size_t)c * S + s) * 3;
         const float ax = cp[0], ay = cp[1], az = cp[2];
         const float a2 = sumsq3(ax, ay, az);
@@ -937,7 +940,7 @@ __global__ __launch_bounds__(256) void memo_src_kernel(const int* __restrict__ b
 // points made FPS re-draw an index: the level-1 multiset is then not the cloud) sends all its centroids to the list.
 __global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ idx0, const int* __restrict__ idx1, const unsigned char* __restrict__ unc,
                                                         const float* __restrict__ F2, int nc1, float* __restrict__ out, int* __restrict__ list,
-                                                        int* __restrict__ count) {
+                                                        int* __restrict__ count, unsigned char* __restrict__ crowd) {
     constexpr int N = kPoints, S = 256, C = 128;
     __shared__ unsigned char seen[N];
     __shared__ int missing;
@@ -956,6 +959,7 @@ __global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ 
     const int src = i0[idx1[(size_t)c * S + tid]];
     const bool crowded = missing || !unc[(size_t)ci * N + src];
     srow[tid] = crowded ? -1 : src;
+    crowd[(size_t)c * S + tid] = crowded ? 1 : 0;        // (the stage's ball query then runs for these centroids only)
     const unsigned long long m = __ballot(crowded);
     int base = 0;
     if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
@@ -982,18 +986,18 @@ void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds
 }
 
 void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod,
-                       hipStream_t st) {
+                       hipStream_t st, const unsigned char* only, bool scan) {
     dim3 grid((S + 15) / 16 * num_clouds), block(256);
-    if (N == 1024 && S == 1024) {
+    if (N == 1024 && S == 1024 && !scan) {
         // finest level (r = 0.1, every point is a centroid): grid-pruned candidates, one thread per centroid.  Measured on
         // MI355X: 0.19 -> 0.10 ms per step; at the next level (r = 0.2, 8x the candidates) the ordered scan stays faster.
         hipLaunchKernelGGL(ball_query_grid_kernel, dim3(S / 256 * num_clouds), block, 0, st, xyz, new_xyz, S, r2, sqrtf(r2) * 1.02f, out, src_mod);
         return;
     }
     switch (N) {
-        case 1024: hipLaunchKernelGGL(ball_query_kernel<1024>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
-        case 256: hipLaunchKernelGGL(ball_query_kernel<256>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
-        case 64: hipLaunchKernelGGL(ball_query_kernel<64>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod); break;
+        case 1024: hipLaunchKernelGGL(ball_query_kernel<1024>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod, only); break;
+        case 256: hipLaunchKernelGGL(ball_query_kernel<256>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod, only); break;
+        case 64: hipLaunchKernelGGL(ball_query_kernel<64>, grid, block, 0, st, xyz, new_xyz, S, r2, out, src_mod, only); break;
     }
 }
 
@@ -1001,8 +1005,8 @@ void launch_memo_src(const int* ball2, long long total, unsigned char* unc, int*
     hipLaunchKernelGGL(memo_src_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ball2, total, unc, list, count);
 }
 void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsigned char* unc, const float* F2, int nc1, float* out, int* list, int* count,
-                      hipStream_t st) {
-    hipLaunchKernelGGL(memo_cent_kernel, dim3(clouds), dim3(256), 0, st, idx0, idx1, unc, F2, nc1, out, list, count);
+                      unsigned char* crowd, hipStream_t st) {
+    hipLaunchKernelGGL(memo_cent_kernel, dim3(clouds), dim3(256), 0, st, idx0, idx1, unc, F2, nc1, out, list, count, crowd);
 }
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,

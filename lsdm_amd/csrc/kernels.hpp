@@ -79,7 +79,9 @@ enum StepMode { MODE_FORWARD = 0, MODE_P_SAMPLE = 1, MODE_DDIM = 2 };
 // src_mod / fine_mod = nc_step when the operand is the level-0 input cloud (shared by the steps), else 0
 void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],
                       hipStream_t st);
-void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod, hipStream_t st);
+void launch_ball_query(const float* xyz, const float* new_xyz, int num_clouds, int N, int S, float r2, int* out, int src_mod, hipStream_t st,
+                       const unsigned char* only = nullptr, bool scan = false);
+// (only: one flag per centroid, 0 = skip it; scan: the ordered-scan kernel also where the grid kernel would be chosen)
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,
                      hipStream_t st);
 // level-1 loop-invariant work translated into the step's FPS order (lsdm_sample_steps_invariant): feature rows + 3-NN positions
@@ -113,7 +115,7 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
 // memo of sa2 (geometry.hip): per call the uncrowded source points (flags + list), per group the copies / the crowded centroids' list
 void launch_memo_src(const int* ball2, long long total, unsigned char* unc, int* list, int* count, hipStream_t st);
 void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsigned char* unc, const float* F2, int nc1, float* out, int* list, int* count,
-                      hipStream_t st);
+                      unsigned char* crowd, hipStream_t st);
 void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
                       const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count);
 void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
