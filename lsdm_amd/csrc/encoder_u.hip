@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                                                          float* __restrict__ out, int src_mod, const int* __restrict__ list,
                                                          const int* __restrict__ list_count) {
     // list (optional): the launch covers the centroids list[0 .. *list_count) (global centroid numbers, any order) instead of
-    // 0 .. total_centroids -- the loop-invariant schedule's memo of sa2 (api.hip: run_sa2_memo)
+    // 0 .. total_centroids -- the loop-invariant schedule's memo of sa2 (api.hip: memo_ready)
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
     constexpr int W2E = NB2 * KS2 * NP * 512, W3E = NB3 * KS3 * NP * 512;

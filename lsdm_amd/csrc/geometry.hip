@@ -910,7 +910,7 @@ void launch_l1_remap(int nc, const void* F1, int row_bytes, const int* idx1, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// Memo of sa2 in the loop-invariant schedule (api.hip::run_sa2_memo).  sa2's source set is the WHOLE cloud (level 1 = all 1024
+// Memo of sa2 in the loop-invariant schedule (api.hip: memo_ready).  sa2's source set is the WHOLE cloud (level 1 = all 1024
 // points in a step-dependent order) and its ball keeps the first 32 points, in level-1 order, with NOT(d > r^2).  When a point has
 // FEWER than 32 points within r, its ball is all of them whatever the order (the padding repeats one of them) and the max over the
 // ball -- the stage's output for that centroid -- depends only on WHICH point the centroid is: it is evaluated once per call for
