@@ -385,7 +385,7 @@ def main():
                                   "stages); what does NOT depend on the FPS order is evaluated once per call INSIDE the timed call and "
                                   "re-ordered / copied per step: the level-1 work (balls, sa1 features, 3-NN candidates) and sa2's output of "
                                   "the points with fewer than 32 points within r = 0.2 (their ball is the same set every step; the others -- "
-                                  "45 %% of the centroids on this data -- go through sa2 every step) -- results bit-identical to the strict "
+                                  "45 % of the centroids on this data -- go through sa2 every step) -- results bit-identical to the strict "
                                   "schedule, whose figure is under strict_recompute" if inv else
                                   "strict per-step recompute of everything the reference recomputes"),
                    "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
