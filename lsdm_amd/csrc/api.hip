@@ -1423,7 +1423,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
         // memo of sa2 (geometry.hip::memo_src_kernel): the stage's output of every source point with fewer than 32 points within r, once
         c->memo_ready = false;
-        if (K > 1 && group_batched(c) && c->sa2_memo && c->gws.memo_F2) {
+        if (K > 1 && gmax > 1 && group_batched(c) && c->sa2_memo && c->gws.memo_F2) {
             const lsdm_ctx::GroupWs& gw = c->gws;
             const float r2b = (float)(kRadius[1] * kRadius[1]);
             prof_mark(c, K_BALL1 + 1, si);
