@@ -205,7 +205,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
 
-    from lsdm_amd.parallel import gather_samples
+    from lsdm_amd.parallel import gather_results
 
     B, K, W, C = a.batch, a.steps, a.warmup, 13
 
@@ -221,7 +221,7 @@ def main():
     if W:
         r.run(T - 1, 0, W, invariant=inv)
     if dist:
-        gather_samples(r.x, dist)                 # untimed: RCCL communicator set-up belongs to the warm-up
+        gather_results(r.x, r.out_cat, r.out_g, dist)   # untimed: RCCL communicator set-up + shard-size agreement belong to the warm-up
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -252,7 +252,9 @@ def main():
     t0 = time.perf_counter()
     r.run(T - 1 - W, W, K, invariant=inv)
     ev[0].record()
-    gathered = gather_samples(r.x, dist, agree=False)   # the path's only collective (RCCL all-gather over xGMI); sizes agreed in the warm-up
+    # the path's only collective (RCCL all-gather over xGMI; sizes agreed in the warm-up): what run/test_sdm.py:184-202 reads after the
+    # loop -- final samples, saved_cat and the guiding points of every chain -- packed into one buffer (lsdm_amd/parallel.py)
+    gathered, gathered_cat, gathered_guid = gather_results(r.x, r.out_cat, r.out_g, dist, agree=False)
     ev[1].record()
     torch.cuda.synchronize()
     if dist:
@@ -270,6 +272,7 @@ def main():
         per_rank_dt = [float(v) for v in every.cpu()]
         dt = max(per_rank_dt)                     # the job's time is its slowest rank's
     assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
+    assert gathered_cat.shape == (B * world, 1, C) and gathered_guid.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered_guid).all())
     x_final = r.x.clone()
 
     if rank != 0:
@@ -390,10 +393,11 @@ def main():
                                   "strict per-step recompute of everything the reference recomputes"),
                    "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
                    "global_batch": B * world, "chains_per_gpu": B,
-                   "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples" % world},
+                   "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples + saved_cat + guiding points (one packed buffer)" % world},
         "schedule": "loop-invariant (level-1 encoder work and the order-free part of sa2 once per %d-step call, inside the timed call; bit-identical to strict)" % K if inv
                     else "strict (every stage every step)",
         "rccl_ranks": world, "per_rank_seeds": [shard_seed(a.seed, q) for q in range(world)], "allgather_us": allgather_us,
+        "allgather_bytes_per_rank": int(B * (2 * 3072 + C) * 4) if world > 1 else 0,
         "per_rank_ms_per_step": [round(v / K * 1e3, 4) for v in per_rank_dt],
         "roofline": {"bound": "mfma", "kernel": dom["name"],
                      "launches_of_the_stage": STAGE_KERNELS_BF16X3.get(dom["name"], dom["name"]) if a.precision == "bf16x3" else dom["name"],

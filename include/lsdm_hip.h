@@ -27,6 +27,9 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its only dynamic symbols. */
+#define LSDM_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -55,30 +58,30 @@ typedef enum {
 } lsdm_precision;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
-int lsdm_create(lsdm_ctx** out, int device);
-int lsdm_destroy(lsdm_ctx* ctx);
+LSDM_API int lsdm_create(lsdm_ctx** out, int device);
+LSDM_API int lsdm_destroy(lsdm_ctx* ctx);
 /* message of the last failing call on ctx (ctx may be NULL for lsdm_create failures) */
-const char* lsdm_last_error(const lsdm_ctx* ctx);
+LSDM_API const char* lsdm_last_error(const lsdm_ctx* ctx);
 
 /* ---- parameters: replaces model.load_state_dict(ckpt['model_state_dict'])  (run/test_sdm.py:124) ---------- */
 /* `name` is a state_dict key of SURVEY.md Appendix A; `data` is a HOST fp32 pointer (num_batches_tracked and the
  * duplicate pe alias are ignored).  Shapes are checked in lsdm_finalize_params. */
-int lsdm_set_param(lsdm_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
+LSDM_API int lsdm_set_param(lsdm_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
 /* arithmetic of the dense (1x1-conv / Linear) stacks; geometry (FPS, ball query, 3-NN), normalisations, softmaxes and
  * the sampler update are always fp32.  Call before lsdm_finalize_params / lsdm_reserve (changing it invalidates both). */
-int lsdm_set_precision(lsdm_ctx* ctx, int precision);
-int lsdm_get_precision(const lsdm_ctx* ctx);
+LSDM_API int lsdm_set_precision(lsdm_ctx* ctx, int precision);
+LSDM_API int lsdm_get_precision(const lsdm_ctx* ctx);
 /* folds eval-mode BatchNorm into the 1x1 convolutions, packs the MFMA operands, uploads.  max_cats = C. */
-int lsdm_finalize_params(lsdm_ctx* ctx, int max_cats);
+LSDM_API int lsdm_finalize_params(lsdm_ctx* ctx, int max_cats);
 /* per-timestep fp32 tables of the (possibly respaced) diffusion process, length T each:
  * posterior_mean_coef1/2, posterior_log_variance_clipped, sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
  * alphas_cumprod, alphas_cumprod_prev   (gaussian_diffusion.py:166-202, cast to fp32 as _extract_into_tensor :1594) */
-int lsdm_set_schedule(lsdm_ctx* ctx, int T, const float* coef1, const float* coef2, const float* logvar,
+LSDM_API int lsdm_set_schedule(lsdm_ctx* ctx, int T, const float* coef1, const float* coef2, const float* logvar,
                       const float* sqrt_recip_acp, const float* sqrt_recipm1_acp, const float* acp, const float* acp_prev);
 /* allocates the workspace for batches up to max_batch samples (stage tensors + the geometry sets of 32 steps: ≈ 115 MB per chain; the
  * first multi-step call of the loop-invariant schedule adds the group workspace -- per-step slots of 32 steps' level features, ≈ 97 MB per
  * chain: 13.7 GB in all at B = 64, measured) */
-int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
+LSDM_API int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
 
 /* ---- the hot path ---------------------------------------------------------------------------------------- */
 /* One denoising-network evaluation, optionally fused with the sampler update.
@@ -95,7 +98,7 @@ int lsdm_reserve(lsdm_ctx* ctx, int max_batch);
  *   out_guiding  (B,1024,3)   model.saved_guiding_points
  *   out_sample   (B,1024,3)   x_{t-1}; ignored for LSDM_MODE_FORWARD
  */
-int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* mask, const int64_t* t,
+LSDM_API int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* mask, const int64_t* t,
               const float* given_objs, const float* given_cats, const float* text_feat, const int64_t* fps_start,
               const float* noise, float* out_cat, float* out_x0, float* out_guiding, float* out_sample, void* stream);
 
@@ -105,7 +108,7 @@ int lsdm_step(lsdm_ctx* ctx, int mode, float eta, int B, float* x, const float* 
  * results are identical to K single-step calls.  Replaces the loop body of
  * p_sample_loop_progressive (gaussian_diffusion.py:736-759) for a fixed batch.
  *   fps_start_steps (K,4,B*9) int64 ; noise_steps (K,B,1024,3) */
-int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+LSDM_API int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
                       const float* given_objs, const float* given_cats, const float* text_feat,
                       const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,
                       float* out_guiding, void* stream);
@@ -119,7 +122,7 @@ int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, in
  * The arithmetic and its operands are those of lsdm_sample_steps -- results are bit-identical (tests) -- unlike the hoisted
  * variant below, which changes the random stream.  Clouds whose finest FPS is not a permutation (duplicated points) fall
  * back to the per-step 3-NN inside the kernel. */
-int lsdm_sample_steps_invariant(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+LSDM_API int lsdm_sample_steps_invariant(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
                                 const float* given_objs, const float* given_cats, const float* text_feat,
                                 const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,
                                 float* out_guiding, void* stream);
@@ -129,36 +132,36 @@ int lsdm_sample_steps_invariant(lsdm_ctx* ctx, int mode, float eta, int B, int t
  * (4,B*9); each of the K steps then runs only the t-dependent embedding MLPs, the up-sampling layers and the fused
  * per-point denoiser + sampler update.  Equals the reference when its per-forward FPS re-draw (pointnet2_utils.py:72,
  * SURVEY.md Q11) is pinned to the same starts; NOT equal to the stock reference, whose scene features jitter per step. */
-int lsdm_sample_steps_hoisted(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
+LSDM_API int lsdm_sample_steps_hoisted(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
                               const float* given_objs, const float* given_cats, const float* text_feat, const int64_t* fps_start,
                               const float* noise_steps, float* out_cat, float* out_x0, float* out_guiding, void* stream);
 
 /* ---- stage entry points (parity tests against the oracle's taps; same kernels the hot path launches) -------- */
 /* farthest_point_sample x4 chained (pointnet2_utils.py:60-81): idx_l (num_clouds,S_l) int32, xyz_l (num_clouds,S_l,3),
  * S = 1024,256,64,16 */
-int lsdm_fps(lsdm_ctx* ctx, const float* clouds, const int64_t* fps_start, int num_clouds, int32_t* idx1, int32_t* idx2,
+LSDM_API int lsdm_fps(lsdm_ctx* ctx, const float* clouds, const int64_t* fps_start, int num_clouds, int32_t* idx1, int32_t* idx2,
              int32_t* idx3, int32_t* idx4, float* xyz1, float* xyz2, float* xyz3, float* xyz4, void* stream);
 /* query_ball_point (pointnet2_utils.py:84-104): out (num_clouds,S,32) int32; N in {1024,256,64}.  `radius` is a
  * double like the reference's Python float; radius*radius is rounded to fp32 for the comparison */
-int lsdm_ball_query(lsdm_ctx* ctx, const float* xyz, const float* new_xyz, int num_clouds, int N, int S, double radius,
+LSDM_API int lsdm_ball_query(lsdm_ctx* ctx, const float* xyz, const float* new_xyz, int num_clouds, int N, int S, double radius,
                     int32_t* out, void* stream);
 /* 3-NN + inverse-distance weights (pointnet2_utils.py:293-299): idx (num_clouds,N,3) int32, w (num_clouds,N,3) */
-int lsdm_three_nn(lsdm_ctx* ctx, const float* fine, const float* coarse, int num_clouds, int N, int S, int32_t* idx,
+LSDM_API int lsdm_three_nn(lsdm_ctx* ctx, const float* fine, const float* coarse, int num_clouds, int N, int S, int32_t* idx,
                   float* w, void* stream);
 /* get_backbone.forward (pointnet2.py:61-80): clouds (num_clouds,1024,3) -> out (num_clouds,1024,3) */
-int lsdm_scene_encoder(lsdm_ctx* ctx, const float* clouds, const int64_t* fps_start, int num_clouds, float* out, void* stream);
+LSDM_API int lsdm_scene_encoder(lsdm_ctx* ctx, const float* clouds, const int64_t* fps_start, int num_clouds, float* out, void* stream);
 /* POSA Decoder.forward (posa_models.py:320-326) on given_objs[:,0]: -> hm (B,1024,3) */
-int lsdm_human_backbone(lsdm_ctx* ctx, const float* given_objs, int B, float* hm, void* stream);
+LSDM_API int lsdm_human_backbone(lsdm_ctx* ctx, const float* given_objs, int B, float* hm, void* stream);
 /* device pointer + element count of a named workspace intermediate of the last call
  * ("feat1".."feat4","fp4","fp3","fp2","pcd","hm","w","tr","o12","e0","ball1".."ball4","nn_idx1".."nn_idx4") */
-int lsdm_workspace_tensor(lsdm_ctx* ctx, const char* name, void** ptr, int64_t* numel);
+LSDM_API int lsdm_workspace_tensor(lsdm_ctx* ctx, const char* name, void** ptr, int64_t* numel);
 
 /* ---- evaluation metrics of the CLI (run/test_sdm.py:185-196) -------------------------------------------------------- */
 /* For every point of a (batch,na,3) the squared Euclidean distance to its nearest point of b (batch,nb,3), fp32
  * (ax-bx)^2+(ay-by)^2+(az-bz)^2, and optionally its index (lowest on ties; out_idx may be NULL).  One direction per
  * call.  The K = 1 search underneath pytorch3d.loss.chamfer_distance (run/test_sdm.py:186: mean over points of both
  * directions, summed) and open3d compute_point_cloud_distance (util/evaluation.py:37-38: sqrt(d2) < th for the F-score). */
-int lsdm_nn_distance(lsdm_ctx* ctx, const float* a, int na, const float* b, int nb, int batch, float* out_d2,
+LSDM_API int lsdm_nn_distance(lsdm_ctx* ctx, const float* a, int na, const float* b, int nb, int batch, float* out_d2,
                      int32_t* out_idx, void* stream);
 
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream ----------------------------- */
@@ -166,9 +169,9 @@ int lsdm_nn_distance(lsdm_ctx* ctx, const float* a, int na, const float* b, int 
  * synchronises and returns (number of kernels, or < 0): total_ms[k] = summed duration, launches[k] = launch count,
  * macs_per_unit[k] = algorithmic multiply-accumulates of one launch per cloud (PointNet++ kernels) or per sample
  * (the others) -- the figures of DESIGN.md / SURVEY.md 8(d).  Arrays must hold `capacity` >= 23 entries. */
-int lsdm_profile_begin(lsdm_ctx* ctx);
-int lsdm_profile_end(lsdm_ctx* ctx, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit);
-const char* lsdm_profile_kernel_name(int k);
+LSDM_API int lsdm_profile_begin(lsdm_ctx* ctx);
+LSDM_API int lsdm_profile_end(lsdm_ctx* ctx, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit);
+LSDM_API const char* lsdm_profile_kernel_name(int k);
 
 /* ---- training objective: replaces diffusion.training_losses(...) + loss.backward()  (gaussian_diffusion.py:1256-1342,
  *      run/train_sdm.py:62-80) -------------------------------------------------------------------------------------------------
@@ -178,10 +181,10 @@ const char* lsdm_profile_kernel_name(int k);
  * gradient -- an optimizer step on the caller's tensors is seen by the next lsdm_train_step.  attn_layer.{v_proj_weight,out_proj.*}
  * do not enter the loss and need not be bound. */
 typedef struct lsdm_train lsdm_train;
-int lsdm_train_create(lsdm_train** out, int device, int max_cats);
-int lsdm_train_destroy(lsdm_train* s);
-const char* lsdm_train_last_error(const lsdm_train* s);
-int lsdm_train_bind(lsdm_train* s, const char* name, float* param, float* grad, int64_t numel);
+LSDM_API int lsdm_train_create(lsdm_train** out, int device, int max_cats);
+LSDM_API int lsdm_train_destroy(lsdm_train* s);
+LSDM_API const char* lsdm_train_last_error(const lsdm_train* s);
+LSDM_API int lsdm_train_bind(lsdm_train* s, const char* name, float* param, float* grad, int64_t numel);
 /* One training batch: x_t = qa[b] x_start + qb[b] noise (q_sample, :233-256; qa = sqrt_alphas_cumprod[t], qb =
  * sqrt_one_minus_alphas_cumprod[t] gathered from the float64 tables and cast by the caller, as _extract_into_tensor does),
  * SceneDiffusionModel.forward(x_t, mask, t, given_objs, given_cats, text) with every activation kept,
@@ -194,7 +197,7 @@ int lsdm_train_bind(lsdm_train* s, const char* name, float* param, float* grad, 
  * dropout_keep (nullable): (B*9,128,1024) bytes, the keep-mask of the encoder head's Dropout(0.5) (pointnet2.py:58,76), drawn by
  * the caller (the reference draws it on the host generator right after the four FPS start draws); kept activations are doubled.
  * fps_starts: (4, B*9) int64 as in lsdm_step.  model_output (B,1024,3) and out_cat (B,max_cats) are optional outputs. */
-int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const float* qa, const float* qb, const float* noise,
+LSDM_API int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const float* qa, const float* qb, const float* noise,
                     const int64_t* t, const float* mask, const float* given_objs, const float* given_cats, const int64_t* target,
                     const float* text, const int64_t* fps_starts, const unsigned char* dropout_keep, float lambda_cat,
                     float grad_scale, float* losses, float* model_output, float* out_cat, void* stream);
@@ -203,7 +206,7 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
  * "sa1.arg" .. "sa4.arg": uint8 (B*9 * S, C) -- which of the 32 neighbours attains the max of every (centroid, channel), i.e. where the
  * max-pool routes the gradient.  (Two neighbours whose activations differ in the last bits make that choice depend on the summation
  * order of the layer before; the parity test injects these choices into the oracle and checks that every difference IS such a near-tie.) */
-int lsdm_train_read(lsdm_train* s, const char* name, void* host_dst, int64_t capacity_bytes, int64_t* nbytes);
+LSDM_API int lsdm_train_read(lsdm_train* s, const char* name, void* host_dst, int64_t capacity_bytes, int64_t* nbytes);
 
 #ifdef __cplusplus
 }

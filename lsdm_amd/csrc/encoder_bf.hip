@@ -206,7 +206,7 @@ __global__ void calib_kernel(unsigned long long* out) {
     out[1] = clock64() - c0;
     out[2] = wall_clock64() - w0;
 }
-extern "C" int lsdm_debug_calibrate(unsigned long long* out3) {
+extern "C" __attribute__((visibility("default"))) int lsdm_debug_calibrate(unsigned long long* out3) {
     unsigned long long* d = nullptr;
     if (hipMalloc(&d, 24) != hipSuccess) return -1;
     hipLaunchKernelGGL(calib_kernel, dim3(1), dim3(64), 0, 0, d);
@@ -214,7 +214,7 @@ extern "C" int lsdm_debug_calibrate(unsigned long long* out3) {
     (void)hipFree(d);
     return rc;
 }
-extern "C" int lsdm_debug_phase_counters(unsigned long long* out, int reset) {
+extern "C" __attribute__((visibility("default"))) int lsdm_debug_phase_counters(unsigned long long* out, int reset) {
     static unsigned long long h[64 * 64], z[64 * 64];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return -1;
     for (int s = 0; s < 64; ++s) { out[s] = 0; for (int c = 0; c < 64; ++c) out[s] += h[c * 64 + s]; }

@@ -132,15 +132,19 @@ def main(argv=None):
     valid_loader = DataLoader(mkds(valid_dir, objs_v), batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
     model, diffusion = create_model_and_diffusion(args.datatype, device=device.index or 0)
     diffusion.host_rng = bool(args.host_rng)
-    if args.load_ckpt is not None:
-        model.load_state_dict(torch.load(args.load_ckpt, map_location="cpu")['model_state_dict'])
+    starting_epoch = 0
+    if args.load_ckpt is not None:      # resume as run/train_sdm.py:284-289: weights + the epoch counter
+        checkpoint = torch.load(args.load_ckpt, map_location="cpu")
+        model.load_state_dict(checkpoint['model_state_dict'])
+        starting_epoch = int(checkpoint.get('epoch', -1)) + 1
+        print('loading stats of epoch {}'.format(starting_epoch))
     elif args.synthetic:
         model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=model.max_cats))
     if text_encoder is not None:
         model.text_encoder = text_encoder
     save_dir = os.path.join(args.out_dir, args.experiment, "model_ckpt")
     best_valid, best_cfd = float('inf'), float('inf')
-    for e in range(args.epochs):
+    for e in range(starting_epoch, args.epochs):
         print('Training epoch {}'.format(e))
         t0 = time.time()
         if args.forward_only:
@@ -164,7 +168,7 @@ def main(argv=None):
             if cfd < best_cfd:
                 print("Updated best model due to new highest total_cfd. Current epoch: {}".format(e))
                 best_cfd = cfd
-                torch.save(data, os.path.join(save_dir, 'best_model_cfd.pt'))
+                torch.save(dict(data, total_cfd=cfd), os.path.join(save_dir, 'best_model_cfd.pt'))
     return 0
 
 

@@ -28,6 +28,8 @@ Golden sets:
       embed_text 768 -> 384 -> 256 -> 128): one forward at B = 2 with injected (B,768) features -- outputs, saved_cat, guiding points,
       the embedding tap.  (The encoder itself -- transformers' bert-base-uncased -- is third party and not reachable offline: the
       boundary is its (B,768) feature, like CLIP's (B,512).)
+  G14 BASELINE configs[1] at depth: B = 16, C = 43, first K = 5 steps (t = 999..995) and last K = 5 steps (init_image + skip_timesteps
+      = 995, t = 4..0) of p_sample_loop, per-step samples + saved_cat + guiding points.
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
 import argparse
@@ -494,6 +496,34 @@ def g13():
     hook.remove()
     save("g13_forward_clipdim768", x_in=x_in, t=t, starts=starts, out_cat=out_cat, out=out, guiding=m.saved_guiding_points, x_mutated=x,
          enc=taps["enc"], meta=np.array([B, C, D, 131, 132]))
+
+
+def g14():
+    """BASELINE configs[1] at the depth SURVEY.md 8(d) "Config 2" asks for: B = 16, C = 43, the FIRST K = 5 steps of the stock loop
+    (t = 999..995, from x_T) and the LAST K = 5 steps (init_image + skip_timesteps = 995: q_sample to t = 4, then t = 4..0 with the
+    coef1[0] = 1 / no-noise end).  Per step: the sample on every 8th point (the last step in full); after the last forward saved_cat
+    and every 2nd guiding point.  Two files of ~0.4 MB."""
+    diff = ref_diffusion()
+    B, C, K = 16, 43, 5
+    m = ref_model(C)
+    bt = make_synthetic_batch(B, seed=141, max_cats=C)
+    clip._model.features = bt["text_features"]
+    args = (m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], ["p"] * B)
+    for tag, seed, kw in (("first", 142, {}), ("last", 143, {"skip_timesteps": 1000 - K})):
+        extra = {}
+        if tag == "last":
+            g = torch.Generator().manual_seed(144)
+            kw["init_image"] = 0.7 * torch.randn(B, 1024, 3, generator=g)
+            extra["init_seed"] = np.array(144)
+        torch.manual_seed(seed)
+        t0, got = time.time(), []
+        for i, out in enumerate(diff.p_sample_loop_progressive(*args, clip_denoised=False, **kw)):
+            got.append(out["sample"].clone())
+            if len(got) == K:
+                break
+        print("g14 %s: %.1f s" % (tag, time.time() - t0))
+        save("g14_config2_%s" % tag, steps_sub=torch.stack(got)[:, :, ::8], final=got[-1], saved_cat=m.saved_cat,
+             guiding_sub=m.saved_guiding_points[:, ::2], meta=np.array([B, C, K, seed, 141]), **extra)
 
 
 def long_chain(steps):

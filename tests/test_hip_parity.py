@@ -475,6 +475,57 @@ def test_config2_b16_c43_chain_vs_reference_golden(golden, precision):
     assert maxabs(m.saved_guiding_points, T(g["guiding"])) <= 1e-3
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("tag", ["first", "last"])
+def test_config2_b16_c43_first_and_last_five_steps_vs_reference_golden(golden, precision, tag):
+    """BASELINE configs[1] at the depth SURVEY.md 8(d) "Config 2" specifies (G14, recorded from the real reference): B = 16, C = 43,
+    the FIRST K = 5 steps of the stock loop (t = 999..995 from x_T) and the LAST K = 5 (init_image + skip_timesteps = 995: t = 4..0,
+    ending on coef1[0] = 1 without noise) -- every step's sample, saved_cat and the guiding points, through the per-step progressive
+    loop AND through the K-steps-per-call path (bit-equal to each other)."""
+    from test_oracle_golden import g14_args, g14_check
+    g = golden("g14_config2_%s" % tag)
+    B, C_, K, seed, bt_seed, kw = g14_args(g, tag)
+    assert (B, C_, K) == (16, 43, 5)
+    if "init_image" in kw:
+        kw["init_image"] = kw["init_image"].to(DEV)
+    m, diff = create_model_and_diffusion("proxd", max_cats=C_, precision=precision)
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C_))
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=bt_seed, max_cats=C_).items()}
+    args = (m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"])
+    torch.manual_seed(seed)
+    got = []
+    for o in diff.p_sample_loop_progressive(*args, clip_denoised=False, **kw):
+        got.append(o["sample"].clone())
+        if len(got) == K:
+            break
+    worst = g14_check(g, got, m.saved_cat, m.saved_guiding_points, 1e-3)
+    print("g14 %s %s: worst per-step max-abs %.2e" % (tag, precision, worst))
+    cat_loop, guid_loop = m.saved_cat.clone(), m.saved_guiding_points.clone()
+    if tag == "last":        # the drop-in call itself: bulk loop, loop-invariant schedule
+        torch.manual_seed(seed)
+        bulk = diff.p_sample_loop(*args, clip_denoised=False, **kw)
+        assert torch.equal(bulk, got[-1]) and torch.equal(m.saved_cat, cat_loop) and torch.equal(m.saved_guiding_points, guid_loop)
+        return
+    # first K steps in ONE library call per schedule (what a chunk of the bulk loop is): draws in the reference's order (SURVEY H1)
+    torch.manual_seed(seed)
+    x_T = torch.randn(B, 1024, 3)
+    starts, noise = [], []
+    for _ in range(K):
+        starts.append(torch.stack(cpu_ref.draw_fps_starts(B * 9)))
+        noise.append(torch.randn(B, 1024, 3))
+    d_starts, d_noise = torch.stack(starts).to(DEV).contiguous(), torch.stack(noise).to(DEV).contiguous()
+    for entry in ("lsdm_sample_steps", "lsdm_sample_steps_invariant"):
+        x = x_T.clone().to(DEV)
+        out_cat = torch.empty(B, 1, C_, device=DEV)
+        out_x0, out_g = torch.empty_like(x), torch.empty_like(x)
+        m._ctx.call(entry, _lib.MODE_P_SAMPLE, 0.0, B, 999, K, x.data_ptr(), bt["mask"].data_ptr(), bt["given_objs"].data_ptr(),
+                    bt["given_cats"].data_ptr(), bt["text_features"].data_ptr(), d_starts.data_ptr(), d_noise.data_ptr(),
+                    out_cat.data_ptr(), out_x0.data_ptr(), out_g.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert torch.equal(x, got[-1]), entry
+        assert torch.equal(out_cat, cat_loop) and torch.equal(out_g, guid_loop), entry
+
+
 def test_sample_steps_entry_point_equals_python_loop(sd13):
     """lsdm_sample_steps (device-resident RNG draws, K steps in one call) == K calls of lsdm_step."""
     B, K = 2, 3

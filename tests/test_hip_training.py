@@ -224,6 +224,18 @@ def test_train_cli_steps_the_optimizer_and_the_loss_goes_down(tmp_path, capsys):
     assert len(moved) > 150
     model, diffusion = create_model_and_diffusion("proxd", device=0)
     model.load_state_dict(ck["model_state_dict"])
+    best = torch.load(tmp_path / "out" / "t" / "model_ckpt" / "best_model_cfd.pt", map_location="cpu")
+    assert "total_cfd" in best and best["epoch"] == 2                 # run/train_sdm.py:326-335
+    # --load_ckpt resumes at checkpoint['epoch'] + 1 (run/train_sdm.py:284-289): epochs 3..4 run, epoch_0002.pt is not rewritten
+    before = os.path.getmtime(tmp_path / "out" / "t" / "model_ckpt" / "epoch_0002.pt")
+    rc = cli.main(["--train_data_dir", str(tmp_path / "tr"), "--valid_data_dir", str(tmp_path / "va"), "--synthetic", "8", "--epochs", "5",
+                   "--batch_size", "4", "--lr", "1e-3", "--save_interval", "5", "--valid_skip_timesteps", "997", "--out_dir", str(tmp_path / "out"),
+                   "--experiment", "t", "--device", "cuda:0", "--load_ckpt", str(tmp_path / "out" / "t" / "model_ckpt" / "epoch_0002.pt")])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "loading stats of epoch 3" in out and "Training epoch 3" in out and "Training epoch 4" in out and "Training epoch 0" not in out
+    assert os.path.getmtime(tmp_path / "out" / "t" / "model_ckpt" / "epoch_0002.pt") == before
+    assert torch.load(tmp_path / "out" / "t" / "model_ckpt" / "epoch_0004.pt", map_location="cpu")["epoch"] == 4
 
 
 def test_train_cli_forward_only_reports_the_eval_objective(tmp_path, capsys):

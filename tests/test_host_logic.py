@@ -28,6 +28,16 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "liblsdm_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    # ... and nothing else: the library is built with -fvisibility=hidden and linked through csrc/exports.map, so its dynamic symbol
+    # table is exactly the C ABI (no mangled launch helpers, kernel handles or libstdc++ instantiations)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    dynamic = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert dynamic == declared, sorted(dynamic ^ declared)[:10]
+    for name in sorted(declared):
+        assert re.search(r"^LSDM_API [^;]*\b%s\(" % name, header, flags=re.M), name
 
 
 def test_no_cpu_fallback():

@@ -110,18 +110,57 @@ def test_g3_square_distance_rounding(golden):
 
 
 # ---------------------------------------------------------------- G4
-def test_g4_config2_b16_c43(golden):
-    """BASELINE configs[1] shapes (B = 16, 43 classes): last of K = 2 steps recorded from the real reference."""
-    g = golden("g4_chain_b16c43")
+class _Enough(Exception):
+    pass
+
+
+def g14_args(g, tag):
+    """The call oracle/make_goldens.py::g14 made on the reference: (B, C, K, seed, batch seed, loop keyword arguments)."""
     B, C, K, seed, bt_seed = [int(v) for v in g["meta"]]
+    kw = {}
+    if tag == "last":
+        gen = torch.Generator().manual_seed(int(g["init_seed"]))
+        kw = dict(kw, init_image=0.7 * torch.randn(B, 1024, 3, generator=gen), skip_timesteps=1000 - K)
+    return B, C, K, seed, bt_seed, kw
+
+
+def g14_check(g, steps, saved_cat, guiding, tol):
+    """steps: the K per-step samples (B,1024,3); per-step samples on every 8th point, the last one in full, saved_cat, every 2nd
+    guiding point -- against the record of the real reference."""
+    K = int(g["meta"][2])
+    assert len(steps) == K
+    worst = 0.0
+    for k in range(K):
+        worst = max(worst, maxabs(steps[k][:, ::8].cpu(), g["steps_sub"][k]))
+        assert worst <= tol, (k, worst)
+    assert maxabs(steps[-1].cpu(), g["final"]) <= tol
+    assert maxabs(saved_cat.cpu(), g["saved_cat"]) <= 1e-6
+    assert maxabs(guiding[:, ::2].cpu(), g["guiding_sub"]) <= tol
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["first", "last"])
+def test_g14_config2_depth(golden, tag):
+    """BASELINE configs[1] (B = 16, 43 classes) at the depth SURVEY.md 8(d) asks for: the first K = 5 steps of the stock loop
+    (t = 999..995) and the last K = 5 (init_image + skip_timesteps = 995, t = 4..0), recorded from the real reference."""
+    g = golden("g14_config2_%s" % tag)
+    B, C, K, seed, bt_seed, kw = g14_args(g, tag)
     sd = make_synthetic_state_dict(seed=0, max_cats=C)
     bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
     smp = cpu_ref.Sampler(sd)
+    got = []
+
+    def on_step(i, o):
+        got.append(o["sample"].clone())
+        if len(got) == K:
+            raise _Enough
+
     torch.manual_seed(seed)
-    final = smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=1000 - K)
-    assert maxabs(final, g["samples"][-1]) <= 1e-4
-    assert maxabs(smp.saved_cat, g["saved_cat"]) <= 1e-6
-    assert maxabs(smp.saved_guiding_points, g["guiding"]) <= 1e-4
+    try:
+        smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], on_step=on_step, **kw)
+    except _Enough:
+        pass
+    g14_check(g, got, smp.saved_cat, smp.saved_guiding_points, 1e-4)
 
 
 @pytest.mark.parametrize("tag", ["b1", "b3"])

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from lsdm_amd.parallel import gather_samples, shard_range, shard_seed
+from lsdm_amd.parallel import gather_results, gather_samples, shard_range, shard_seed
 
 
 def _free_port():
@@ -31,12 +31,15 @@ def _worker(rank, world, port, q):
     sd = make_synthetic_state_dict(seed=0)
     bt = make_synthetic_batch(B, seed=shard_seed(base, rank))
     torch.manual_seed(shard_seed(base, rank))
-    local = cpu_ref.Sampler(sd).sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"],
-                                            skip_timesteps=1000 - K)
-    gathered = gather_samples(local, dist)
+    smp = cpu_ref.Sampler(sd)
+    local = smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=1000 - K)
+    # what the caller reads after the loop (run/test_sdm.py:184-202), in one packed collective
+    gathered, cat, guid = gather_results(local, smp.saved_cat, smp.saved_guiding_points, dist)
+    only = gather_results(local, None, None, dist)
+    assert only[1] is None and only[2] is None and torch.equal(only[0], gathered)
     dist.barrier()
     if rank == 0:
-        q.put(gathered.numpy())
+        q.put((gathered.numpy(), cat.numpy(), guid.numpy()))
     dist.destroy_process_group()
 
 
@@ -47,11 +50,11 @@ def test_sharded_chains_allgather_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=600)
+    got, cat, guid = q.get(timeout=600)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got.shape == (2, 1024, 3)
+    assert got.shape == (2, 1024, 3) and cat.shape == (2, 1, 13) and guid.shape == (2, 1024, 3)
     # oracle for rank r = the single-process run with seed base + r (no cross-rank coupling)
     torch.set_grad_enabled(False)
     from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
@@ -60,9 +63,11 @@ def test_sharded_chains_allgather_world2():
     for r in range(world):
         bt = make_synthetic_batch(1, seed=40 + r)
         torch.manual_seed(40 + r)
-        ref = cpu_ref.Sampler(sd).sample_loop([1, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"],
-                                              skip_timesteps=999)
+        smp = cpu_ref.Sampler(sd)
+        ref = smp.sample_loop([1, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], skip_timesteps=999)
         assert float((torch.from_numpy(got[r]) - ref[0]).abs().max()) <= 1e-5
+        assert float((torch.from_numpy(cat[r]) - smp.saved_cat[0]).abs().max()) <= 1e-6
+        assert float((torch.from_numpy(guid[r]) - smp.saved_guiding_points[0]).abs().max()) <= 1e-5
 
 
 def _ragged_worker(rank, world, port, q):
@@ -87,6 +92,16 @@ def _ragged_worker(rank, world, port, q):
     l1, h1 = shard_range(1, rank, world)
     one = gather_samples(units[l1:h1], dist, total=1)
     assert one.shape == (1, 2, 3) and bool((one == units[:1]).all())
+    # the packed collective on a ragged split: three tensors of different widths / dtypes, one all-gather, split back per chain
+    cats = torch.arange(total * 4, dtype=torch.float32).view(total, 1, 4) * 0.5
+    gpts = -units
+    s3, c3, g3 = gather_results(units[lo:hi], cats[lo:hi], gpts[lo:hi], dist, total=total)
+    assert torch.equal(s3, units) and torch.equal(c3, cats) and torch.equal(g3, gpts)
+    try:
+        gather_results(units[lo:hi], cats[:1 + hi - lo], None, dist, total=total)
+        raise AssertionError("mismatched chain counts accepted")
+    except ValueError:
+        pass
     dist.barrier()
     if rank == 0:
         q.put((got.numpy(), bad))
