@@ -43,44 +43,59 @@ GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
 # them separately (profiles/r01_*_kernel_stats.md), the HIP-event interval of the stage covers both.
 STAGE_KERNELS_BF16X3 = {
     "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64> (once per call in the loop-invariant schedule)",
-    "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128> "
-                               "(ONE launch per group of 7 steps in the loop-invariant schedule; avg_launch_ms is per step covered)",
+    "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128>; "
+                               "in the loop-invariant schedule: once per call the r = 0.2 ball of every source point (ball_query_kernel<1024>, ordered "
+                               "scan) + memo_src_kernel + sa_ur_kernel on the list of uncrowded points (the memo F2), then per GROUP of steps (up to "
+                               "LSDM_GROUP, default 28 / 32) memo_cent_kernel (copies F2 rows, lists the crowded centroids) + ONE sa_ur_kernel launch "
+                               "over that list; avg_launch_ms is per step covered",
     "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_p_kernel<128,128,256,12> (epilogues software-pipelined against the next block's MFMAs)",
     "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_w_kernel",
     "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y); one launch per "
-                      "group of 7 steps in the loop-invariant schedule",
+                      "group of steps (up to LSDM_GROUP, default 28 / 32) in the loop-invariant schedule",
     "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
     "fp_kernel<fp2>": "fp_pre_kernel<64,256,128>",
     "fp_kernel<fp1+head>": "fp_s_kernel<8,2>",
-    "denoise_kernel": "denoise_r_kernel (guiding-point pass on the call's last forward only in the loop-invariant schedule)",
+    "denoise_kernel": "denoise_r_kernel (one launch per group of steps and the guiding-point pass on the call's last forward only in the "
+                      "loop-invariant schedule)",
 }
 GFLOP_PER_SAMPLE_STEP_HOISTED = 0.740   # the x/t-dependent part only
 
 
 def cpu_baseline(batch, steps, C):
-    """Times the CPU oracle on `steps` consecutive p_sample steps at a small batch; returns batch-steps/s scaled to B=64."""
+    """Times the CPU oracle: one p_sample step at B = 16 (BASELINE configs[1]'s batch, the largest batch the reference itself was measured
+    at) -> `value`; and `steps` consecutive steps at the small batch `batch` beside it.  Both scaled to batches of 64 chains."""
     from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
     from oracle import cpu_ref
-    # 16 threads is the fastest setting for the oracle's many small ATen ops on the 256-core GPU-box host
-    # (8: 2.3 s, 16: 2.0 s, 32: 2.2 s, 64: 3.6 s, 128+: minutes per B=2 step; tools/cpu_threads_probe.py)
+    # BASELINE.md 3 says all host cores; on the 256-core GPU-box host that is minutes per step for the oracle's many small ATen ops.
+    # 16 threads is the fastest setting (tools/cpu_threads_probe.py, kept as profiles/r04_cpu_threads.txt: 8: 2.3 s, 16: 2.0 s, 32: 2.2 s,
+    # 64: 3.6 s per B = 2 step, 128+: minutes), so the baseline is the oracle at ITS best thread count, stated in `cores`.
     threads = min(16, os.cpu_count())
     torch.set_num_threads(threads)
     sd = make_synthetic_state_dict(seed=0, max_cats=C)
-    bt = make_synthetic_batch(batch, seed=1, max_cats=C, num_objects=8)
     smp = cpu_ref.Sampler(sd)
-    torch.manual_seed(1)
-    x = torch.randn(batch, 1024, 3)
-    t = torch.tensor([999] * batch)
-    out = smp.p_sample(x, bt["mask"], t, bt["given_objs"], bt["given_cats"], bt["text_features"])  # warm-up
-    t0 = time.time()
-    for k in range(steps):
-        out = smp.p_sample(out["sample"], bt["mask"], t - 1 - k, bt["given_objs"], bt["given_cats"], bt["text_features"])
-    dt = time.time() - t0
-    sample_steps = batch * steps / dt
-    return {"value": sample_steps / 64.0, "unit": "denoising-steps/sec (batch of 64 chains)", "cores": threads,
-            "kind": "port", "sample_steps_per_s": sample_steps,
-            "sample": "%d p_sample steps at B=%d (8 objects, C=%d) with the torch-CPU oracle on %d of %d host cores, %.1f s; "
-                      "scaled to B=64 by /64" % (steps, batch, C, threads, os.cpu_count(), dt)}
+
+    def timed(b, k):
+        bt = make_synthetic_batch(b, seed=1, max_cats=C, num_objects=8)
+        torch.manual_seed(1)
+        x = torch.randn(b, 1024, 3)
+        t = torch.tensor([999] * b)
+        t0 = time.time()
+        for j in range(k):
+            x = smp.p_sample(x, bt["mask"], t - j, bt["given_objs"], bt["given_cats"], bt["text_features"])["sample"]
+        return time.time() - t0
+
+    timed(batch, 1)                     # warm-up (thread pool, allocator)
+    dt_small = timed(batch, steps)
+    dt16 = timed(16, 1)
+    ss16, ss_small = 16 / dt16, batch * steps / dt_small
+    return {"value": ss16 / 64.0, "unit": "denoising-steps/sec (batch of 64 chains)", "cores": threads,
+            "kind": "port", "sample_steps_per_s": ss16,
+            "sample": "1 p_sample step at B=16 (8 objects, C=%d; BASELINE configs[1]'s batch) with the torch-CPU oracle on %d of %d host cores, "
+                      "%.1f s, after a warm-up step at B=%d; scaled to B=64 by /4 (cost per chain is flat in B: see small_batch)"
+                      % (C, threads, os.cpu_count(), dt16, batch),
+            "small_batch": {"value": ss_small / 64.0, "sample_steps_per_s": ss_small,
+                            "sample": "%d p_sample steps at B=%d, %.1f s" % (steps, batch, dt_small)},
+            "thread_sweep": "profiles/r04_cpu_threads.txt"}
 
 
 def parity_check(precision, dev):
@@ -183,7 +198,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=5, help="timed oracle steps after 1 warm-up (BASELINE.md §3)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps at --cpu-batch after 1 warm-up (BASELINE.md §3); one more step is timed at B=16")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -294,13 +309,31 @@ def main():
         r.run(T - 1, 0, KH, hoisted=True, x=xh, noise=nh)
         torch.cuda.synchronize()
         dth = time.perf_counter() - t1
+        # executed work of the same schedule from a profiled (shorter) call: per-step stages vs the once-per-call conditioning
+        KP = min(KH, 112)
+        r.ctx.profile_begin()
+        r.run(T - 1, 0, KP, hoisted=True, x=xh, noise=nh)
+        torch.cuda.synchronize()
+        ph = r.ctx.profile_end()
+        per_step_names = ("denoise_kernel", "upsample12_kernel", "cond_kernel", "scene_attn_kernel")
+        ex_h_step = sum(2.0 * q["executed_macs"] for q in ph if q["name"] in per_step_names) / KP / 1e9
+        ex_h_call = sum(2.0 * q["executed_macs"] for q in ph if q["name"] not in per_step_names) / 1e9
         del nh
         hoisted = {"value": KH / dth, "unit": "denoising-steps/sec per GPU (B=%d)" % B, "steps": KH, "ms_per_step": dth / KH * 1e3,
                    "dtype": a.precision,
                    "roofline": {"bound": "mfma", "achieved": GFLOP_PER_SAMPLE_STEP_HOISTED * B / (dth / KH * 1e3), "peak": PEAK_TFLOPS[a.precision],
                                 "unit": "TFLOP/s", "frac": GFLOP_PER_SAMPLE_STEP_HOISTED * B / (dth / KH * 1e3) / PEAK_TFLOPS[a.precision],
                                 "note": "0.740 GFLOP per sample-step (SURVEY.md 8d: the x/t-dependent part) x B / ms_per_step; the once-per-call "
-                                        "conditioning (13.8 GFLOP per sample) is inside the timed call and not counted as work"},
+                                        "conditioning (13.8 GFLOP per sample) is inside the timed call and not counted as work",
+                                "executed_gflop": ex_h_step + ex_h_call / KH, "executed_gflop_per_step_stages": ex_h_step,
+                                "executed_gflop_once_per_call": ex_h_call,
+                                "frac_executed": (ex_h_step + ex_h_call / KH) / (dth / KH * 1e3) / PEAK_TFLOPS[a.precision],
+                                "mfma_issue_frac": (ex_h_step + ex_h_call / KH) / (dth / KH * 1e3) / PEAK_TFLOPS[a.precision]
+                                                   * (3.0 if a.precision == "bf16x3" else 1.0),
+                                "executed_note": "products issued per step of the batch (denoiser first pass + its shared S block, the timestep "
+                                                 "half of the up-sampling / combine_extraction ONCE per step for the whole batch, the guiding-point "
+                                                 "pass once per call) + the once-per-call conditioning / KH; the reference's 0.740 GFLOP counts the "
+                                                 "up-sampling per chain and the guiding pass per step"},
                    "note": "NOT the headline metric: conditioning (human branch, PointNet++ geometry + dense stages, scene attention) "
                            "evaluated once per call with pinned FPS starts, included in the timed call; equals the reference only with "
                            "its per-step FPS re-draw pinned (tests: g6_hoisted golden)"}
@@ -361,8 +394,12 @@ def main():
             continue
         avg_ms = pr["total_ms"] / pr["launches"]
         flops = 2.0 * pr["macs_per_unit"] * per_launch_units(pr["name"])
+        # executed work (include/lsdm_hip.h lsdm_profile_executed): products the stage's launches issued to the matrix pipe over the
+        # window; a stage without an explicit figure (no matrix work, or a non-default kernel) reports its algorithmic count
+        ex_flop = 2.0 * pr["executed_macs"] if pr["executed_macs"] > 0 else flops * pr["launches"]
         rows.append(dict(name=pr["name"], avg_ms=avg_ms, launches=pr["launches"], total_ms=pr["total_ms"],
-                         tflops=flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, gflop=flops / 1e9))
+                         tflops=flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0, gflop=flops / 1e9,
+                         ex_gflop_step=ex_flop / K / 1e9, ex_tflops=ex_flop / (pr["total_ms"] * 1e-3) / 1e12 if pr["total_ms"] > 0 else 0.0))
     rows.sort(key=lambda q: -q["total_ms"])
     # the dominant MFMA kernel = the matrix stage with the largest share of the timed region (FPS etc. carry no matrix work;
     # once-per-call launches such as sa1 in the loop-invariant schedule have long launches but a small share)
@@ -375,6 +412,9 @@ def main():
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(a.precision, {}).get(dom["name"])
     whole = GFLOP_PER_SAMPLE_STEP * B / step_ms
+    issue = 3.0 if a.precision == "bf16x3" else 1.0          # matrix instructions issued per executed product
+    ex_step_gflop = sum(q["ex_gflop_step"] for q in mfma_rows)
+    whole_ex = ex_step_gflop / step_ms
     res = {
         "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
         "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch per GPU; value sums the GPUs)",
@@ -410,13 +450,24 @@ def main():
                                          "a side stream of the library, LSDM_STREAMS=%s); profiles/ are recorded with LSDM_STREAMS=1 for the same reason"
                                          % os.environ.get("LSDM_STREAMS", "2"),
                      "algorithmic_gflop_per_launch": dom["gflop"],
+                     "executed_gflop": dom["ex_gflop_step"], "frac_executed": dom["ex_tflops"] / peak, "mfma_issue_frac": dom["ex_tflops"] * issue / peak,
+                     "executed_is": "products the stage's launches ISSUE to the matrix pipe per step (lsdm_profile_executed: K padded to the k-step, "
+                                    "split first layers, work the schedule evaluates once per call counted once) x 2 FLOP; frac_executed = that / "
+                                    "stage time / peak; mfma_issue_frac = x%d matrix instructions per product (the figure PMC's MFMA-pipe "
+                                    "utilisation measures against the actual clock); `frac` above stays reference FLOPs / time / peak" % int(issue),
                      "peak_note": {"f32": "dense f32-input MFMA (v_mfma_f32_32x32x2_f32)",
                                    "bf16x3": "dense bf16 MFMA; 3 MFMAs per algorithmic product -> attainable frac 0.333",
                                    "bf16": "dense bf16 MFMA"}[a.precision],
                      "whole_step": {"achieved": whole, "frac": whole / peak, "frac_of_f32_mfma_peak": whole / PEAK_TFLOPS["f32"],
-                                    "note": "14.58 GFLOP per sample-step (SURVEY.md 8d) x B / ms_per_step"},
+                                    "note": "14.58 GFLOP per sample-step (SURVEY.md 8d) x B / ms_per_step",
+                                    "executed_gflop": ex_step_gflop, "executed_gflop_per_sample_step": ex_step_gflop / B,
+                                    "frac_executed": whole_ex / peak, "mfma_issue_frac": whole_ex * issue / peak,
+                                    "executed_note": "sum of the matrix stages' executed products per step of the instrumented pass (once-per-call "
+                                                     "work divided by the call's %d steps) x 2 FLOP / ms_per_step of the timed region" % K},
                      "kernels": [{"name": q["name"], "launches": q["launches"], "avg_ms": round(q["avg_ms"], 4),
-                                  "ms_per_step": round(q["total_ms"] / K, 4), "tflops": round(q["tflops"], 2)} for q in rows]},
+                                  "ms_per_step": round(q["total_ms"] / K, 4), "tflops": round(q["tflops"], 2),
+                                  "executed_gflop": round(q["ex_gflop_step"], 3), "tflops_executed": round(q["ex_tflops"], 2),
+                                  "frac_executed": round(q["ex_tflops"] / peak, 4), "mfma_issue_frac": round(q["ex_tflops"] * issue / peak, 4)} for q in rows]},
     }
     if hoisted:
         res["hoisted_conditioning"] = hoisted

@@ -171,6 +171,12 @@ LSDM_API int lsdm_nn_distance(lsdm_ctx* ctx, const float* a, int na, const float
  * (the others) -- the figures of DESIGN.md / SURVEY.md 8(d).  Arrays must hold `capacity` >= 23 entries. */
 LSDM_API int lsdm_profile_begin(lsdm_ctx* ctx);
 LSDM_API int lsdm_profile_end(lsdm_ctx* ctx, int capacity, double* total_ms, int64_t* launches, double* macs_per_unit);
+/* executed_macs[k] = the multiply-accumulates the launches of stage k ISSUED to the matrix pipe over the window just closed by
+ * lsdm_profile_end, summed over all clouds / chains and launches, counted as products (MFMA MACs / 3 in the bf16x3 mode): K padded to
+ * the instruction's k-step, 3-channel output layers padded to one channel block, linear first layers split across the grouping /
+ * the concat boundary, work the loop-invariant schedule evaluates once per call counted once.  The reference has no
+ * counterpart: its FLOPs are lsdm_profile_end's macs_per_unit. */
+LSDM_API int lsdm_profile_executed(lsdm_ctx* ctx, int capacity, double* executed_macs);
 LSDM_API const char* lsdm_profile_kernel_name(int k);
 
 /* ---- training objective: replaces diffusion.training_losses(...) + loss.backward()  (gaussian_diffusion.py:1256-1342,

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "lsdm_workspace_tensor": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "lsdm_profile_begin": (_i, [_vp]),
     "lsdm_profile_end": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "lsdm_profile_executed": (_i, [_vp, _i, _vp]),
     "lsdm_profile_kernel_name": (C.c_char_p, [_i]),
     "lsdm_train_create": (_i, [C.POINTER(_vp), _i, _i]),
     "lsdm_train_destroy": (_i, [_vp]),
@@ -107,14 +108,17 @@ class Context:
         self.call("lsdm_profile_begin")
 
     def profile_end(self):
-        """-> list of dict(name, total_ms, launches, macs_per_unit) per kernel of the hot path."""
+        """-> list of dict(name, total_ms, launches, macs_per_unit, executed_macs) per kernel of the hot path (executed_macs: total
+        over the window, see include/lsdm_hip.h)."""
         cap = 64
         ms, n, macs = (C.c_double * cap)(), (C.c_int64 * cap)(), (C.c_double * cap)()
         k = self.lib.lsdm_profile_end(self.handle, cap, ms, n, macs)
         if k < 0:
             self.check(k, "lsdm_profile_end")
-        return [dict(name=self.lib.lsdm_profile_kernel_name(i).decode(), total_ms=ms[i], launches=n[i], macs_per_unit=macs[i])
-                for i in range(k)]
+        ex = (C.c_double * cap)()
+        self.check(min(0, self.lib.lsdm_profile_executed(self.handle, cap, ex)), "lsdm_profile_executed")
+        return [dict(name=self.lib.lsdm_profile_kernel_name(i).decode(), total_ms=ms[i], launches=n[i], macs_per_unit=macs[i],
+                     executed_macs=ex[i]) for i in range(k)]
 
     def close(self):
         if getattr(self, "handle", None):

@@ -176,6 +176,7 @@ struct lsdm_ctx {
     int inv_side = getenv("LSDM_INV_SIDE") ? atoi(getenv("LSDM_INV_SIDE")) : 1;      // A/B switch: 0 = the per-call level-1 work on the caller's stream
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
+    double prof_exec[64] = {0};                      // executed MACs per stage id over the profiled window (prof_exec())
 };
 
 namespace {
@@ -240,6 +241,34 @@ void prof_mark(lsdm_ctx* c, int id, hipStream_t st, int weight = 1) {
     c->prof_w[c->prof_cur] = weight;
     (void)hipEventRecord(c->prof_ev[c->prof_cur++], st);
 }
+
+// Executed-work accounting of the profiled window (bench.py "executed_gflop"): the MACs the launches of a stage ISSUE to the matrix pipe,
+// counted as products (MFMA MACs / 3 in bf16x3) -- K padded to the 16-wide k-step of the bf16 cores, the 3-channel output layers padded to one
+// 32-channel block, first SA / FP layers split (encoder_u.hip), work skipped by the loop-invariant schedule not counted.  Cross-checked
+// against SQ_INSTS_MFMA x 16384 / 3 of the PMC pass (profiles/).  Stages without an explicit figure report their algorithmic MACs.
+void prof_exec(lsdm_ctx* c, int id, double macs) {
+    if (c->prof_on && id >= 0 && id < 64) c->prof_exec[id] += macs;
+}
+// ... with a count that lives on the device (the sa2 memo's work lists): macs_per_count x *counter, read back right away (the profiled
+// pass keeps every stage on one stream and is not the timed region)
+void prof_exec_dev(lsdm_ctx* c, int id, const int* counter, double macs_per_count, hipStream_t st) {
+    if (!c->prof_on) return;
+    int v = 0;
+    if (hipMemcpyAsync(&v, counter, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
+    prof_exec(c, id, macs_per_count * v);
+}
+namespace xm {     // per cloud (encoder) / per chain or row (others), split-bf16 kernels in their default configuration
+constexpr double SA1 = 32768.0 * (16 * 32 + 32 * 32 + 32 * 64);
+constexpr double SA2_UV = 1024.0 * 64 * 64, SA2_CENT = 32.0 * (64 * 64 + 64 * 128), SA2_FULL = 8192.0 * (80 * 64 + 64 * 64 + 64 * 128);
+constexpr double SA3 = 256.0 * 128 * 128 + 2048.0 * (128 * 128 + 128 * 256), SA3_FULL = 2048.0 * (144 * 128 + 128 * 128 + 128 * 256);
+constexpr double SA4 = 64.0 * 256 * 256 + 512.0 * (256 * 256 + 256 * 512), SA4_FULL = 512.0 * (272 * 256 + 256 * 256 + 256 * 512);
+constexpr double FP4_PRE = 16.0 * 512 * 256 + 64.0 * 3 * 256 * 256, FP4_Y = 64.0 * (768 * 256 + 2 * 256 * 256), FP4_FULL = 64.0 * (768 * 256 + 256 * 256);
+constexpr double FP3_PRE = 256.0 * (128 * 256 + 256 * 256), FP3_OWN_Y = 64.0 * 256 * 256, FP3_NEXT_Y = 256.0 * 256 * 256, FP3_FULL = 256.0 * (384 * 256 + 256 * 256);
+constexpr double FP2_PRE = 1024.0 * (64 * 256 + 256 * 128), FP2_OWN_Y = 256.0 * 256 * 256, FP2_FULL = 1024.0 * (320 * 256 + 256 * 128);
+constexpr double FP1 = 1024.0 * (4 * 128 * 128 + 128 * 32);
+constexpr double DEN_PASS = 32.0 * 132 * 16384, DEN_S = 32.0 * 48 * 16384;   // denoise_reg.hip RL<>: products per 32-point block x 32 blocks per chain
+constexpr double UP12_HALF = 128.0 * 128 * 512, CTEXT_HALF = 1024.0 * 128 * 512 + 1024.0 * 128 * 128;   // per row (sample or step), one half of the 256 rows
+}  // namespace xm
 
 int check_launch(lsdm_ctx* c, const char* what) {
     hipError_t e = hipGetLastError();
@@ -551,7 +580,9 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         for (int l = skip_sa1 ? 1 : 0; l < 4; ++l) {
             prof_mark(c, K_SA1 + l, st);
             launch_sa(l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa[l], c->feat[l], st);
+            prof_exec(c, K_SA1 + l, nc * kKernelMacs[K_SA1 + l]);
         }
+        for (int k = K_FP4; k <= K_FP1; ++k) prof_exec(c, k, nc * kKernelMacs[k]);
         prof_mark(c, K_FP4, st);
         launch_fp(4, nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp[0], nullptr, c->fpo4, st);
         prof_mark(c, K_FP3, st);
@@ -578,17 +609,24 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
             const bool src = skip_sa1 && inv_in_source_order(c);
             if (!src) launch_lin_u(1, nc * 1024, c->feat[0], lvl_xyz[1], c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
             launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
+            prof_exec(c, K_SA1 + 1, nc * ((src ? 0.0 : xm::SA2_UV) + 256 * xm::SA2_CENT));
         } else if (np == 2 && l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
             launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
             launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+            prof_exec(c, K_SA1 + 2, nc * xm::SA3);
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
             launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
-        } else if (l < c->sa_reg)
-            launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
-        else
-            launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
+            prof_exec(c, K_SA1 + 3, nc * xm::SA4);
+        } else {
+            if (l < c->sa_reg)
+                launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
+            else
+                launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
+            const double full[4] = {xm::SA1, xm::SA2_FULL, xm::SA3_FULL, xm::SA4_FULL};
+            prof_exec(c, K_SA1 + l, nc * full[l]);
+        }
     }
     const Lin head2{c->head[1].w, c->head[1].b};
     prof_mark(c, K_FP4, st);
@@ -602,12 +640,14 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
                       c->fp_y[0], c->fp_ybuf[0], c->keep_taps, st);
     else if (fuse_y) launch_fp4_y(nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], c->fp_y[0], c->fpo4, c->fp_ybuf[0], c->keep_taps, st);
     else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
+    prof_exec(c, K_FP4, nc * (fuse_y && c->fp4_pre ? xm::FP4_PRE : (fuse_y ? xm::FP4_Y : xm::FP4_FULL)));
     prof_mark(c, K_FP3, st);
     if (np == 2 && c->fp_pre >= 2)
         launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, fuse_y,
                       c->fp_y[1], fuse_y ? c->fp_ybuf[1] : nullptr, c->keep_taps, st);
     else
         launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
+    prof_exec(c, K_FP3, nc * (np == 2 && c->fp_pre >= 2 ? xm::FP3_PRE + (fuse_y ? xm::FP3_NEXT_Y : xm::FP3_OWN_Y) : xm::FP3_FULL));
     prof_mark(c, K_FP2, st);
     if (np == 2 && c->fp_pre >= 1) {
         const bool src = skip_sa1 && inv_in_source_order(c);   // level-1 features in source order, read through f.idx[0]
@@ -617,9 +657,11 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
                       DenseH{nullptr, nullptr}, nullptr, true, st);
     } else
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
+    prof_exec(c, K_FP2, nc * (np == 2 && c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
     prof_mark(c, K_FP1, st);
     if (np == 2 && c->fp1_reg) launch_fp_s(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
     else launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
+    prof_exec(c, K_FP1, nc * xm::FP1);
 }
 
 // Group-batched encoder stages (loop-invariant schedule, bf16x3, default kernels).  Nothing in the scene encoder reads x or anything a
@@ -724,8 +766,11 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
         prof_mark(c, K_SA1 + 1, st, steps);
         launch_sa_u_list(256, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1, g.memo_list,
                          g.memo_cnt + 1);
-    } else
+        prof_exec_dev(c, K_SA1 + 1, g.memo_cnt + 1, xm::SA2_CENT, st);      // the crowded centroids of the group only
+    } else {
         launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
+        prof_exec(c, K_SA1 + 1, nc * 256 * xm::SA2_CENT);
+    }
     // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were
     // measured: fp2 337 -> 323 us, but fp1 275 -> 295, fp3 165 -> 190, sa3 / sa4 slower as well -- the extra launch ramps and tails cost
     // more than the cache residency gains)
@@ -748,9 +793,11 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
             prof_mark(c, K_SA1 + 2, st);
             launch_lin_u(2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], U0, V0, st);
             launch_sa_u(2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+            prof_exec(c, K_SA1 + 2, ncp * xm::SA3);
             prof_mark(c, K_SA1 + 3, st);
             launch_lin_u(3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], U1, V1, st);
             launch_sa_u(3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+            prof_exec(c, K_SA1 + 3, ncp * xm::SA4);
         }
     }
     st = st0;
@@ -759,6 +806,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     // (fp4 / fp3 store only the next finer stage's pre-multiplied operand inside a multi-step call: keep_out = false, `out` unused)
     launch_fp_pre(4, nc, g.feat[2], nullptr, g.feat[3], c->fp_y[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], nullptr, false,
                   c->fp_y[0], g.ybuf[0], false, st);
+    prof_exec(c, K_FP4, nc * xm::FP4_PRE);
     prof_mark(c, -1, st);
 }
 
@@ -777,11 +825,14 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         prof_mark(c, K_FP3, st);
         launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
                       fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], ybuf1, false, st);
+        prof_exec(c, K_FP3, ncp * (xm::FP3_PRE + xm::FP3_NEXT_Y));
         prof_mark(c, K_FP2, st);
         launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], ybuf1, fj.nn_idx[2] + o * 1024 * 3,
                       fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
+        prof_exec(c, K_FP2, ncp * xm::FP2_PRE);
         prof_mark(c, K_FP1, st);
         launch_fp_s(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st);
+        prof_exec(c, K_FP1, ncp * xm::FP1);
     }
 }
 
@@ -803,8 +854,12 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         launch_cond(c->cond, t, text, given_cats, mask, B, g, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
         prof_mark(c, K_UP12, st);
         launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B * g, 0, f.h2p, st);
+        prof_exec(c, K_UP12, np == 0 ? B * g * kKernelMacs[K_UP12] : B * g * xm::UP12_HALF);
         // per-sample timesteps: the timestep half of combine_extraction's pre-activation per (step, sample) row
-        if (np != 0 && c->den_reg && g == 1) launch_ctext(np, c->den_h, B, f.h2p, c->ct_time, true, st);
+        if (np != 0 && c->den_reg && g == 1) {
+            launch_ctext(np, c->den_h, B, f.h2p, c->ct_time, true, st);
+            prof_exec(c, K_UP12, B * xm::CTEXT_HALF);
+        }
     } else if (!reuse_hm) {
         // per call: the sample rows (text / category embeddings, attention weights, translation tokens) of set 0
         launch_cond(c->cond, t, text, given_cats, mask, B, 1, c->max_cats, out_cat, f.e0, f.tr, f.w, st);
@@ -815,9 +870,11 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
             prof_mark(c, K_UP12, st);
             launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B, 128, c->h2x, st);
             launch_ctext(np, c->den_h, B, c->h2x, c->ctext, false, st);
+            prof_exec(c, K_UP12, B * (xm::UP12_HALF + xm::CTEXT_HALF));
         }
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->posa_ws, c->hm, st);
+        prof_exec(c, K_POSA, B * kKernelMacs[K_POSA]);
     }
     if (shared) {
         // per group: one timestep-embedding row per STEP (t of step j = t[j * B]) into the first halves of rows 0 .. g-1 of e0
@@ -827,6 +884,7 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         prof_mark(c, K_UP12, st);
         launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, g, 0, f.h2p, st);
         launch_ctext(np, c->den_h, g, f.h2p, c->ct_time, true, st);
+        prof_exec(c, K_UP12, g * (xm::UP12_HALF + xm::CTEXT_HALF));      // one row per STEP: every chain of the batch is at the same timestep
     }
     prof_mark(c, -1, st);
 }
@@ -862,6 +920,8 @@ void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, flo
     else
         launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, nsteps, shared ? 0 : 1, x, t, mask, c->pcd, f.w, c->o12, c->hm,
                          f.h2p, c->ctext, shared ? (f.ctime ? f.ctime : c->ct_time) : nullptr, noise, out_x0, out_guiding, out_sample, st);
+    if (c->prec != LSDM_PREC_F32 && c->den_reg) prof_exec(c, K_DENOISE, (double)B * (nsteps * (xm::DEN_S + xm::DEN_PASS) + (out_guiding ? xm::DEN_PASS : 0.0)));
+    else prof_exec(c, K_DENOISE, (double)B * nsteps * (kKernelMacs[K_DENOISE] - (c->prec != LSDM_PREC_F32 && shared ? 1024.0 * (512 * 256 + 256 * 128) : 0.0)));
     prof_mark(c, -1, st);
 }
 
@@ -1414,13 +1474,18 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         prof_mark(c, K_SA1, si);
         if (c->prec == LSDM_PREC_F32) {
             launch_sa(0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), si);
+            prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
+            prof_exec(c, K_SA1, nc * xm::SA1);
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
             if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
             else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, si);
         }
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
+        {
             launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
+            prof_exec(c, K_SA1 + 1, nc * xm::SA2_UV);       // (timed inside the sa1 interval of the call's prelude)
+        }
         // memo of sa2 (geometry.hip::memo_src_kernel): the stage's output of every source point with fewer than 32 points within r, once
         c->memo_ready = false;
         if (K > 1 && gmax > 1 && group_batched(c) && c->sa2_memo && c->gws.memo_F2) {
@@ -1433,6 +1498,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             prof_mark(c, K_SA1 + 1, si);
             launch_sa_u_list(1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
                              gw.memo_src_list, gw.memo_cnt);
+            prof_exec_dev(c, K_SA1 + 1, gw.memo_cnt, xm::SA2_CENT, si);     // sa2 once per call on the uncrowded source points
             c->memo_ready = true;
         }
         prof_mark(c, K_NN1, si);
@@ -1477,6 +1543,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             launch_denoise_r(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_r, c->den_h.pwt, c->sched, mode, eta, B, g, 0, cur, c->fs0.tbuf, mask, gw.pcd, c->fs0.w,
                              gw.o12, c->hm, c->ctext, c->ct_time, noise + (size_t)k0 * xn, c->s_stash, out_x0, k0 + g < K ? nullptr : out_guiding, nullptr,
                              c->fps_slots / 16, st, (long long)pstep, (long long)ostep);
+            prof_exec(c, K_DENOISE, (double)B * (g * (xm::DEN_S + xm::DEN_PASS) + (k0 + g < K ? 0.0 : xm::DEN_PASS)));
             prof_mark(c, -1, st);
             rc = check_launch(c, "sample steps (group)");
             if (rc) return rc;
@@ -1634,6 +1701,7 @@ int lsdm_nn_distance(lsdm_ctx* c, const float* a, int na, const float* b, int nb
 int lsdm_profile_begin(lsdm_ctx* c) {
     if (!c) return LSDM_ERR_ARG;
     c->prof_cur = 0;
+    for (double& v : c->prof_exec) v = 0.0;
     c->prof_on = true;
     return LSDM_OK;
 }
@@ -1653,6 +1721,12 @@ int lsdm_profile_end(lsdm_ctx* c, int capacity, double* total_ms, int64_t* launc
         total_ms[id] += ms;
         launches[id] += c->prof_w[i];
     }
+    return K_COUNT;
+}
+
+int lsdm_profile_executed(lsdm_ctx* c, int capacity, double* executed_macs) {
+    if (!c || !executed_macs || capacity < K_COUNT) return fail(c, LSDM_ERR_ARG, "lsdm_profile_executed: need capacity >= %d", (int)K_COUNT);
+    for (int k = 0; k < K_COUNT; ++k) executed_macs[k] = c->prof_exec[k];
     return K_COUNT;
 }
 

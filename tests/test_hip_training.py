@@ -1,6 +1,8 @@
 """GPU tests of the training objective: diffusion.training_losses(...).backward() through lsdm_train_step
 (lsdm_amd/csrc/train.hip) against G12 -- loss terms and d loss / d theta of every parameter recorded from the REAL reference in
 model.eval() and model.train() -- and against torch.autograd of the CPU oracle; the optimizer loop of run.train_sdm."""
+import os
+
 import numpy as np
 import pytest
 import torch
