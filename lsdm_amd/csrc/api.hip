@@ -97,7 +97,8 @@ struct lsdm_ctx {
     void* inv_F1 = nullptr;
     float* inv_nn8_d = nullptr;
     int* inv_nn8_i = nullptr;
-    int fps_slots = 4096;               // resident FPS waves on the device (lsdm_create: 16 x CUs)
+    int fps_slots = 4096;               // resident FPS waves on the device (lsdm_create: 4 SIMDs x LSDM_FPS_WPE x CUs)
+    int num_cus = 256;
     int group_cap = getenv("LSDM_GROUP") ? atoi(getenv("LSDM_GROUP")) : 0;   // A/B switch: steps per batched geometry launch
     struct FrontSet {
         int* idx[4] = {};
@@ -916,7 +917,7 @@ void run_denoise(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, flo
     else if (c->den_reg)
         launch_denoise_r(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_r, c->den_h.pwt, c->sched, mode, eta, B, nsteps, shared ? 0 : 1, x, t, mask, c->pcd, f.w,
                          c->o12, c->hm, c->ctext, shared && f.ctime ? f.ctime : c->ct_time, noise, c->s_stash, out_x0, out_guiding, out_sample,
-                         c->fps_slots / 16, st);
+                         c->num_cus, st);
     else
         launch_denoise_h(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_h, c->sched, mode, eta, B, nsteps, shared ? 0 : 1, x, t, mask, c->pcd, f.w, c->o12, c->hm,
                          f.h2p, c->ctext, shared ? (f.ctime ? f.ctime : c->ct_time) : nullptr, noise, out_x0, out_guiding, out_sample, st);
@@ -970,7 +971,7 @@ int lsdm_create(lsdm_ctx** out, int device) {
     lsdm_ctx* c = new lsdm_ctx();
     c->device = device;
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->fps_slots = 16 * cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) { c->fps_slots = 4 * LSDM_FPS_WPE * cus; c->num_cus = cus; }
     *out = c;
     return LSDM_OK;
 }
@@ -1542,7 +1543,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             prof_mark(c, K_DENOISE, st, g);
             launch_denoise_r(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_r, c->den_h.pwt, c->sched, mode, eta, B, g, 0, cur, c->fs0.tbuf, mask, gw.pcd, c->fs0.w,
                              gw.o12, c->hm, c->ctext, c->ct_time, noise + (size_t)k0 * xn, c->s_stash, out_x0, k0 + g < K ? nullptr : out_guiding, nullptr,
-                             c->fps_slots / 16, st, (long long)pstep, (long long)ostep);
+                             c->num_cus, st, (long long)pstep, (long long)ostep);
             prof_exec(c, K_DENOISE, (double)B * (g * (xm::DEN_S + xm::DEN_PASS) + (k0 + g < K ? 0.0 : xm::DEN_PASS)));
             prof_mark(c, -1, st);
             rc = check_launch(c, "sample steps (group)");

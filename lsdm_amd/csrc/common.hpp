@@ -3,6 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// resident FPS waves per SIMD (fps_chain_reg_kernel: one wave per cloud, everything in registers; 97 VGPRs at 4, 95 at 5)
+#ifndef LSDM_FPS_WPE
+#define LSDM_FPS_WPE 4
+#endif
+
 namespace lsdm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

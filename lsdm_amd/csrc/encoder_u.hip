@@ -854,10 +854,248 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp2 as a PERSISTENT, WAVE-SPECIALISED work-group (one per CU, 8 waves): the same arithmetic as fp_pre_kernel<D1, C1, C2> in the same
+// order (bit-identical results), but the gather of tile n + 1 runs NEXT TO the matrix work of tile n instead of in front of its own.
+// fp_pre_kernel spends a tile as [indices -> 192 KB of Y rows through L1 -> interpolation -> 5 barriers of dependent phases]; its MFMAs
+// are 13 % of a tile's time, and the second work-group of the CU is usually in the same phase (PMC: MFMA pipe 23 % busy).
+//   waves 0..3 ("matrix"): accumulators <- interpolated tile T (LDS), layer 1 over the p1 operand tile, ReLU + split -> bufB, layer 2, stores
+//   waves 4..7 ("gather"): indices, the three Y rows and the p1 row of every point of the NEXT tile -> T / bufX
+// A work-group's waves are placed on the SIMDs cyclically, so every SIMD holds one wave of each role: the gather wave's VMEM / VALU /
+// LDS-store stream fills the issue slots next to the matrix wave's MFMAs without any compiler scheduling.  Three barriers per tile:
+//   B1  T(n), bufX(n) complete; bufB free     | matrix: acc <- T, layer-1 MFMAs            | gather: requests rows of tile n + 1 (batch 1) + p1
+//   B2  T, bufX free                          | matrix: ReLU + split -> bufB                | gather: batch 1 -> T, requests batch 2
+//   B3  bufB complete                         | matrix: layer 2 + output stores             | gather: batch 2 -> T, p1 -> bufX, indices of tile n + 2
+// T (64 KB fp32) + bufX + bufB (hi / lo planes) = 150 KB of LDS.  Tiles are walked in the XCD-cooperative round order (common.hpp).
+#ifdef LSDM_PHASE_TIMING
+__device__ unsigned long long g_ws_phase[64 * 16];   // 64 spread copies of 16 slots: matrix role 0..5 (+7 = tiles), gather role 8..13
+#define WS_T0() unsigned long long wt_ = __builtin_amdgcn_s_memtime(); unsigned long long wd_[6] = {}
+#define WS_MARK(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); wd_[slot] += n_ - wt_; wt_ = n_; } while (0)
+#define WS_FLUSH(base, ntiles) do { if (lane == 0 && (wave & 3) == 0) { unsigned long long* g_ = g_ws_phase + (blockIdx.x & 63) * 16 + (base); \
+        for (int i_ = 0; i_ < 6; ++i_) atomicAdd(g_ + i_, wd_[i_]); atomicAdd(g_ + 7, (unsigned long long)(ntiles)); } } while (0)
+#else
+#define WS_T0() do {} while (0)
+#define WS_MARK(slot) do {} while (0)
+#define WS_FLUSH(base, ntiles) do {} while (0)
+#endif
+template <int D1, int C1, int C2>
+__global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
+                                                    const float* __restrict__ y, const int* __restrict__ nn_idx,
+                                                    const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
+                                                    float* __restrict__ out, int p1_mod, int total_tiles) {
+    constexpr int TM = 64, NWM = 4, NP = 2, NTG = 256, TPP = NTG / TM;
+    static_assert(TPP == 4 && C1 % 64 == 0, "four gather threads per fine point; tile rows are whole bank rounds");
+    constexpr int LDT = C1;
+    auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
+    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
+    __shared__ __attribute__((aligned(16))) float tile[TM * LDT];
+    __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
+    __shared__ __attribute__((aligned(16))) __bf16 bufB[NP * PB];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool gath = wave >= NWM;
+    const int tpc = N / TM;
+    const XcdRounds R = xcd_rounds(total_tiles);
+
+    // ---------------- gather role: state of the tile being fetched ----------------
+    const int gt = tid & (NTG - 1);
+    const int arow = gt / TPP, sub = gt % TPP;
+    constexpr int XIT = TM * (D1 / 4) / NTG;
+    constexpr int PIECES = C1 / (4 * TPP), GB = PIECES / 2;        // two batches of GB pieces x 3 rows per thread
+    int gi0 = 0, gi1 = 0, gi2 = 0, gc = 0, gn0 = 0;
+    float gw0 = 0.0f, gw1 = 0.0f, gw2 = 0.0f;
+    int xrow[XIT];
+    f32x4 gx[XIT], ga[GB], gb[GB], gd[GB];
+#define FPW_CH(sub, k) (4 * (2 * (sub) + ((k) & 1) + 2 * TPP * ((k) >> 1)))
+    auto g_indices = [&](int t) {
+        gc = t / tpc;
+        gn0 = (t - gc * tpc) * TM;
+        const size_t ao = ((size_t)gc * N + gn0 + arow) * 3;
+        if (p1_remap) {
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)gc * N + gn0 + (gt + it * NTG) / (D1 / 4)];
+        }
+        gi0 = nn_idx[ao + 0]; gi1 = nn_idx[ao + 1]; gi2 = nn_idx[ao + 2];
+        gw0 = nn_w[ao + 0]; gw1 = nn_w[ao + 1]; gw2 = nn_w[ao + 2];
+    };
+    auto g_request = [&](int k0) {
+        const float* yb = y + (size_t)gc * S * C1;
+        const float* r0 = yb + (size_t)gi0 * C1;
+        const float* r1 = yb + (size_t)gi1 * C1;
+        const float* r2 = yb + (size_t)gi2 * C1;
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int ch = FPW_CH(sub, k0 + k);
+            ga[k] = load4f(r0 + ch); gb[k] = load4f(r1 + ch); gd[k] = load4f(r2 + ch);
+        }
+    };
+    auto g_request_p1 = [&]() {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = gt + it * NTG;
+            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
+            if (p1_remap) gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? gc % p1_mod : gc) * N + xrow[it]) * D1 + 4 * c4);
+            else gx[it] = load4f(points1 + ((size_t)gc * N + gn0) * D1 + (size_t)e * 4);
+        }
+    };
+    auto g_interp = [&](int k0) {
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int ch = FPW_CH(sub, k0 + k);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(ga[k][j], gw0), __fmul_rn(gb[k][j], gw1)), __fmul_rn(gd[k][j], gw2));
+            *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = v;
+        }
+    };
+    auto g_store_p1 = [&]() {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = gt + it * NTG;
+            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
+            store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
+        }
+    };
+
+    // The two roles run their own loops (same trip count, three barriers per tile each): with the role test inside one loop the register
+    // allocator keeps both roles' state live together (453 spilled VGPRs).
+    if (gath) {
+        // prologue: the first tile of the work-group, and the indices of the second
+        if (R.first < R.end) {
+            g_indices(R.first);
+            g_request(0);
+            g_request_p1();
+            g_interp(0);
+            g_request(GB);
+            g_interp(GB);
+            g_store_p1();
+            if (R.first + R.stride < R.end) g_indices(R.first + R.stride);
+        }
+        WS_T0();
+        [[maybe_unused]] int ntl = 0;
+#pragma unroll 1
+        for (int t = R.first; t < R.end; t += R.stride) {
+            const bool has_next = t + R.stride < R.end;
+            __syncthreads();                                   // B1
+            WS_MARK(0);
+            if (has_next) {
+                g_request(0);
+                g_request_p1();
+            }
+            WS_MARK(1);
+            __syncthreads();                                   // B2
+            WS_MARK(2);
+            if (has_next) {
+                g_interp(0);
+                g_request(GB);
+            }
+            WS_MARK(3);
+            __syncthreads();                                   // B3
+            WS_MARK(4);
+            if (has_next) {
+                g_interp(GB);
+                g_store_p1();
+                if (t + 2 * R.stride < R.end) g_indices(t + 2 * R.stride);
+            }
+#ifdef LSDM_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            ++ntl;
+#endif
+            WS_MARK(5);
+        }
+        WS_FLUSH(8, ntl);
+        return;
+    }
+    // ---------------- matrix role: work split of fp_pre_kernel on four waves ----------------
+    using TS = SplitH<NWM, TM, C1>;
+    constexpr int NCB = TS::CB / TS::CSTEP, RB1 = TS::RB;
+    static_assert(TS::WPC == 1, "split");
+    using T2 = SplitH<NWM, TM, C2>;
+    static_assert(T2::CB == T2::CSTEP, "one layer-2 channel block per matrix wave");
+    const int mw = wave & (NWM - 1);
+    const int p = lane & 31, h = lane >> 5;
+    const int cb0 = mw % TS::CSTEP;
+    const int cb2 = mw % T2::CSTEP, rg2 = mw / T2::CSTEP;
+    f32x4 bv1[NCB][4];
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane);
+    const float bv2 = l2.b[cb2 * 32 + (lane & 31)];
+    WS_T0();
+    [[maybe_unused]] int ntl = 0;
+#pragma unroll 1
+    for (int t = R.first; t < R.end; t += R.stride) {
+        f32x16 acc[NCB][RB1];
+        // (the weight streams are loop-invariant: laundered, or hipcc hoists their addresses and first fragments out of the tile loop
+        // and spills them)
+        const __bf16* const w1p = opaque_ptr(l1.w);
+        const __bf16* const w2p = opaque_ptr(l2.w);
+        __syncthreads();                                   // B1
+        WS_MARK(0);
+        // accumulators start from the interpolated rows (transposed product: lane owns channels 8 qd + 4 h + j of point p)
+#pragma unroll
+        for (int q = 0; q < NCB; ++q)
+#pragma unroll
+            for (int rb = 0; rb < RB1; ++rb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
+                }
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lane);
+        WS_MARK(1);
+        __syncthreads();                                   // B2
+        WS_MARK(2);
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
+        WS_MARK(3);
+        __syncthreads();                                   // B3
+        WS_MARK(4);
+        {
+            const int c = t / tpc, n0 = (t - c * tpc) * TM;
+            // (direct orientation: 32 consecutive channels of a row per half-wave -- coalesced 128-byte row segments.  The transposed form with
+            // one 16-byte store per lane and quad was measured SLOWER here and in lin_u / fp3's extra layer: sa3 315 -> 329, fp2 310 -> 323 us)
+            f32x16 a2[T2::RB];
+            acc_zero_h(a2);
+            const int col = cb2 * 32 + (lane & 31);
+            mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, w2p, C2, cb2, 0, lane);
+#pragma unroll
+            for (int rb = 0; rb < T2::RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lane);
+                    out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv2);
+                }
+        }
+#ifdef LSDM_PHASE_TIMING
+        ++ntl;
+#endif
+        WS_MARK(5);
+    }
+    WS_FLUSH(0, ntl);
+#undef FPW_CH
+}
+
+#ifdef LSDM_PHASE_TIMING
+extern "C" __attribute__((visibility("default"))) int lsdm_debug_ws_phase(unsigned long long* out16, int reset) {
+    static unsigned long long h[64 * 16], z[64 * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ws_phase), sizeof h) != hipSuccess) return -1;
+    for (int s = 0; s < 16; ++s) { out16[s] = 0; for (int c = 0; c < 64; ++c) out16[s] += h[c * 16 + s]; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ws_phase), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 // which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
 // Y = coarse-level FP output x Wb^T, R = num_clouds * S rows of 256 channels
 void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
     hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
+}
+
+// LSDM_FP2_WS (default 1): fp2 on the persistent wave-specialised kernel; 0 = the tile-per-work-group form (same results)
+static bool fp2_ws() {
+    static const bool on = !(getenv("LSDM_FP2_WS") && atoi(getenv("LSDM_FP2_WS")) == 0);
+    return on;
 }
 
 // y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):
@@ -884,7 +1122,12 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
         return;
     }
     if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
-    if (which == 2) {
+    if (which == 2 && fp2_ws()) {
+        const int total = 1024 / 64 * nc;
+        hipLaunchKernelGGL((fp_ws_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
+                           out, p1_mod, total);
+    }
+    else if (which == 2) {
 #ifdef LSDM_TIMING_EXPERIMENTS   // `make TIMING=1` only: results are wrong with these (1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs)
         static const int dbg = getenv("LSDM_DBG_FP2") ? atoi(getenv("LSDM_DBG_FP2")) : 0;
 #else

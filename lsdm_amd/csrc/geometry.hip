@@ -286,6 +286,9 @@ __device__ __forceinline__ void fps_level1_compact(const FpsVec<16>::type& px, c
     {
         FpsState<16, true> A;
         A.px = px; A.py = py; A.pz = pz;
+        // (laundered: otherwise the pack after the epoch is matched to the (x, y, z) triples the loads delivered, which are then kept
+        // alive next to the coordinate vectors -- 48 registers spilled in the prologue and reloaded in fps_pack_store)
+        asm volatile("" : "+v"(A.px), "+v"(A.py), "+v"(A.pz));
 #pragma unroll
         for (int j = 0; j < 16; ++j) A.run[j] = 1e10f;
         zero = fps_epoch<16, true>(A, sj, sl, 0, 256, out_idx, out_xyz, &filled);
@@ -334,7 +337,7 @@ __device__ __forceinline__ void fps_load_prev(const float* prev_xyz, typename Fp
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fps_chain_reg_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LSDM_FPS_WPE, LSDM_FPS_WPE))) void fps_chain_reg_kernel(
     const float* __restrict__ clouds, const int64_t* __restrict__ starts, int nc_step,
     int* __restrict__ idx1, int* __restrict__ idx2, int* __restrict__ idx3, int* __restrict__ idx4,
     float* __restrict__ xyz1, float* __restrict__ xyz2, float* __restrict__ xyz3, float* __restrict__ xyz4) {

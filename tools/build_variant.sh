@@ -9,9 +9,9 @@ cd $R/lsdm_amd/csrc
 pids=()
 for f in *.hip; do
   extra=""; [ "$f" = geometry.hip ] && extra="-ffp-contract=off"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-inline-asm $extra $FLAGS -c $f -o $O/${f%.hip}.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-inline-asm $extra $FLAGS -c $f -o $O/${f%.hip}.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/lsdm_amd/variants/$NAME.so $O/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o $R/lsdm_amd/variants/$NAME.so $O/*.o
 ls -la $R/lsdm_amd/variants/$NAME.so
