@@ -507,6 +507,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
         }
     };
+    // the same copy in pieces: piece i of panel q (i < FP / NW), issued from INSIDE the k loop of the panel before it (LSDM_SAW_SPREAD).  Issued
+    // as one block in front of a panel's 96 matrix instructions, the 16 copies of a wave (~60 issue cycles each) run with the matrix pipe
+    // idle -- at one wave per SIMD nothing else covers them; spread two per k-step over the first half of the k loop they issue in the
+    // shadow of the MFMAs and still have half a panel's time to land.
+    auto fetch_piece = [&](int q, int i) {
+        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FP * 512);
+        const int fr = wave + i * NW;
+        lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
+    };
+#ifndef LSDM_SAW_SPREAD
+#define LSDM_SAW_SPREAD 1
+#endif
+    constexpr bool SPREAD = LSDM_SAW_SPREAD != 0;
+    constexpr int PPS = (FP / NW) / (KS / 2);        // pieces per k-step over the first half of the k loop
+    static_assert(!SPREAD || (FP / NW) % (KS / 2) == 0, "spread");
     fetch(0);
     lds_dma_wait();
     __syncthreads();
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if (rd + rstep < rend) { const long long ce = (rd + rstep) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
         }
-#define SAW_BEGIN(Q) { if (!(dbg & 1)) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
+#define SAW_BEGIN(Q) { if (!(dbg & 1) && !SPREAD) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
 #define SAW_END(Q) lds_dma_wait(); if (!(dbg & 2)) __syncthreads(); }
         // ---- layer 2 (transposed): two channel blocks per panel as two interleaved accumulator chains
 #pragma unroll
@@ -581,6 +596,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (s + 1 < KS) {
                     f0h = wfrag_lds_u<NP>(W, KS, 0, s + 1, 0, lane); f1h = wfrag_lds_u<NP>(W, KS, 1, s + 1, 0, lane);
                     f0l = wfrag_lds_u<NP>(W, KS, 0, s + 1, NP - 1, lane); f1l = wfrag_lds_u<NP>(W, KS, 1, s + 1, NP - 1, lane);
+                }
+                if constexpr (SPREAD) {
+                    if (s < KS / 2) {
+#pragma unroll
+                        for (int i = 0; i < PPS; ++i) fetch_piece((q + 1) % NPANEL, s * PPS + i);
+                    }
                 }
 
                 if constexpr (NP == 2) {
@@ -619,6 +640,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (s + 1 < KS) {
                     f0h = wfrag_lds_u<NP>(W, KS, 0, s + 1, 0, lane); f1h = wfrag_lds_u<NP>(W, KS, 1, s + 1, 0, lane);
                     f0l = wfrag_lds_u<NP>(W, KS, 0, s + 1, NP - 1, lane); f1l = wfrag_lds_u<NP>(W, KS, 1, s + 1, NP - 1, lane);
+                }
+                if constexpr (SPREAD) {
+                    if (s < KS / 2) {
+#pragma unroll
+                        for (int i = 0; i < PPS; ++i) fetch_piece((NB2 / PB + q + 1) % NPANEL, s * PPS + i);
+                    }
                 }
 
                 if constexpr (NP == 2) {
@@ -891,8 +918,10 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     __shared__ __attribute__((aligned(16))) float tile[TM * LDT];
     __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
     __shared__ __attribute__((aligned(16))) __bf16 bufB[NP * PB];
+    __shared__ __attribute__((aligned(16))) float b1s[C1];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool gath = wave >= NWM;
+    for (int e = tid; e < C1; e += 512) b1s[e] = l1.b[e];
     const int tpc = N / TM;
     const XcdRounds R = xcd_rounds(total_tiles);
 
@@ -1015,10 +1044,23 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     const int p = lane & 31, h = lane >> 5;
     const int cb0 = mw % TS::CSTEP;
     const int cb2 = mw % T2::CSTEP, rg2 = mw / T2::CSTEP;
-    f32x4 bv1[NCB][4];
-#pragma unroll
-    for (int q = 0; q < NCB; ++q) load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane);
     const float bv2 = l2.b[cb2 * 32 + (lane & 31)];
+    // layer-1 weights of the wave's channel blocks stay in registers for the life of the work-group (D1 = 64: 16 fragments = 64 VGPRs):
+    // a third of the weight bytes a tile pulls through the L1 (the kernel is bound by that path: TA 68 % busy, profiles/r04_a_pmc_mem.json)
+#ifndef LSDM_FP2_W1REG
+#define LSDM_FP2_W1REG 0
+#endif
+    constexpr bool W1REG = LSDM_FP2_W1REG != 0 && D1 <= 64;
+    [[maybe_unused]] bf16x8 w1h[NCB][D1 / 16], w1l[NCB][D1 / 16];
+    if constexpr (W1REG) {
+        const size_t ws = (size_t)C1 * NP * 16;
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) {
+            const __bf16* wp = l1.w + ((size_t)((cb0 + q * TS::CSTEP) * 32 + p) * NP) * 16 + 8 * h;
+#pragma unroll
+            for (int u = 0; u < D1 / 16; ++u) { w1h[q][u] = gload<bf16x8>(wp + (size_t)u * ws); w1l[q][u] = gload<bf16x8>(wp + (size_t)u * ws + 16); }
+        }
+    }
     WS_T0();
     [[maybe_unused]] int ntl = 0;
 #pragma unroll 1
@@ -1041,13 +1083,41 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
                 }
+        if constexpr (W1REG) {
+            // layer 1 against the wave's RESIDENT weight fragments (same instruction order as mma_kloop_pre_h: per k-step and point block
+            // hi x lo, lo x hi, hi x hi)
+            const __bf16* xp = bufX + p * LDX + 8 * h;
 #pragma unroll
-        for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lane);
+            for (int q = 0; q < NCB; ++q)
+#pragma unroll
+                for (int u = 0; u < D1 / 16; ++u) {
+                    bf16x8 xh[RB1], xl[RB1];
+#pragma unroll
+                    for (int rb = 0; rb < RB1; ++rb) {
+                        xh[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16);
+                        xl[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16 + PX);
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < RB1; ++rb) {
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xl[rb], acc[q][rb], 0, 0, 0);
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[q][u], xh[rb], acc[q][rb], 0, 0, 0);
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xh[rb], acc[q][rb], 0, 0, 0);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lane);
+        }
         WS_MARK(1);
         __syncthreads();                                   // B2
         WS_MARK(2);
 #pragma unroll
-        for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
+        for (int q = 0; q < NCB; ++q) {
+            f32x4 bv1[4];        // (from LDS at its use: 32 registers less across the tile loop)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h);
+            store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1, bufB, LDB, PB, lane);
+        }
         WS_MARK(3);
         __syncthreads();                                   // B3
         WS_MARK(4);
