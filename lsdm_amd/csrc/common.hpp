@@ -3,9 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// resident FPS waves per SIMD (fps_chain_reg_kernel: one wave per cloud, everything in registers; 97 VGPRs at 4, 95 at 5)
+// resident FPS waves per SIMD (fps_chain_reg_kernel: one wave per cloud, everything in registers; 97 VGPRs at 4, 95 at 5, 80 at 6 -- all without spills; 7 spills)
 #ifndef LSDM_FPS_WPE
-#define LSDM_FPS_WPE 4
+#define LSDM_FPS_WPE 6
 #endif
 
 namespace lsdm {

@@ -59,7 +59,7 @@ struct Gemm {
 
 __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
     // k-major tiles: the MFMA operands of k-pair (2 kk, 2 kk + 1) are rows 2 kk + (lane >> 5) at column (lane & 31) of the wave's quadrant
-    __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+    __shared__ __attribute__((aligned(16))) float As[16][64 + 4], Bs[16][64 + 4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int batch = blockIdx.z / g.ksplit, ks = blockIdx.z - batch * g.ksplit;
     const float* A = g.A + (long long)batch * g.bA;
@@ -68,29 +68,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;      // (row tiles on x: up to millions of rows)
     const int k_lo = ks * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
     const bool a_kfast = g.sak == 1, b_nfast = g.sbn == 1;
-    // the four A and four B elements this thread moves per k-block: tile coordinates and global addresses (advanced by 16 k per block)
-    int am[4], ak[4], bn[4], bk[4];
-    const float* pa[4];
-    const float* pb[4];
-    bool va[4], vb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (a_kfast) { ak[i] = t & 15; am[i] = (t >> 4) + 16 * i; } else { am[i] = t & 63; ak[i] = (t >> 6) + 4 * i; }
-        if (b_nfast) { bn[i] = t & 63; bk[i] = (t >> 6) + 4 * i; } else { bk[i] = t & 15; bn[i] = (t >> 4) + 16 * i; }
-        va[i] = m0 + am[i] < g.M;
-        vb[i] = n0 + bn[i] < g.N;
-        pa[i] = A + (long long)(m0 + am[i]) * g.sam + (long long)(k_lo + ak[i]) * g.sak;
-        pb[i] = B + (long long)(k_lo + bk[i]) * g.sbk + (long long)(n0 + bn[i]) * g.sbn;
-    }
+    // The four A and four B elements this thread moves per k-block are CONSECUTIVE along the operand's contiguous axis (k for a row-major
+    // activation / gradient matrix, m or n for its transposed view): one 16-byte load when the four are in range and the address is aligned
+    // (column slices of a concat buffer start at odd offsets: those fall back to four scalar loads), four scalars otherwise.
+    const int am0 = a_kfast ? t >> 2 : (t & 15) * 4, ak0 = a_kfast ? (t & 3) * 4 : t >> 4;
+    const int bn0 = b_nfast ? (t & 15) * 4 : t >> 2, bk0 = b_nfast ? t >> 4 : (t & 3) * 4;
+    const long long aes = a_kfast ? g.sak : g.sam, bes = b_nfast ? g.sbn : g.sbk;       // element stride along the thread's four
+    const float* pa = A + (long long)(m0 + am0) * g.sam + (long long)(k_lo + ak0) * g.sak;
+    const float* pb = B + (long long)(k_lo + bk0) * g.sbk + (long long)(n0 + bn0) * g.sbn;
     const long long da = 16 * g.sak, db = 16 * g.sbk;
+    // rows / columns of the tile that exist (the k range is checked per block)
+    const int am_n = a_kfast ? (m0 + am0 < g.M ? 4 : 0) : max(0, min(4, g.M - (m0 + am0)));
+    const int bn_n = b_nfast ? max(0, min(4, g.N - (n0 + bn0))) : (n0 + bn0 < g.N ? 4 : 0);
     float ra[4], rb[4];
     auto fetch = [&](int k0) {
+        const int ka = a_kfast ? max(0, min(4, k_hi - (k0 + ak0))) : (k0 + ak0 < k_hi ? 4 : 0);
+        const int na = a_kfast ? (am_n ? ka : 0) : (ka ? am_n : 0);          // valid elements of the thread's four (a prefix)
+        if (na == 4 && aes == 1 && ((size_t)pa & 15) == 0) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
+            ra[0] = v[0]; ra[1] = v[1]; ra[2] = v[2]; ra[3] = v[3];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = (va[i] && k0 + ak[i] < k_hi) ? *pa[i] : 0.0f;
-            rb[i] = (vb[i] && k0 + bk[i] < k_hi) ? *pb[i] : 0.0f;
-            pa[i] += da; pb[i] += db;
+            for (int i = 0; i < 4; ++i) ra[i] = i < na ? pa[i * aes] : 0.0f;
         }
+        const int kb = b_nfast ? (k0 + bk0 < k_hi ? 4 : 0) : max(0, min(4, k_hi - (k0 + bk0)));
+        const int nb = b_nfast ? (kb ? bn_n : 0) : (bn_n ? kb : 0);
+        if (nb == 4 && bes == 1 && ((size_t)pb & 15) == 0) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
+            rb[0] = v[0]; rb[1] = v[1]; rb[2] = v[2]; rb[3] = v[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = i < nb ? pb[i * bes] : 0.0f;
+        }
+        pa += da; pb += db;
     };
     // exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain over k): wave w owns the 32 x 32 quadrant
     // (w & 1, w >> 1) of the 64 x 64 tile; the next k-block's elements are in flight while this one is multiplied
@@ -101,8 +111,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
     float arow = 0.0f;
     if (k_lo < k_hi) fetch(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        if (a_kfast) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { As[ak[i]][am[i]] = ra[i]; Bs[bk[i]][bn[i]] = rb[i]; }
+            for (int i = 0; i < 4; ++i) As[ak0 + i][am0] = ra[i];
+        } else {
+            *reinterpret_cast<f32x4*>(&As[ak0][am0]) = f32x4{ra[0], ra[1], ra[2], ra[3]};
+        }
+        if (b_nfast) {
+            *reinterpret_cast<f32x4*>(&Bs[bk0][bn0]) = f32x4{rb[0], rb[1], rb[2], rb[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[bk0 + i][bn0] = rb[i];
+        }
         __syncthreads();
         if (k0 + 16 < k_hi) fetch(k0 + 16);
         if (g.asum && blockIdx.y == 0 && t < 64) {
@@ -208,6 +228,9 @@ __global__ void bn_finish_kernel(const double* sum, const double* sq, long long 
         invstd[c] = 1.0f / sqrtf(running_var[c] + kBnEps);
     }
 }
+// the affine normalisation, with its rounding sequence spelled out: forward and both backward kernels evaluate the SAME value (the backward
+// kernels decide Y > 0 from it instead of reading Y)
+__device__ __forceinline__ float bn_act(float z, float mu, float is, float ga, float be) { return __fmaf_rn(__fmul_rn(__fsub_rn(z, mu), is), ga, be); }
 // Y = ReLU((Z - mean) invstd gamma + beta) [* keep * 2: the Dropout(0.5) of the encoder head, mask (clouds, C, 1024) channel-first]
 __global__ void bn_relu_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ invstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ Y, long long ldy, long long rows,
@@ -223,7 +246,7 @@ __global__ void bn_relu_fwd_kernel(const float* __restrict__ Z, const float* __r
     f32x4 y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float v = (z[j] - mu[j]) * is[j] * ga[j] + be[j];
+        float v = bn_act(z[j], mu[j], is[j], ga[j], be[j]);
         v = v > 0.0f ? v : 0.0f;
         if (keep) v = keep[((r >> 10) * C + c + j) * 1024 + (r & 1023)] ? v * 2.0f : 0.0f;
         y[j] = v;
@@ -231,11 +254,14 @@ __global__ void bn_relu_fwd_kernel(const float* __restrict__ Z, const float* __r
     *reinterpret_cast<f32x4*>(Y + r * ldy + c) = y;
 }
 // first backward pass: dA = dY [* 2 keep] * (Y > 0)  ->  sum_r dA (d beta) and sum_r dA xhat (d gamma), in double.
-// Four channels per thread (16-byte loads of dY, Y and Z: the three tensors are dense (rows, C), C a multiple of 4), 256 / (C / 4) rows per
-// pass of the work-group, the row slots of a channel quad combined through LDS, one atomic per channel and work-group.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const float* __restrict__ Z,
-                                                            const float* __restrict__ mean, const float* __restrict__ invstd, long long rows, int C,
-                                                            int keep, double* __restrict__ dbeta, double* __restrict__ dgamma) {
+// Y > 0 is decided from Z with the forward kernel's own expression (bn_act: the same instruction sequence, so the same sign), so the pass
+// reads two tensors instead of three; the dropout layer (keep != NULL) also reads its mask.  Four channels per thread (16-byte loads: the
+// tensors are dense (rows, C), C a multiple of 4), 256 / (C / 4) rows per pass of the work-group with four row groups in flight, the row
+// slots of a channel quad combined through LDS, one atomic per channel and work-group.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, const float* __restrict__ Z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, long long rows, int C,
+                                                            const unsigned char* __restrict__ keep, double* __restrict__ dbeta, double* __restrict__ dgamma) {
     __shared__ double part[256][8];
     const int tpr = C >> 2, rpi = 256 / tpr, t = threadIdx.x;
     const int slot = t / tpr, c4 = (t - slot * tpr) * 4;
@@ -243,16 +269,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     if (slot < rpi) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4), is = *reinterpret_cast<const f32x4*>(invstd + c4);
-        const float ks = keep ? 2.0f : 1.0f;       // (a dropped element has Y = 0 already)
-#pragma unroll 2
-        for (long long r = lo + slot; r < hi; r += rpi) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dY + r * C + c4), y = *reinterpret_cast<const f32x4*>(Y + r * C + c4);
-            const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * C + c4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c4), be = *reinterpret_cast<const f32x4*>(beta + c4);
+        const float ks = keep ? 2.0f : 1.0f;
+        constexpr int U = 4;
+        for (long long r0 = lo + slot; r0 < hi; r0 += (long long)U * rpi) {
+            f32x4 g[U], z[U];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = y[j] > 0.0f ? g[j] * ks : 0.0f;
-                s[j] += d;
-                q[j] += (double)d * (double)((z[j] - mu[j]) * is[j]);
+            for (int u = 0; u < U; ++u) {
+                const long long r = r0 + (long long)u * rpi;
+                const bool ok = r < hi;
+                g[u] = ok ? *reinterpret_cast<const f32x4*>(dY + r * C + c4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                z[u] = ok ? *reinterpret_cast<const f32x4*>(Z + r * C + c4) : mu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long r = r0 + (long long)u * rpi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool on = bn_act(z[u][j], mu[j], is[j], ga[j], be[j]) > 0.0f;
+                    if (keep && r < hi) on = on && keep[((r >> 10) * C + c4 + j) * 1024 + (r & 1023)];
+                    const float d = on ? g[u][j] * ks : 0.0f;
+                    s[j] += d;
+                    q[j] += (double)d * (double)((z[u][j] - mu[j]) * is[j]);
+                }
             }
         }
     }
@@ -269,22 +308,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 // second pass: dZ.  training: gamma invstd (dA - (d beta + xhat d gamma) / rows);  eval: gamma invstd dA
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, long long ldg, const float* __restrict__ Y, long long ldy, const float* __restrict__ Z,
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, long long ldg, const float* __restrict__ Z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const double* __restrict__ dbeta, const double* __restrict__ dgamma, long long rows, int C, int training,
-                                    const unsigned char* __restrict__ keep, float* __restrict__ dZ) {
+                                    const float* __restrict__ beta, const double* __restrict__ dbeta, const double* __restrict__ dgamma, long long rows, int C,
+                                    int training, const unsigned char* __restrict__ keep, float* __restrict__ dZ) {
     const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = C >> 2;
     if (i4 >= rows * q) return;
     const long long r = i4 / q; const int c = (int)(i4 - r * q) * 4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(dY + r * ldg + c), y = *reinterpret_cast<const f32x4*>(Y + r * ldy + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dY + r * ldg + c), z = *reinterpret_cast<const f32x4*>(Z + r * C + c);
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c), ga = *reinterpret_cast<const f32x4*>(gamma + c);
-    f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f}, mu = z;
-    if (training) { z = *reinterpret_cast<const f32x4*>(Z + r * C + c); mu = *reinterpret_cast<const f32x4*>(mean + c); }
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), be = *reinterpret_cast<const f32x4*>(beta + c);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float d = y[j] > 0.0f ? g[j] : 0.0f;
+        bool on = bn_act(z[j], mu[j], is[j], ga[j], be[j]) > 0.0f;
+        if (keep) on = on && keep[((r >> 10) * C + c + j) * 1024 + (r & 1023)];
+        float d = on ? g[j] : 0.0f;
         if (keep) d *= 2.0f;
         if (training) {
             const float xh = (z[j] - mu[j]) * is[j];
@@ -789,7 +829,14 @@ void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const f
     if (need_dx && X.g) gemm(s, dZ, N, 1, W.w, K, 1, X.g, X.ld, 1, rows, K, N, nullptr, 1);
     if (W.g) {
         // (the bias gradient = row sums of the A operand dZ^T: a by-product of the same launch)
-        const int ksplit = rows > 4096 ? (rows + 4095) / 4096 : 1;
+        // The reduction runs over the ROWS (10^4 .. 10^6) into an N x K tile grid of 1 .. 32 work-groups: split it until the launch fills the
+        // chip (~3 work-groups per CU), down to 128 rows per work-group.  (One work-group per 4096 rows left the small layers on 2 .. 56
+        // work-groups for ~200 us each: 5.5 of the step's 12.4 ms of GEMM time, profiles/r04_a_train_*.)
+        const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+        int ksplit = (768 + tiles - 1) / tiles;
+        const int most = (rows + 127) / 128;
+        if (ksplit > most) ksplit = most;
+        if (ksplit < 1) ksplit = 1;
         gemm(s, dZ, 1, N, X.d, X.ld, 1, W.g, K, 1, N, K, rows, nullptr, 2, 1, 0, 0, 0, ksplit, nullptr, nullptr, b.g);
     }
     if (b.g && !W.g) {
@@ -831,7 +878,8 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
     float* mean = talloc<float>(s, N);
     float* invstd = talloc<float>(s, N);
     Ten Zt; Zt.d = Z; Zt.rows = rows; Zt.C = N; Zt.ld = N;
-    const int ry = rows > 2048 ? (int)((rows + 2047) / 2048) : 1;
+    // (work-groups of the backward reduction: 512 rows each, at most ~8 per CU)
+    const int ry4 = (int)std::min<long long>(2048, std::max<long long>(1, (rows + 511) / 512));
     double* st2 = talloc<double>(s, 2 * (size_t)N * kStatCopies, true);
     if (!st2) return Y;
     double* const stq = st2 + (size_t)N * kStatCopies;
@@ -843,8 +891,8 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
         float* dZ = talloc<float>(s, (size_t)rows * N);
         double* red = talloc<double>(s, 2 * (size_t)N, true);
         if (!dZ || !red) return;
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ry), dim3(256), 0, s->st, Y.g, Y.d, Z, mean, invstd, rows, N, keep ? 1 : 0, red, red + N);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Y.g, Y.ld, Y.d, Y.ld, Z, mean, invstd, gam.w, red, red + N, rows, N,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ry4), dim3(256), 0, s->st, Y.g, Z, mean, invstd, gam.w, bet.w, rows, N, keep, red, red + N);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Y.g, Y.ld, Z, mean, invstd, gam.w, bet.w, red, red + N, rows, N,
                            training, keep, dZ);
         if (bet.g) hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, red, bet.g, N);
         if (gam.g) hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, red + N, gam.g, N);
