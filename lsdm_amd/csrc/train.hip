@@ -16,6 +16,7 @@
 // head (pointnet2.py:58,76) is applied when a keep-mask is passed (the caller draws it: the reference draws it on the host generator).
 #include "../../include/lsdm_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -732,6 +734,13 @@ __global__ void chamfer_bwd_kernel(const float* __restrict__ out, const float* _
     }
 }
 __global__ void add3_kernel(const float* a, const float* b, float* out) { out[0] = a[0] + b[0]; out[1] = a[0]; out[2] = b[0]; }
+// zeroes a LIST of buffers in one launch (the ~160 parameter-gradient tensors of the caller: one memset each was 160 launches per step);
+// block (x, y): chunk x of buffer y
+__global__ void zero_list_kernel(float* const* __restrict__ ptrs, const long long* __restrict__ ns) {
+    float* p = ptrs[blockIdx.y];
+    const long long n = ns[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.0f;
+}
 __global__ void axpy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -750,6 +759,12 @@ struct lsdm_train {
     // arena: chunks handed out front to back, everything released at the end of a step
     struct Chunk { char* base; size_t cap, used; };
     std::vector<Chunk> chunks;
+    // buffers that must start from zero come from chunks of their own: the extent the PREVIOUS step used is cleared with one memset per
+    // chunk at the start of a step (the allocation sequence of a step repeats), an allocation beyond it is cleared on its own
+    struct ZChunk { char* base; size_t cap, used, zeroed; };
+    std::vector<ZChunk> zchunks;
+    // device-side list of the bound gradient buffers (zero_list_kernel), rebuilt when the bindings change
+    float** zl_ptrs = nullptr; long long* zl_ns = nullptr; int zl_count = 0; long long zl_max = 0; bool zl_dirty = true;
     hipStream_t st = nullptr;
     std::vector<std::function<void()>> tape;
     std::map<std::string, std::pair<void*, int64_t>> named;     // intermediates of the last step kept for the tests (lsdm_train_tensor)
@@ -778,22 +793,46 @@ void* arena_alloc(lsdm_train* s, size_t bytes) {
     s->chunks.push_back({static_cast<char*>(base), cap, bytes});
     return base;
 }
+void* zarena_alloc(lsdm_train* s, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto& c : s->zchunks)
+        if (c.cap - c.used >= bytes) {
+            char* p = c.base + c.used;
+            if (c.used + bytes > c.zeroed) {        // (partly) beyond what the step's opening memset covered
+                const size_t from = c.used > c.zeroed ? c.used : c.zeroed;
+                (void)hipMemsetAsync(c.base + from, 0, c.used + bytes - from, s->st);
+            }
+            c.used += bytes;
+            return p;
+        }
+    const size_t cap = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+    void* base = nullptr;
+    if (hipMalloc(&base, cap) != hipSuccess) { tfail(s, LSDM_ERR_HIP, "training workspace: hipMalloc of %zu bytes failed", cap); return nullptr; }
+    (void)hipMemsetAsync(base, 0, bytes, s->st);
+    s->zchunks.push_back({static_cast<char*>(base), cap, bytes, 0});
+    return base;
+}
 template <class T>
 T* talloc(lsdm_train* s, size_t n, bool zero = false) {
-    T* p = static_cast<T*>(arena_alloc(s, n * sizeof(T)));
-    if (p && zero) (void)hipMemsetAsync(p, 0, n * sizeof(T), s->st);
-    return p;
+    return static_cast<T*>(zero ? zarena_alloc(s, n * sizeof(T)) : arena_alloc(s, n * sizeof(T)));
 }
 
 inline unsigned nblk(long long n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 
-struct Ten { float* d = nullptr; float* g = nullptr; long long rows = 0; int C = 0; long long ld = 0; };   // (rows, C) view, row stride ld
+// (rows, C) view, row stride ld.  gs (optional): state of a LAZY gradient buffer -- 0 = not written yet and NOT zeroed: its first writer must
+// overwrite every element (a data-gradient GEMM in store mode, the max-pool's backward, which writes all rows); 1 = holds a value, later
+// writers accumulate.  Only tensors whose consumers are all of that kind are created lazy (the hidden activations of the PointNet++
+// MLP stacks: 1.77 M x 32 .. 64 at the finest level): no memset of the buffer and no read-modify-write in the first GEMM.
+struct Ten { float* d = nullptr; float* g = nullptr; long long rows = 0; int C = 0; long long ld = 0; std::shared_ptr<int> gs; };
 
-Ten make(lsdm_train* s, long long rows, int C, bool grad = true) {
+Ten make(lsdm_train* s, long long rows, int C, bool grad = true, bool lazy = false) {
     Ten t;
     t.rows = rows; t.C = C; t.ld = C;
     t.d = talloc<float>(s, (size_t)rows * C);
-    if (grad) t.g = talloc<float>(s, (size_t)rows * C, true);
+    if (grad) {
+        t.g = talloc<float>(s, (size_t)rows * C, !lazy);
+        if (lazy) t.gs = std::make_shared<int>(0);
+    }
     return t;
 }
 Ten cols(const Ten& t, int off, int C) { Ten v = t; v.d += off; if (v.g) v.g += off; v.C = C; return v; }
@@ -826,7 +865,11 @@ void linear_fwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const T
 void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const float* dZ, int N, bool need_dx = true) {
     if (s->failed) return;
     const int rows = (int)X.rows, K = X.C;
-    if (need_dx && X.g) gemm(s, dZ, N, 1, W.w, K, 1, X.g, X.ld, 1, rows, K, N, nullptr, 1);
+    if (need_dx && X.g) {
+        const bool first = X.gs && *X.gs == 0 && X.ld == K;       // lazy buffer, whole tensor: this GEMM stores it
+        gemm(s, dZ, N, 1, W.w, K, 1, X.g, X.ld, 1, rows, K, N, nullptr, first ? 0 : 1);
+        if (X.gs) *X.gs = 1;
+    }
     if (W.g) {
         // (the bias gradient = row sums of the A operand dZ^T: a by-product of the same launch)
         // The reduction runs over the ROWS (10^4 .. 10^6) into an N x K tile grid of 1 .. 32 work-groups: split it until the launch fills the
@@ -866,11 +909,11 @@ Ten dense(lsdm_train* s, const Ten& X, const std::string& name, int N, int act, 
 
 // 1x1 conv + BatchNorm + ReLU (+ dropout keep-mask) on (rows, K) -> (rows, N)
 Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std::string& bn, int N, int training, const unsigned char* keep = nullptr,
-                 bool need_dx = true) {
+                 bool need_dx = true, bool lazy_out = false) {
     const Par W = par(s, conv + ".weight", (int64_t)N * X.C), b = par(s, conv + ".bias", N);
     const Par gam = par(s, bn + ".weight", N), bet = par(s, bn + ".bias", N);
     const Par rm = par(s, bn + ".running_mean", N), rv = par(s, bn + ".running_var", N);
-    Ten Y = make(s, X.rows, N);
+    Ten Y = make(s, X.rows, N, true, lazy_out);
     if (s->failed) return Y;
     if (N % 4 != 0 || N > 1024 || 256 % (N / 4) != 0) { tfail(s, LSDM_ERR_ARG, "training: BatchNorm width %d (a power of two in 32 .. 1024 expected)", N); return Y; }
     const long long rows = X.rows;
@@ -925,6 +968,9 @@ int lsdm_train_destroy(lsdm_train* s) {
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(s->device);
     for (auto& c : s->chunks) (void)hipFree(c.base);
+    for (auto& c : s->zchunks) (void)hipFree(c.base);
+    if (s->zl_ptrs) (void)hipFree(s->zl_ptrs);
+    if (s->zl_ns) (void)hipFree(s->zl_ns);
     if (prev >= 0) (void)hipSetDevice(prev);
     delete s;
     return LSDM_OK;
@@ -935,6 +981,7 @@ const char* lsdm_train_last_error(const lsdm_train* s) { return s ? s->err.c_str
 int lsdm_train_bind(lsdm_train* s, const char* name, float* param, float* grad, int64_t numel) {
     if (!s || !name || !param || numel <= 0) return tfail(s, LSDM_ERR_ARG, "lsdm_train_bind: bad argument");
     s->bound[name] = lsdm_train::Bound{param, grad, numel};
+    s->zl_dirty = true;
     return LSDM_OK;
 }
 
@@ -970,11 +1017,35 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
     s->named.clear();
     for (auto& c : s->chunks) c.used = 0;
     hipStream_t st = s->st;
+    for (auto& c : s->zchunks) {
+        if (c.used) (void)hipMemsetAsync(c.base, 0, c.used, st);
+        c.zeroed = c.used;
+        c.used = 0;
+    }
     const int training = flags & 1, C = s->C;
     const int nc = B * kO;
     // gradient buffers start from zero (the caller owns them; this call defines their content)
-    for (auto& kv : s->bound)
-        if (kv.second.g) (void)hipMemsetAsync(kv.second.g, 0, (size_t)kv.second.n * sizeof(float), st);
+    if (s->zl_dirty) {
+        std::vector<float*> hp;
+        std::vector<long long> hn;
+        s->zl_max = 0;
+        for (auto& kv : s->bound)
+            if (kv.second.g) { hp.push_back(kv.second.g); hn.push_back((long long)kv.second.n); s->zl_max = std::max<long long>(s->zl_max, kv.second.n); }
+        if (s->zl_ptrs) (void)hipFree(s->zl_ptrs);
+        if (s->zl_ns) (void)hipFree(s->zl_ns);
+        s->zl_ptrs = nullptr; s->zl_ns = nullptr; s->zl_count = (int)hp.size();
+        if (s->zl_count) {
+            if (hipMalloc(&s->zl_ptrs, hp.size() * sizeof(float*)) != hipSuccess || hipMalloc(&s->zl_ns, hn.size() * sizeof(long long)) != hipSuccess ||
+                hipMemcpy(s->zl_ptrs, hp.data(), hp.size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(s->zl_ns, hn.data(), hn.size() * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess)
+                return tfail(s, LSDM_ERR_HIP, "training: gradient list");
+        }
+        s->zl_dirty = false;
+    }
+    if (s->zl_count) {
+        const unsigned gx = (unsigned)std::min<long long>(64, (s->zl_max + 1023) / 1024);
+        hipLaunchKernelGGL(zero_list_kernel, dim3(gx ? gx : 1, s->zl_count), dim3(256), 0, st, s->zl_ptrs, s->zl_ns);
+    }
     (void)hipMemsetAsync(losses, 0, 3 * sizeof(float), st);
 
     auto body = [&]() {
@@ -1103,7 +1174,7 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
             const std::string pre = "pcd_backbone.sa" + std::to_string(l + 1);
             const int D = feat[l].C;
             const long long rows = (long long)nc * S[l] * 32;
-            Ten G = make(s, rows, 3 + D, l > 0);
+            Ten G = make(s, rows, 3 + D, l > 0, /*lazy: written by the first conv's data gradient*/ true);
             const Ten src = feat[l];
             const int* bl = ball[l];
             if (!s->failed) hipLaunchKernelGGL(group_fwd_kernel, dim3(nblk(rows * (3 + D))), dim3(256), 0, st, lxyz[l], src.d, lxyz[l + 1], bl, NS[l], S[l], D, G.d, rows);
@@ -1113,7 +1184,8 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
             }
             Ten h = G;
             for (int i = 0; i < 3; ++i)
-                h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), CH[l][i], training, nullptr, !(l == 0 && i == 0));
+                h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), CH[l][i], training, nullptr, !(l == 0 && i == 0),
+                                 /*lazy: consumed by the next conv / the max-pool, whose backward passes write every element*/ true);
             Ten out = make(s, (long long)nc * S[l], CH[l][2]);
             unsigned char* arg = talloc<unsigned char>(s, (size_t)nc * S[l] * CH[l][2]);
             const int Cc = CH[l][2];
@@ -1121,7 +1193,10 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
             if (!s->failed) hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(groups * Cc)), dim3(256), 0, st, h.d, Cc, out.d, arg, groups);
             s->named["sa" + std::to_string(l + 1) + ".arg"] = {arg, (int64_t)(groups * Cc)};
             const Ten hl = h;
-            s->tape.push_back([=]() { hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, hl.g, rows); });
+            s->tape.push_back([=]() {
+                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, hl.g, rows);      // (stores every element)
+                if (hl.gs) *hl.gs = 1;
+            });
             feat[l + 1] = out;
         }
         // feature propagation: fp4 (l3 <- l4), fp3 (l2 <- l3), fp2 (l1 <- l2), fp1 (l0 <- l1, points1 = None)
@@ -1138,7 +1213,7 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
             const Ten p1 = f < 3 ? feat[3 - f] : Ten{};
             const int D1 = f < 3 ? p1.C : 0, D2 = p2.C;
             const long long rows = (long long)nc * N;
-            Ten H = make(s, rows, D1 + D2);
+            Ten H = make(s, rows, D1 + D2, true, /*lazy: written by the first conv's data gradient*/ true);
             const Ten p2c = p2;
             if (!s->failed) {
                 if (D1) hipLaunchKernelGGL(copy_cols_kernel, dim3(nblk(rows * D1)), dim3(256), 0, st, p1.d, p1.ld, 0, H.d, H.ld, 0, rows, D1, 0);
@@ -1150,11 +1225,14 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
             });
             const std::string pre = "pcd_backbone.fp" + std::to_string(4 - f);
             Ten h = H;
-            for (int i = 0; i < (f == 3 ? 3 : 2); ++i)
-                h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), FC[f][i], training);
+            // (the last layer of fp4 / fp3 / fp2 feeds the next stage's interpolation, whose backward ACCUMULATES: not lazy)
+            const int nl = f == 3 ? 3 : 2;
+            for (int i = 0; i < nl; ++i)
+                h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), FC[f][i], training, nullptr, true,
+                                 i + 1 < nl || f == 3);
             p2 = h;
         }
-        Ten hh = conv_bn_relu(s, p2, "pcd_backbone.conv1", "pcd_backbone.bn1", 128, training, dropout_keep);
+        Ten hh = conv_bn_relu(s, p2, "pcd_backbone.conv1", "pcd_backbone.bn1", 128, training, dropout_keep, true, true);
         pcd = dense(s, hh, "pcd_backbone.conv2", 3, T_NONE);
     }
     {
