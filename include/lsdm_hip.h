@@ -200,6 +200,7 @@ LSDM_API int lsdm_train_bind(lsdm_train* s, const char* name, float* param, floa
  * and the reverse sweep: every bound gradient buffer is OVERWRITTEN with grad_scale * d (mse + cat_loss) / d parameter.
  * flags & 1: training-mode BatchNorm (batch statistics; the bound running statistics are updated in place, momentum 0.1) --
  * model.train() of run/train_sdm.py:46; otherwise the running statistics normalise (model.eval()).
+ * flags & 2: the objective only (validation / torch.no_grad()): no reverse sweep, the bound gradient buffers are not touched.
  * dropout_keep (nullable): (B*9,128,1024) bytes, the keep-mask of the encoder head's Dropout(0.5) (pointnet2.py:58,76), drawn by
  * the caller (the reference draws it on the host generator right after the four FPS start draws); kept activations are doubled.
  * fps_starts: (4, B*9) int64 as in lsdm_step.  model_output (B,1024,3) and out_cat (B,max_cats) are optional outputs. */

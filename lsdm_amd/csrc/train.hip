@@ -1042,7 +1042,7 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
         }
         s->zl_dirty = false;
     }
-    if (s->zl_count) {
+    if (s->zl_count && !(flags & 2)) {
         const unsigned gx = (unsigned)std::min<long long>(64, (s->zl_max + 1023) / 1024);
         hipLaunchKernelGGL(zero_list_kernel, dim3(gx ? gx : 1, s->zl_count), dim3(256), 0, st, s->zl_ptrs, s->zl_ns);
     }
@@ -1329,7 +1329,9 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
         hipLaunchKernelGGL(catloss_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, zc.d, target, B, C, lambda_cat, grad_scale, out_cat, zc.g, lt + 1);
         hipLaunchKernelGGL(add3_kernel, dim3(1), dim3(1), 0, st, lt, lt + 1, losses);
         // ---- backward: the tape in reverse ----------------------------------------------------------------------------------------------
-        for (auto it = s->tape.rbegin(); it != s->tape.rend() && !s->failed; ++it) (*it)();
+        // (flags & 2: the objective only -- no reverse sweep, the bound gradient buffers are left as they are)
+        if (!(flags & 2))
+            for (auto it = s->tape.rbegin(); it != s->tape.rend() && !s->failed; ++it) (*it)();
     }
     };
     body();

@@ -65,9 +65,13 @@ class TrainSession:
                         "lsdm_train_bind(%s)" % name)
 
     def step(self, x_start, qa, qb, noise, t, mask, given_objs, given_cats, target, text, fps_starts, dropout_keep, lambda_cat, training,
-             grad_scale=1.0):
-        """-> (losses (3,) = [loss, mse, cat_loss], model_output (B,1024,3), out_cat (B,1,C)); fills ``self.grads``."""
+             grad_scale=1.0, want_grads=True):
+        """-> (losses (3,) = [loss, mse, cat_loss], model_output (B,1024,3), out_cat (B,1,C)); fills ``self.grads`` unless ``want_grads`` is
+        False (flags & 2 of lsdm_train_step: the objective only, no reverse sweep -- about a third of the step).  ``step_id`` counts the
+        calls that rewrote ``self.grads``: a backward() that runs after a LATER such call would read the other batch's gradients and raises."""
         self._bind()
+        if want_grads:
+            self.step_id = getattr(self, "step_id", 0) + 1
         dev = x_start.device
         B = x_start.shape[0]
         f32 = lambda v: v.to(device=dev, dtype=torch.float32).contiguous()
@@ -87,7 +91,7 @@ class TrainSession:
         out_cat = torch.empty(B, 1, self.model.max_cats, device=dev)
         p = lambda v: None if v is None else v.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        self._check(self.lib.lsdm_train_step(self.handle, B, 1 if training else 0, p(x_start), p(qa), p(qb), p(noise), p(t), p(mask), p(given_objs),
+        self._check(self.lib.lsdm_train_step(self.handle, B, (1 if training else 0) | (0 if want_grads else 2), p(x_start), p(qa), p(qb), p(noise), p(t), p(mask), p(given_objs),
                                              p(given_cats), p(target), p(text), p(starts), p(keep), float(lambda_cat), float(grad_scale), p(losses),
                                              p(out), p(out_cat), stream), "lsdm_train_step")
         return losses, out, out_cat
@@ -122,13 +126,17 @@ class HipObjective(torch.autograd.Function):
     @staticmethod
     def forward(ctx, session, names, run, *params):
         losses, out, out_cat = run()
-        ctx.session, ctx.names = session, names
+        ctx.session, ctx.names, ctx.step_id = session, names, session.step_id
         values = losses.clone()
         ctx.mark_non_differentiable(values, out, out_cat)
         return losses[0].clone(), values, out, out_cat
 
     @staticmethod
     def backward(ctx, g_loss, _g_all, _g_out, _g_cat):
+        if ctx.session.step_id != ctx.step_id:
+            raise RuntimeError("HipObjective.backward: the session's gradient buffers were rewritten by a later training_losses() call "
+                               "(step %d, this loss is step %d) -- call backward() before the next objective, or evaluate the other one under "
+                               "torch.no_grad()" % (ctx.session.step_id, ctx.step_id))
         grads = tuple(None if n in DEAD else ctx.session.grads[n] * g_loss for n in ctx.names)
         return (None, None, None) + grads
 
@@ -166,9 +174,10 @@ def training_losses(diffusion, model, x_start, mask, t, given_objs, given_cats, 
         session = model._train_session = TrainSession(model)
     target = torch.argmax(target_cat, dim=1)
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    want_grads = bool(named) and torch.is_grad_enabled()
     run = lambda: session.step(x_start, qa, qb, noise, diffusion._scale_timesteps(t), mask, given_objs, given_cats, target, text, starts,
-                               dropout_keep, diffusion.lambda_cat, training)
-    if named and torch.is_grad_enabled():
+                               dropout_keep, diffusion.lambda_cat, training, want_grads=want_grads)
+    if want_grads:
         loss, all_terms, out, out_cat = HipObjective.apply(session, tuple(n for n, _ in named), run, *[p for _, p in named])
     else:
         all_terms, out, out_cat = run()
@@ -178,6 +187,7 @@ def training_losses(diffusion, model, x_start, mask, t, given_objs, given_cats, 
             for name, buf in model.named_buffers():
                 if name.endswith("num_batches_tracked"):
                     buf += 1
-    model._dirty = True          # the sampling context re-reads the parameters after an optimizer step / running-statistics update
+    if training or want_grads:   # the sampling context re-reads the parameters after an optimizer step / running-statistics update
+        model._dirty = True      # (a pure evaluation changes neither)
     model.saved_cat = out_cat
     return {"loss": loss, "mse": all_terms[1], "cat_loss": all_terms[2], "model_output": out}

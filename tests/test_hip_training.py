@@ -164,6 +164,22 @@ def test_training_objective_without_grad_and_determinism(golden):
     terms["loss"].backward()
     n = "output_process.pose_final.2.weight"
     assert float((dict(model.named_parameters())[n].grad - 2 * grads[1][n]).abs().max()) <= 1e-3 * float(grads[1][n].abs().max())
+    # an evaluation under no_grad between a forward and its backward runs the objective only (flags & 2): the session's gradient buffers
+    # keep the first batch's gradients, the backward is the same as without it, and the model is not marked for a parameter re-upload
+    model.zero_grad()
+    _, terms = _g12_step(g, "eval", model, diffusion)
+    model._dirty = False
+    with torch.no_grad():
+        _, ev = _g12_step(g, "eval", model, diffusion)
+    assert model._dirty is False and abs(float(ev["loss"]) - float(terms["loss"])) <= 1e-6 * abs(float(terms["loss"]))
+    terms["loss"].backward()
+    assert float((dict(model.named_parameters())[n].grad - grads[1][n]).abs().max()) <= 1e-4 * float(grads[1][n].abs().max())
+    # ... but a second objective WITH gradients rewrites those buffers: the stale backward is refused instead of returning the other batch's
+    _, first = _g12_step(g, "eval", model, diffusion)
+    _, second = _g12_step(g, "eval", model, diffusion)
+    with pytest.raises(RuntimeError, match="rewritten by a later"):
+        first["loss"].backward()
+    second["loss"].backward()
 
 
 def test_training_gradients_vs_oracle_autograd_humanise_defaults():
