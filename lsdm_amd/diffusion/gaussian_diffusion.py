@@ -354,6 +354,9 @@ class GaussianDiffusion:
                                         const_noise=const_noise)
                 yield out
                 img = out["sample"]
+        inner = _unwrap(model)
+        if hasattr(inner, "check_timesteps"):
+            inner.check_timesteps()          # the deferred range checks of the loop's device-resident timesteps (model/sdm.py::_run)
 
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,

@@ -215,6 +215,10 @@ class SceneDiffusionModel(nn.Module):
             if t_lo < 0 or t_hi >= t_max:
                 raise ValueError("timesteps must lie in [0, %d), got [%d, %d]" % (t_max, t_lo, t_hi))
         else:
+            # checked WITHOUT a stall: the verdict of this call travels to a pinned host byte by an asynchronous copy and is looked at by the
+            # next call (or by check_timesteps(), which the sampling loops call when they finish) -- an out-of-range index raises one call
+            # late instead of never; the kernels meanwhile see the index clamped into the table, so nothing reads out of bounds
+            self._queue_timestep_check(t, t_max)
             t = t.clamp(0, t_max - 1)
         text = self._encode_text(y, B, dev)
         if fps_starts is None:
@@ -235,6 +239,38 @@ class SceneDiffusionModel(nn.Module):
         self.saved_cat = out_cat
         self.saved_guiding_points = out_guid
         return out_cat, out_x0, out_sample
+
+    def _queue_timestep_check(self, t, t_max):
+        self.check_timesteps(block=False)
+        ring = getattr(self, "_t_ring", None)
+        if ring is None:
+            ring = self._t_ring = [torch.zeros(1, dtype=torch.uint8).pin_memory() for _ in range(8)]
+            self._t_pending, self._t_next = [], 0
+        if len(self._t_pending) >= len(ring):          # every slot still in flight: wait for the oldest (never in practice)
+            self.check_timesteps(block=True)
+        host = ring[self._t_next % len(ring)]
+        self._t_next += 1
+        host.copy_(((t < 0) | (t >= t_max)).any().to(torch.uint8).reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        self._t_pending.append((ev, host, t_max))
+
+    def check_timesteps(self, block=True):
+        """Resolves the deferred range checks of device-resident timesteps (see _run): raises ValueError if a call since the last check was
+        handed an index outside its table.  ``block=False`` looks only at the checks whose copy has already landed."""
+        pending, keep, bad = getattr(self, "_t_pending", []), [], None
+        for ev, host, t_max in pending:
+            if block:
+                ev.synchronize()
+            if block or ev.query():
+                if int(host[0]) and bad is None:
+                    bad = t_max
+            else:
+                keep.append((ev, host, t_max))
+        self._t_pending = keep
+        if bad is not None:
+            raise ValueError("timesteps must lie in [0, %d): an earlier call received a device-resident index outside that range "
+                             "(its kernels saw the index clamped)" % bad)
 
     def _run_steps(self, mode, eta, x, mask, t_first, K, given_objs, given_cats, text, starts, noise, hoisted=False, invariant=False):
         """K consecutive sampler steps t = t_first .. t_first-K+1 in ONE library call (lsdm_sample_steps; lsdm_sample_steps_invariant:

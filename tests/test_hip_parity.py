@@ -709,3 +709,19 @@ def test_errors_are_loud(sd13):
     ctx = m._context()
     with pytest.raises(_lib.LsdmError):   # workspace not reserved for this batch
         ctx.call("lsdm_step", 0, 0.0, 10 ** 6, *([None] * 12), None)
+    # timesteps outside the table: a host tensor raises at once; a DEVICE tensor is not read back (no stall) -- the call runs on the clamped
+    # index and the error surfaces at the next call or at check_timesteps(), which the sampling loops call when they finish
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(1, seed=4).items()}
+    args = lambda t: (torch.zeros(1, 1024, 3, device=DEV), bt["mask"], t, bt["given_objs"], bt["given_cats"])
+    with pytest.raises(ValueError, match="timesteps must lie"):
+        m(*args(torch.tensor([5000])), y=bt["text_features"])
+    m(*args(torch.tensor([4999], device=DEV)), y=bt["text_features"])
+    m.check_timesteps()
+    m(*args(torch.tensor([-1], device=DEV)), y=bt["text_features"])
+    with pytest.raises(ValueError, match="timesteps must lie"):
+        m.check_timesteps()
+    m(*args(torch.tensor([7000], device=DEV)), y=bt["text_features"])
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="timesteps must lie"):       # ... or on the next call
+        m(*args(torch.tensor([3], device=DEV)), y=bt["text_features"])
+    m.check_timesteps()
