@@ -204,11 +204,13 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
         const float* pcd_b = pcd + (size_t)b * kSlots * kPoints * 3;
         const float* w_b = w + (size_t)b * kSlots;
         const size_t g0 = ((size_t)b * kPoints + n0) * 3;       // first element of the wave's (32, 3) tile
+        int lr = lane;
+        asm volatile("" : "+v"(lr));       // (see the step loop: per-lane element addresses are formed at their use)
 #pragma unroll 1
-        for (int i = lane; i < 96; i += 64) xs[i] = x[g0 + i];
+        for (int i = lr; i < 96; i += 64) xs[i] = x[g0 + i];
         wave_sync();
         // the human branch's rows of the tile (per call): element lane and, for the lower half-wave, 64 + lane
-        const float hm0 = hm[g0 + lane], hm1 = lane < 32 ? hm[g0 + 64 + lane] : 0.0f;
+        const float hm0 = hm[g0 + lr], hm1 = lr < 32 ? hm[g0 + 64 + lr] : 0.0f;
 
         // one denoiser pass on the (32, 3) tile zsrc (LDS) -> res; consumes S in place (panels 3 .. 11)
         auto pass = [&](const LF* zsrc, f32x16 (&S)[6]) {
@@ -300,11 +302,13 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                     }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s], wh, acc, 0, 0, 0);
                 }
-                const int c = lane & 31;
+                int lf = lane;
+                asm volatile("" : "+v"(lf));       // (laundered like the scalar sections: no per-lane addresses kept across the step loop)
+                const int c = lf & 31;
                 if (c < 3) {
                     const float bv = bz[B_FIN2 + c];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) res[acc_row(r, lane) * 3 + c] = gelu_fast(acc[r] + bv);
+                    for (int r = 0; r < 16; ++r) res[acc_row(r, lf) * 3 + c] = gelu_fast(acc[r] + bv);
                 }
                 panel_end();
             }
@@ -320,15 +324,20 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             if (step == 0 || pcd_step != 0) {
                 const float* pcd_s = pcd_b + (size_t)step * pcd_step;
                 const float* o12_s = o12 + (size_t)step * o12_step;
-                if (lane < kSlots * 3) {
-                    const int op = lane / 3, c = lane - op * 3;
+                // (the lane index of the scalar sections is laundered at each of them: formed from `lane` itself, the element addresses of
+                // x / noise / out_* / the LDS slots are loop-invariant per-lane values that hipcc hoists out of the step loop and then
+                // spills -- 41 VGPRs of scratch in round 3's build; recomputing them costs a handful of VALU instructions per section)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                if (ln < kSlots * 3) {
+                    const int op = ln / 3, c = ln - op * 3;
                     float s = 0.0f;
                     for (int k = 0; k < 12; ++k) s = fmaf(o12_s[((size_t)b * kSlots + op) * 12 + k], pwt.w[c * 15 + 3 + k], s);
-                    oterm[lane] = s;
+                    oterm[ln] = s;
                 }
                 wave_sync();
 #pragma unroll 1
-                for (int i = lane; i < 96; i += 64) {
+                for (int i = ln; i < 96; i += 64) {
                     const int row = i / 3, c = i - row * 3, n = n0 + row;
                     float acc = 0.0f;
                     for (int op = 0; op < kSlots; ++op) {
@@ -344,8 +353,10 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                 wave_sync();
             }
             // in-place update of x (Q5); the caller's tensor sees it when the launch is a single step
+            int lu = lane;
+            asm volatile("" : "+v"(lu));
 #pragma unroll 1
-            for (int i = lane; i < 96; i += 64) {
+            for (int i = lu; i < 96; i += 64) {
                 const float xv = xs[i] + gt[i];
                 zt[i] = xv;
                 if (!chain && live) x[g0 + i] = xv;
@@ -420,8 +431,10 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
             // ---- denoiser on the mutated x + sampler update -----------------------------------------------------------------------
             pass(zt, S);
             wave_sync();
+            int ls = lane;
+            asm volatile("" : "+v"(ls));
 #pragma unroll 1
-            for (int i = lane; i < 96; i += 64) {
+            for (int i = ls; i < 96; i += 64) {
                 const float x0 = res[i];
                 if (last && live) out_x0[g0 + i] = x0;
                 if (mode != MODE_FORWARD) {
@@ -458,8 +471,10 @@ __global__ __launch_bounds__(NT) void denoise_r_kernel(const __bf16* __restrict_
                     }
                 pass(gt, S);
                 wave_sync();
+                int lg = lane;
+                asm volatile("" : "+v"(lg));
 #pragma unroll 1
-                for (int i = lane; i < 96; i += 64)
+                for (int i = lg; i < 96; i += 64)
                     if (live) out_guiding[g0 + i] = res[i];
                 wave_sync();
             }
