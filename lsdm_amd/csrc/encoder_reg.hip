@@ -423,6 +423,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
                 lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
         }
     };
+    // the same copy piecewise, issued from inside the channel blocks of the panel before it (LSDM_FPS_SPREAD): the copies of a wave then
+    // issue in the shadow of its own matrix instructions instead of as one block in front of them (sa_w_kernel, encoder_u.hip)
+#ifndef LSDM_FPS_SPREAD
+#define LSDM_FPS_SPREAD 1
+#endif
+    constexpr bool SPREAD = LSDM_FPS_SPREAD != 0 && FPN % (NW * NBP) == 0;
+    constexpr int PPB = FPN / NW / NBP;                      // pieces per channel block and wave
+    auto fetch_pieces = [&](int q, int blk) {
+        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FPN * 512);
+#pragma unroll
+        for (int i = blk * PPB; i < (blk + 1) * PPB; ++i) {
+            const int fr = wave + i * NW;
+            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
+        }
+    };
     fetch(0);
     lds_dma_wait();
     __syncthreads();
@@ -483,6 +498,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
         // next layer's two k-step fragments
 #define FP_BLOCK(L, NBI, XH, XL, OH, OL)   /* channel block NBI of layer L, read from the panel that holds it */                                                                                     \
     {                                                                                                                        \
+        if constexpr (SPREAD) fetch_pieces(nextq, (NBI) % NBP);                                                              \
         f32x16 acc;                                                                                                          \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                      \
             const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + lz + (L) * C + 32 * (NBI) + 8 * q + 4 * h);               \
@@ -509,7 +525,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
         // this layer's panel, then wait for the own copies and the barrier that publishes the panel
 #define FP_PANEL(L, H, XH, XL, OH, OL, BODY)                                                                                 \
     {                                                                                                                        \
-        fetch(((L) * PH + (H) + 1) % (NL * PH));                                                                             \
+        constexpr int nextq = ((L) * PH + (H) + 1) % (NL * PH);                                                              \
+        if constexpr (!SPREAD) fetch(nextq);                                                                                 \
         const __bf16* W = &wl[((L) * PH + (H)) & 1][0];                                                                      \
         int lz = 0;                                                                                                          \
         asm volatile("" : "+v"(lz));                                                                                         \
