@@ -1045,6 +1045,23 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     const int cb0 = mw % TS::CSTEP;
     const int cb2 = mw % T2::CSTEP, rg2 = mw / T2::CSTEP;
     const float bv2 = l2.b[cb2 * 32 + (lane & 31)];
+    // LSDM_FP2_W2REG: the wave's layer-2 fragments (its channel block x all of K: 128 registers) stay resident -- a third of what a tile
+    // pulls through the L1
+#ifndef LSDM_FP2_W2REG
+#define LSDM_FP2_W2REG 1
+#endif
+    constexpr bool W2REG = LSDM_FP2_W2REG != 0;
+    constexpr int KS2 = C1 / 16;
+    [[maybe_unused]] bf16x8 w2h[KS2], w2l[KS2];
+    if constexpr (W2REG) {
+        static_assert(T2::WPC == 1 && T2::RB == TM / 32, "one layer-2 channel block per matrix wave, all rows");
+        const size_t ws2 = (size_t)C2 * NP * 16;
+        const __bf16* wp2 = l2.w + ((size_t)(cb2 * 32 + p) * NP) * 16 + 8 * h;
+#pragma unroll
+        for (int u = 0; u < KS2; ++u) { w2h[u] = gload<bf16x8>(wp2 + (size_t)u * ws2); w2l[u] = gload<bf16x8>(wp2 + (size_t)u * ws2 + 16); }
+#pragma unroll
+        for (int u = 0; u < KS2; ++u) asm volatile("" : "+v"(w2h[u]), "+v"(w2l[u]));
+    }
     // layer-1 weights of the wave's channel blocks stay in registers for the life of the work-group (D1 = 64: 16 fragments = 64 VGPRs):
     // a third of the weight bytes a tile pulls through the L1 (the kernel is bound by that path: TA 68 % busy, profiles/r04_a_pmc_mem.json)
 #ifndef LSDM_FP2_W1REG
@@ -1069,7 +1086,9 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
         // (the weight streams are loop-invariant: laundered, or hipcc hoists their addresses and first fragments out of the tile loop
         // and spills them)
         const __bf16* const w1p = opaque_ptr(l1.w);
-        const __bf16* const w2p = opaque_ptr(l2.w);
+        [[maybe_unused]] const __bf16* const w2p = opaque_ptr(l2.w);
+        int pv = p, hv = h, lv = lane;
+        asm volatile("" : "+v"(pv), "+v"(hv), "+v"(lv));       // (per-lane addresses formed per tile, not hoisted and kept across the loop)
         __syncthreads();                                   // B1
         WS_MARK(0);
         // accumulators start from the interpolated rows (transposed product: lane owns channels 8 qd + 4 h + j of point p)
@@ -1079,14 +1098,14 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
             for (int rb = 0; rb < RB1; ++rb)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + pv) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * hv) ^ tile_swz(pv)));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
                 }
         if constexpr (W1REG) {
             // layer 1 against the wave's RESIDENT weight fragments (same instruction order as mma_kloop_pre_h: per k-step and point block
             // hi x lo, lo x hi, hi x hi)
-            const __bf16* xp = bufX + p * LDX + 8 * h;
+            const __bf16* xp = bufX + pv * LDX + 8 * hv;
 #pragma unroll
             for (int q = 0; q < NCB; ++q)
 #pragma unroll
@@ -1106,7 +1125,7 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
                 }
         } else {
 #pragma unroll
-            for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lane);
+            for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lv);
         }
         WS_MARK(1);
         __syncthreads();                                   // B2
@@ -1115,8 +1134,8 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
         for (int q = 0; q < NCB; ++q) {
             f32x4 bv1[4];        // (from LDS at its use: 32 registers less across the tile loop)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h);
-            store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1, bufB, LDB, PB, lane);
+            for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * hv);
+            store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1, bufB, LDB, PB, lv);
         }
         WS_MARK(3);
         __syncthreads();                                   // B3
@@ -1127,13 +1146,31 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
             // one 16-byte store per lane and quad was measured SLOWER here and in lin_u / fp3's extra layer: sa3 315 -> 329, fp2 310 -> 323 us)
             f32x16 a2[T2::RB];
             acc_zero_h(a2);
-            const int col = cb2 * 32 + (lane & 31);
-            mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, w2p, C2, cb2, 0, lane);
+            const int col = cb2 * 32 + (lv & 31);
+            if constexpr (W2REG) {
+                const __bf16* bp = bufB + pv * LDB + 8 * hv;
+#pragma unroll
+                for (int u = 0; u < KS2; ++u) {
+                    bf16x8 xh[T2::RB], xl[T2::RB];
+#pragma unroll
+                    for (int rb = 0; rb < T2::RB; ++rb) {
+                        xh[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16);
+                        xl[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16 + PB);
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < T2::RB; ++rb) {
+                        a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], w2h[u], a2[rb], 0, 0, 0);
+                        a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2l[u], a2[rb], 0, 0, 0);
+                        a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2h[u], a2[rb], 0, 0, 0);
+                    }
+                }
+            } else
+                mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, w2p, C2, cb2, 0, lv);
 #pragma unroll
             for (int rb = 0; rb < T2::RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lane);
+                    const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lv);
                     out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv2);
                 }
         }
@@ -1144,6 +1181,228 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     }
     WS_FLUSH(0, ntl);
 #undef FPW_CH
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp2 with the weights RESIDENT IN REGISTERS (round 4c).  fp_ws_kernel showed what the stage is bound by: the L2 -> L1 fill path of the
+// CU (TA 68 % busy), and half of what a tile pulls through it are the 192 KB of weight fragments every tile re-reads.  Here a
+// work-group is four waves, ONE per SIMD, each with the whole 512-entry register file (as sa_w_kernel): wave w keeps the fragments of
+// ITS channel blocks for the life of the persistent work-group -- layer 1 blocks {w, w + 4} (64 registers), layer 2 block w (128) --
+// so a tile moves only its own data through the L1: the three Y rows and the p1 row of its points (208 KB) and its output.  The
+// four waves are also the gatherers (256 threads, the mapping of fp_pre_kernel's phase A); the rows of tile n + 1 are requested in two
+// batches of 24 pieces inside tile n's barrier intervals and interpolated behind its matrix instructions.  Same arithmetic in the
+// same order as fp_pre_kernel / fp_ws_kernel: bit-identical results.
+//   A   T(n), bufX(n) complete              requests batch 1 + p1 of tile n + 1;  accumulators <- T
+//   B   T free                              layer 1 (resident W1 x bufX);  batch 1 -> T, requests batch 2;  ReLU + split -> bufB
+//   C   bufB complete, bufX free            p1 -> bufX;  layer 2 (resident W2 x bufB);  batch 2 -> T;  stores;  indices of tile n + 2
+template <int D1, int C1, int C2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fp_rw_kernel(
+    const float* __restrict__ points1, const int* __restrict__ p1_remap, const float* __restrict__ y, const int* __restrict__ nn_idx,
+    const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2, float* __restrict__ out, int p1_mod, int total_tiles) {
+    constexpr int TM = 64, NW = 4, NP = 2, NT = 256, TPP = NT / TM;
+    static_assert(TPP == 4 && C1 % 64 == 0 && D1 % 16 == 0, "tile");
+    constexpr int LDT = C1;
+    auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
+    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
+    __shared__ __attribute__((aligned(16))) float tile[TM * LDT];
+    __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
+    __shared__ __attribute__((aligned(16))) __bf16 bufB[NP * PB];
+    __shared__ __attribute__((aligned(16))) float b1s[C1];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int e = tid; e < C1; e += NT) b1s[e] = l1.b[e];
+    const int tpc = N / TM;
+    const XcdRounds R = xcd_rounds(total_tiles);
+    int p = lane & 31, h = lane >> 5;
+
+    // ---- resident weights ----
+    using TS = SplitH<NW, TM, C1>;
+    constexpr int NCB = TS::CB / TS::CSTEP, RB1 = TS::RB, KS1 = D1 / 16, KS2 = C1 / 16;
+    static_assert(TS::WPC == 1 && TS::CSTEP == NW, "layer-1 split");
+    using T2 = SplitH<NW, TM, C2>;
+    static_assert(T2::CB == NW && T2::RB == TM / 32, "one layer-2 channel block per wave");
+    constexpr int RB2 = T2::RB;
+    bf16x8 w1h[NCB][KS1], w1l[NCB][KS1], w2h[KS2], w2l[KS2];
+    {
+        const size_t ws1 = (size_t)C1 * NP * 16, ws2 = (size_t)C2 * NP * 16;
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) {
+            const __bf16* wp = l1.w + ((size_t)((wave + q * NW) * 32 + p) * NP) * 16 + 8 * h;
+#pragma unroll
+            for (int u = 0; u < KS1; ++u) { w1h[q][u] = gload<bf16x8>(wp + (size_t)u * ws1); w1l[q][u] = gload<bf16x8>(wp + (size_t)u * ws1 + 16); }
+        }
+        const __bf16* wp2 = l2.w + ((size_t)(wave * 32 + p) * NP) * 16 + 8 * h;
+#pragma unroll
+        for (int u = 0; u < KS2; ++u) { w2h[u] = gload<bf16x8>(wp2 + (size_t)u * ws2); w2l[u] = gload<bf16x8>(wp2 + (size_t)u * ws2 + 16); }
+        // (opaque from here on: values in registers, not loads the compiler may sink back into the tile loop)
+#pragma unroll
+        for (int q = 0; q < NCB; ++q)
+#pragma unroll
+            for (int u = 0; u < KS1; ++u) asm volatile("" : "+a"(w1h[q][u]), "+a"(w1l[q][u]));
+#pragma unroll
+        for (int u = 0; u < KS2; ++u) asm volatile("" : "+a"(w2h[u]), "+a"(w2l[u]));
+    }
+    const float bv2 = l2.b[wave * 32 + (lane & 31)];
+
+    // ---- gather state (fp_pre_kernel's phase A mapping on 256 threads) ----
+    int arow = tid / TPP, sub = tid % TPP, tidv = tid, lanev = lane;
+    constexpr int XIT = TM * (D1 / 4) / NT;
+    constexpr int PIECES = C1 / (4 * TPP), GB = PIECES / 2;
+    int gi0 = 0, gi1 = 0, gi2 = 0, gc = 0, gn0 = 0;
+    float gw0 = 0.0f, gw1 = 0.0f, gw2 = 0.0f;
+    int xrow[XIT];
+    f32x4 gx[XIT], ga[GB], gb[GB], gd[GB];
+#define FPR_CH(sub, k) (4 * (2 * (sub) + ((k) & 1) + 2 * TPP * ((k) >> 1)))
+    auto g_indices = [&](int t) {
+        gc = t / tpc;
+        gn0 = (t - gc * tpc) * TM;
+        const size_t ao = ((size_t)gc * N + gn0 + arow) * 3;
+        if (p1_remap) {
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)gc * N + gn0 + (tidv + it * NT) / (D1 / 4)];
+        }
+        gi0 = nn_idx[ao + 0]; gi1 = nn_idx[ao + 1]; gi2 = nn_idx[ao + 2];
+        gw0 = nn_w[ao + 0]; gw1 = nn_w[ao + 1]; gw2 = nn_w[ao + 2];
+    };
+    auto g_request = [&](int k0) {
+        const float* yb = y + (size_t)gc * S * C1;
+        const float* r0 = yb + (size_t)gi0 * C1;
+        const float* r1 = yb + (size_t)gi1 * C1;
+        const float* r2 = yb + (size_t)gi2 * C1;
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int ch = FPR_CH(sub, k0 + k);
+            ga[k] = load4f(r0 + ch); gb[k] = load4f(r1 + ch); gd[k] = load4f(r2 + ch);
+        }
+    };
+    auto g_request_p1 = [&]() {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tidv + it * NT;
+            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
+            if (p1_remap) gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? gc % p1_mod : gc) * N + xrow[it]) * D1 + 4 * c4);
+            else gx[it] = load4f(points1 + ((size_t)gc * N + gn0) * D1 + (size_t)e * 4);
+        }
+    };
+    auto g_interp = [&](int k0) {
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int ch = FPR_CH(sub, k0 + k);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(ga[k][j], gw0), __fmul_rn(gb[k][j], gw1)), __fmul_rn(gd[k][j], gw2));
+            *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = v;
+        }
+    };
+    auto g_store_p1 = [&]() {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int e = tidv + it * NT;
+            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
+            store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
+        }
+    };
+
+    if (R.first < R.end) {
+        g_indices(R.first);
+        g_request(0);
+        g_request_p1();
+        g_interp(0);
+        g_request(GB);
+        g_interp(GB);
+        g_store_p1();
+        if (R.first + R.stride < R.end) g_indices(R.first + R.stride);
+    }
+#pragma unroll 1
+    for (int t = R.first; t < R.end; t += R.stride) {
+        const bool has_next = t + R.stride < R.end;
+        f32x16 acc[NCB][RB1];
+        // (per-lane indices laundered once per tile: every LDS / global element address below is loop-invariant per lane, and hipcc hoists
+        // ~100 of them out of the persistent loop into registers it then spills)
+        asm volatile("" : "+v"(p), "+v"(h), "+v"(arow), "+v"(sub), "+v"(tidv), "+v"(lanev));
+        __syncthreads();                                   // A
+        if (has_next) {
+            g_request(0);
+            g_request_p1();
+        }
+#pragma unroll
+        for (int q = 0; q < NCB; ++q)
+#pragma unroll
+            for (int rb = 0; rb < RB1; ++rb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((wave + q * NW) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
+                }
+        __syncthreads();                                   // B
+        {
+            // layer 1: per channel block and k-step, per point block: hi x lo, lo x hi, hi x hi (the order of mma_kloop_pre_h)
+            const __bf16* xp = bufX + p * LDX + 8 * h;
+#pragma unroll
+            for (int q = 0; q < NCB; ++q)
+#pragma unroll
+                for (int u = 0; u < KS1; ++u) {
+                    bf16x8 xh[RB1], xl[RB1];
+#pragma unroll
+                    for (int rb = 0; rb < RB1; ++rb) {
+                        xh[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16);
+                        xl[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16 + PX);
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < RB1; ++rb) {
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xl[rb], acc[q][rb], 0, 0, 0);
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[q][u], xh[rb], acc[q][rb], 0, 0, 0);
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xh[rb], acc[q][rb], 0, 0, 0);
+                    }
+                }
+        }
+        if (has_next) {
+            g_interp(0);
+            g_request(GB);
+        }
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) {
+            f32x4 bv1[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (wave + q * NW) * 32 + 8 * qd + 4 * h);
+            store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, wave + q * NW, bv1, bufB, LDB, PB, lanev);
+        }
+        __syncthreads();                                   // C
+        if (has_next) g_store_p1();
+        {
+            const int c = t / tpc, n0 = (t - c * tpc) * TM;
+            f32x16 a2[RB2];
+            acc_zero_h(a2);
+            // layer 2, direct orientation D[point][channel] (coalesced 128-byte row segments on the way out)
+            const __bf16* bp = bufB + p * LDB + 8 * h;
+#pragma unroll
+            for (int u = 0; u < KS2; ++u) {
+                bf16x8 xh[RB2], xl[RB2];
+#pragma unroll
+                for (int rb = 0; rb < RB2; ++rb) {
+                    xh[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16);
+                    xl[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16 + PB);
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB2; ++rb) {
+                    a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], w2h[u], a2[rb], 0, 0, 0);
+                    a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2l[u], a2[rb], 0, 0, 0);
+                    a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2h[u], a2[rb], 0, 0, 0);
+                }
+            }
+            if (has_next) g_interp(GB);
+            const int col = wave * 32 + (lanev & 31);
+#pragma unroll
+            for (int rb = 0; rb < RB2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb * 32 + acc_row(r, lanev);
+                    out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv2);
+                }
+        }
+        if (t + 2 * R.stride < R.end) g_indices(t + 2 * R.stride);
+    }
+#undef FPR_CH
 }
 
 #ifdef LSDM_PHASE_TIMING
@@ -1162,10 +1421,14 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
     hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
 }
 
-// LSDM_FP2_WS (default 1): fp2 on the persistent wave-specialised kernel; 0 = the tile-per-work-group form (same results)
-static bool fp2_ws() {
-    static const bool on = !(getenv("LSDM_FP2_WS") && atoi(getenv("LSDM_FP2_WS")) == 0);
-    return on;
+// LSDM_FP2_WS: fp2 on 2 = the persistent kernel with register-resident weights (fp_rw_kernel), 1 = the persistent wave-specialised kernel
+// (fp_ws_kernel), 0 = the tile-per-work-group form (fp_pre_kernel).  Same results bit for bit.
+#ifndef LSDM_FP2_DEFAULT
+#define LSDM_FP2_DEFAULT 1
+#endif
+static int fp2_ws() {
+    static const int v = getenv("LSDM_FP2_WS") ? atoi(getenv("LSDM_FP2_WS")) : LSDM_FP2_DEFAULT;
+    return v;
 }
 
 // y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):
@@ -1192,7 +1455,12 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
         return;
     }
     if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
-    if (which == 2 && fp2_ws()) {
+    if (which == 2 && fp2_ws() == 2) {
+        const int total = 1024 / 64 * nc;
+        hipLaunchKernelGGL((fp_rw_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
+                           out, p1_mod, total);
+    }
+    else if (which == 2 && fp2_ws()) {
         const int total = 1024 / 64 * nc;
         hipLaunchKernelGGL((fp_ws_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
                            out, p1_mod, total);
