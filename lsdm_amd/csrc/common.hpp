@@ -77,6 +77,42 @@ __device__ __forceinline__ unsigned lds_addr(const T* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) T*)p;
 }
 
+// Three-neighbour interpolation of one value (pointnet2_utils.py:299-303: torch.sum(points[idx] * w, dim=2)) with its rounding sequence
+// SPELLED OUT -- a w0, then two fused multiply-adds -- and each step kept a SCALAR VALU instruction (the empty asm statements):
+//  * written as plain arithmetic (or with __fmul_rn / __fadd_rn, which do not stop contraction) hipcc fuses one of the products into an
+//    add, and WHICH one differs from call site to call site: two inlined copies of the same expression disagreed in the last bit (fp2's
+//    three kernels on the second tile of a persistent work-group, round 4);
+//  * left to itself hipcc packs the four values of a 16-byte piece into v_pk_mul_f32 / v_pk_fma_f32 with op_sel operand selection (the
+//    low lane takes the weight from the HIGH register of the pair).  In the gather waves of the wave-specialised kernels (fp_ws_kernel,
+//    fp_s_kernel: one gather and one MFMA wave per SIMD) these lost an update now and then: the first packed FMAs after the wave woke
+//    from a long s_waitcnt vmcnt(0) came out WITHOUT their b w1 term in the low lane of lanes 48..63 (tools/fp2_reveal.py makes the
+//    interpolated rows visible in fp2's output: got = a w0 + d w2 exactly).  88 of 100 forwards at B = 16 had a few such rows in fp2, 4
+//    of 400 in fp1; nothing else changes run to run.  With scalar instructions: 0 of 400 (tools/determinism_stress.py,
+//    tests/test_hip_determinism.py).  Same speed: the gather waves have VALU slots to spare.
+__device__ __forceinline__ float interp3(float a, float b, float d, float w0, float w1, float w2) {
+#ifdef LSDM_INTERP_PACKED
+    return __builtin_fmaf(d, w2, __builtin_fmaf(b, w1, a * w0));       // (A/B only: reproduces the lost updates)
+#else
+    float t = a * w0;
+    asm("" : "+v"(t));
+    t = __builtin_fmaf(b, w1, t);
+    asm("" : "+v"(t));
+    t = __builtin_fmaf(d, w2, t);
+    asm("" : "+v"(t));
+    return t;
+#endif
+}
+
+// Work-group barrier of the persistent kernels that hand plain LDS stores from one wave to another: an explicit wait for the wave's LDS
+// operations in front of it.  __syncthreads() alone was NOT enough in fp_ws_kernel: hipcc (ROCm 7.2, gfx950) emitted the barrier at the
+// head of the tile loop without `s_waitcnt lgkmcnt(0)` although the loop's latch ends in ds_write instructions -- the other role's waves read
+// the interpolated tile before the stores had landed (a few hundred wrong elements per launch under load; round 4, tools/race_hunt.py).
+// Only lgkmcnt: the gather loads in flight across the barrier must not be waited for.
+__device__ __forceinline__ void wg_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // C/D map of the 32x32 MFMA shapes (dtype-independent on gfx950): col = lane & 31, row = acc_row(r, lane)
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

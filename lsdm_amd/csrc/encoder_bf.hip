@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void fp_h_kernel(const typename FeatT
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        v[j] = __fadd_rn(__fadd_rn(__fmul_rn(f0[it][j], w0[it]), __fmul_rn(f1[it][j], w1[it])), __fmul_rn(f2[it][j], w2[it]));
+                        v[j] = interp3(f0[it][j], f1[it][j], f2[it][j], w0[it], w1[it], w2[it]);
                     store_split4<NP>(bufX + row * LDX + 4 * c4, PX, v[0], v[1], v[2], v[3]);
                 }
             }

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        v[4 * q + j] = __fadd_rn(__fadd_rn(__fmul_rn(a[s][q][j], w0), __fmul_rn(b[s][q][j], w1)), __fmul_rn(d[s][q][j], w2));
+                        v[4 * q + j] = interp3(a[s][q][j], b[s][q][j], d[s][q][j], w0, w1, w2);
                 split8<NP>(v, yh[s0 + s], yl[s0 + s]);
             }
         }

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
                 const int ch = FP_CH(sub, k0 + k);
                 f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(a[k][j], w0), __fmul_rn(b[k][j], w1)), __fmul_rn(d[k][j], w2));
+                for (int j = 0; j < 4; ++j) v[j] = interp3(a[k][j], b[k][j], d[k][j], w0, w1, w2);
                 *reinterpret_cast<f32x4*>(tile + row * LDT + (ch ^ tile_swz(row))) = v;
             }
         }
@@ -969,11 +969,13 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     auto g_interp = [&](int k0) {
 #pragma unroll
         for (int k = 0; k < GB; ++k) {
-            const int ch = FPW_CH(sub, k0 + k);
-            f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(ga[k][j], gw0), __fmul_rn(gb[k][j], gw1)), __fmul_rn(gd[k][j], gw2));
-            *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = v;
+            for (int j = 0; j < 4; ++j) ga[k][j] = interp3(ga[k][j], gb[k][j], gd[k][j], gw0, gw1, gw2);
+        }
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int ch = FPW_CH(sub, k0 + k);
+            *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = ga[k];
         }
     };
     auto g_store_p1 = [&]() {
@@ -987,6 +989,10 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
 
     // The two roles run their own loops (same trip count, three barriers per tile each): with the role test inside one loop the register
     // allocator keeps both roles' state live together (453 spilled VGPRs).
+    // (Gather schedule measured and not kept, round 4c: the WHOLE next-but-one tile requested in phase 3 -- 48 pieces + the p1 row, 208
+    // registers of loads in flight -- and interpolated in phase 2: 285 against 252 us, also with the layer-2 weights resident, i.e. with no
+    // other loads in that phase: 52 back-to-back requests per thread are throttled at the texture addresser; two batches spread over the
+    // three phases keep more of them in flight.)
     if (gath) {
         // prologue: the first tile of the work-group, and the indices of the second
         if (R.first < R.end) {
@@ -1004,21 +1010,21 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
 #pragma unroll 1
         for (int t = R.first; t < R.end; t += R.stride) {
             const bool has_next = t + R.stride < R.end;
-            __syncthreads();                                   // B1
+            wg_sync();                                   // B1
             WS_MARK(0);
             if (has_next) {
                 g_request(0);
                 g_request_p1();
             }
             WS_MARK(1);
-            __syncthreads();                                   // B2
+            wg_sync();                                   // B2
             WS_MARK(2);
             if (has_next) {
                 g_interp(0);
                 g_request(GB);
             }
             WS_MARK(3);
-            __syncthreads();                                   // B3
+            wg_sync();                                   // B3
             WS_MARK(4);
             if (has_next) {
                 g_interp(GB);
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
         [[maybe_unused]] const __bf16* const w2p = opaque_ptr(l2.w);
         int pv = p, hv = h, lv = lane;
         asm volatile("" : "+v"(pv), "+v"(hv), "+v"(lv));       // (per-lane addresses formed per tile, not hoisted and kept across the loop)
-        __syncthreads();                                   // B1
+        wg_sync();                                   // B1
         WS_MARK(0);
         // accumulators start from the interpolated rows (transposed product: lane owns channels 8 qd + 4 h + j of point p)
 #pragma unroll
@@ -1128,7 +1134,7 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
             for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lv);
         }
         WS_MARK(1);
-        __syncthreads();                                   // B2
+        wg_sync();                                   // B2
         WS_MARK(2);
 #pragma unroll
         for (int q = 0; q < NCB; ++q) {
@@ -1138,7 +1144,7 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
             store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1, bufB, LDB, PB, lv);
         }
         WS_MARK(3);
-        __syncthreads();                                   // B3
+        wg_sync();                                   // B3
         WS_MARK(4);
         {
             const int c = t / tpc, n0 = (t - c * tpc) * TM;
@@ -1289,7 +1295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int ch = FPR_CH(sub, k0 + k);
             f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fadd_rn(__fmul_rn(ga[k][j], gw0), __fmul_rn(gb[k][j], gw1)), __fmul_rn(gd[k][j], gw2));
+            for (int j = 0; j < 4; ++j) v[j] = interp3(ga[k][j], gb[k][j], gd[k][j], gw0, gw1, gw2);
             *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = v;
         }
     };
@@ -1319,7 +1325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // (per-lane indices laundered once per tile: every LDS / global element address below is loop-invariant per lane, and hipcc hoists
         // ~100 of them out of the persistent loop into registers it then spills)
         asm volatile("" : "+v"(p), "+v"(h), "+v"(arow), "+v"(sub), "+v"(tidv), "+v"(lanev));
-        __syncthreads();                                   // A
+        wg_sync();                                   // A
         if (has_next) {
             g_request(0);
             g_request_p1();
@@ -1334,7 +1340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
                 }
-        __syncthreads();                                   // B
+        wg_sync();                                   // B
         {
             // layer 1: per channel block and k-step, per point block: hi x lo, lo x hi, hi x hi (the order of mma_kloop_pre_h)
             const __bf16* xp = bufX + p * LDX + 8 * h;
@@ -1367,7 +1373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (wave + q * NW) * 32 + 8 * qd + 4 * h);
             store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, wave + q * NW, bv1, bufB, LDB, PB, lanev);
         }
-        __syncthreads();                                   // C
+        wg_sync();                                   // C
         if (has_next) g_store_p1();
         {
             const int c = t / tpc, n0 = (t - c * tpc) * TM;
@@ -1427,8 +1433,8 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
 #define LSDM_FP2_DEFAULT 1
 #endif
 static int fp2_ws() {
-    static const int v = getenv("LSDM_FP2_WS") ? atoi(getenv("LSDM_FP2_WS")) : LSDM_FP2_DEFAULT;
-    return v;
+    const char* e = getenv("LSDM_FP2_WS");      // (read per launch: the A/B tests flip it inside one process)
+    return e ? atoi(e) : LSDM_FP2_DEFAULT;
 }
 
 // y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):

@@ -27,9 +27,18 @@ side = torch.cuda.Stream()
 a = torch.randn(4096, 4096, device=DEV)
 nc = B * 9
 names = [("feat1", nc * 1024 * 64), ("feat2", nc * 256 * 128), ("feat3", nc * 64 * 256), ("feat4", nc * 16 * 512), ("fp4", nc * 64 * 256),
-         ("fp3", nc * 256 * 256), ("fp2", nc * 1024 * 128), ("pcd", nc * 3072), ("o12", nc * 12), ("hm", B * 3072)]
+         ("fp3", nc * 256 * 256), ("fp4_y", nc * 16 * 256), ("fp3_y", nc * 64 * 256), ("fp2_y", nc * 256 * 256), ("fp2", nc * 1024 * 128), ("pcd", nc * 3072), ("o12", nc * 12), ("hm", B * 3072)]
 ref = None
+GOOD = os.environ.get("GOOD_WS")          # e.g. GOOD_WS=0: run 0 (the reference) is made with LSDM_FP2_WS=0, the others with the environment's setting
+keep_ws = os.environ.get("LSDM_FP2_WS")
 for it in range(int(os.environ.get("N", 12))):
+    if GOOD is not None:
+        if it == 0:
+            os.environ["LSDM_FP2_WS"] = GOOD
+        elif keep_ws is None:
+            os.environ.pop("LSDM_FP2_WS", None)
+        else:
+            os.environ["LSDM_FP2_WS"] = keep_ws
     if it > 0:
         with torch.cuda.stream(side):
             for _ in range(40):
@@ -45,3 +54,13 @@ for it in range(int(os.environ.get("N", 12))):
         continue
     bad = [(n, int((cur[n] != ref[n]).sum()), float((cur[n] - ref[n]).abs().max())) for n in cur if not torch.equal(cur[n], ref[n])]
     print("iter %d:" % it, bad if bad else "identical", flush=True)
+    if "fp2" in dict((b[0], 1) for b in bad) and os.environ.get("WHERE"):
+        d = (cur["fp2"] != ref["fp2"]).view(nc, 1024, 128)
+        rows = d.any(dim=2).nonzero()
+        tl = sorted(set(c * 16 + n // 64 for c, n in rows.tolist()))
+        print("    bad tiles (round, wg-in-xcd): %s" % [(t_, (t_ % 288) // 32, (t_ % 288) % 32) for t_ in tl], flush=True)
+        for c, n in rows.tolist()[:int(os.environ.get("WHERE"))]:
+            ch = d[c, n].nonzero().flatten().tolist()
+            tile = c * 16 + n // 64
+            print("    cloud %d point %d (tile %d, row %d): %d channels, first %s; max err %.3g" % (c, n, tile, n % 64, len(ch), ch[:6],
+                  float((cur["fp2"].view(nc, 1024, 128)[c, n] - ref["fp2"].view(nc, 1024, 128)[c, n]).abs().max())), flush=True)
