@@ -927,9 +927,21 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
 
     // ---------------- gather role: state of the tile being fetched ----------------
     const int gt = tid & (NTG - 1);
-    const int arow = gt / TPP, sub = gt % TPP;
     constexpr int XIT = TM * (D1 / 4) / NTG;
-    constexpr int PIECES = C1 / (4 * TPP), GB = PIECES / 2;        // two batches of GB pieces x 3 rows per thread
+    // LSDM_FPW_ROWS (default): one wave instruction fetches ONE WHOLE Y ROW -- 64 lanes x 16 bytes = 1 KB = eight full cache lines, its
+    // address wave-uniform (index and weights of the point read out of a lane with v_readlane: scalar address arithmetic, weights as SGPR
+    // operands) -- and the interpolated row is one conflict-free 1 KB LDS store.  0 = the round-3 mapping (four lanes per point, each lane 16
+    // bytes of every other 32: an instruction touches 16 rows and HALF of each of their lines; every line is requested by two instructions).
+    // The stage is bound by the L1's access rate (TCP busy 62 %, TA 68 %, profiles/r04_a_pmc_mem.json): the row form halves its accesses.
+#ifndef LSDM_FPW_ROWS
+#define LSDM_FPW_ROWS 1
+#endif
+    constexpr bool ROWS = LSDM_FPW_ROWS != 0;
+    constexpr int PIECES = C1 / (4 * TPP), GB = PIECES / 2;        // two batches per thread: GB pieces x 3 rows (ROWS: GB points x 3 rows)
+    constexpr int PPW = TM / (NTG / 64);                            // ROWS: points per gather wave
+    static_assert(!ROWS || (C1 == 4 * 64 && PPW == 2 * GB && 3 * PPW <= 64), "a Y row is one wave-wide 16-byte load; two batches of GB points");
+    [[maybe_unused]] const int arow = gt / TPP, sub = gt % TPP;
+    [[maybe_unused]] const int gwv = wave - NWM;                    // gather wave 0 .. 3: points PPW gwv .. of the tile
     int gi0 = 0, gi1 = 0, gi2 = 0, gc = 0, gn0 = 0;
     float gw0 = 0.0f, gw1 = 0.0f, gw2 = 0.0f;
     int xrow[XIT];
@@ -938,23 +950,40 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     auto g_indices = [&](int t) {
         gc = t / tpc;
         gn0 = (t - gc * tpc) * TM;
-        const size_t ao = ((size_t)gc * N + gn0 + arow) * 3;
         if (p1_remap) {
 #pragma unroll
             for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)gc * N + gn0 + (gt + it * NTG) / (D1 / 4)];
         }
-        gi0 = nn_idx[ao + 0]; gi1 = nn_idx[ao + 1]; gi2 = nn_idx[ao + 2];
-        gw0 = nn_w[ao + 0]; gw1 = nn_w[ao + 1]; gw2 = nn_w[ao + 2];
+        if constexpr (ROWS) {       // lane L < 3 PPW: index / weight of (point L / 3, neighbour L % 3) of the wave's points -- one coalesced load each
+            const size_t ao = ((size_t)gc * N + gn0 + PPW * gwv) * 3 + (lane < 3 * PPW ? lane : 3 * PPW - 1);
+            gi0 = nn_idx[ao];
+            gw0 = nn_w[ao];
+        } else {
+            const size_t ao = ((size_t)gc * N + gn0 + arow) * 3;
+            gi0 = nn_idx[ao + 0]; gi1 = nn_idx[ao + 1]; gi2 = nn_idx[ao + 2];
+            gw0 = nn_w[ao + 0]; gw1 = nn_w[ao + 1]; gw2 = nn_w[ao + 2];
+        }
     };
     auto g_request = [&](int k0) {
-        const float* yb = y + (size_t)gc * S * C1;
-        const float* r0 = yb + (size_t)gi0 * C1;
-        const float* r1 = yb + (size_t)gi1 * C1;
-        const float* r2 = yb + (size_t)gi2 * C1;
+        if constexpr (ROWS) {
+            const float* yb = y + (size_t)gc * S * C1 + 4 * lane;
+            const int q0 = k0 ? GB : 0;
 #pragma unroll
-        for (int k = 0; k < GB; ++k) {
-            const int ch = FPW_CH(sub, k0 + k);
-            ga[k] = load4f(r0 + ch); gb[k] = load4f(r1 + ch); gd[k] = load4f(r2 + ch);
+            for (int q = 0; q < GB; ++q) {
+                const int ia = __builtin_amdgcn_readlane(gi0, 3 * (q0 + q) + 0), ib = __builtin_amdgcn_readlane(gi0, 3 * (q0 + q) + 1),
+                          ic = __builtin_amdgcn_readlane(gi0, 3 * (q0 + q) + 2);
+                ga[q] = load4f(yb + (size_t)ia * C1); gb[q] = load4f(yb + (size_t)ib * C1); gd[q] = load4f(yb + (size_t)ic * C1);
+            }
+        } else {
+            const float* yb = y + (size_t)gc * S * C1;
+            const float* r0 = yb + (size_t)gi0 * C1;
+            const float* r1 = yb + (size_t)gi1 * C1;
+            const float* r2 = yb + (size_t)gi2 * C1;
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int ch = FPW_CH(sub, k0 + k);
+                ga[k] = load4f(r0 + ch); gb[k] = load4f(r1 + ch); gd[k] = load4f(r2 + ch);
+            }
         }
     };
     auto g_request_p1 = [&]() {
@@ -967,15 +996,30 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
         }
     };
     auto g_interp = [&](int k0) {
+        if constexpr (ROWS) {
+            const int gwf = __builtin_bit_cast(int, gw0);
+            const int q0 = k0 ? GB : 0;
 #pragma unroll
-        for (int k = 0; k < GB; ++k) {
+            for (int q = 0; q < GB; ++q) {
+                const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 0)),
+                            wb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 1)),
+                            wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 2));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ga[k][j] = interp3(ga[k][j], gb[k][j], gd[k][j], gw0, gw1, gw2);
-        }
+                for (int j = 0; j < 4; ++j) ga[q][j] = interp3(ga[q][j], gb[q][j], gd[q][j], wa, wb, wc);
+                const int row = PPW * gwv + q0 + q;
+                *reinterpret_cast<f32x4*>(tile + row * LDT + ((4 * lane) ^ tile_swz(row))) = ga[q];
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < GB; ++k) {
-            const int ch = FPW_CH(sub, k0 + k);
-            *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = ga[k];
+            for (int k = 0; k < GB; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ga[k][j] = interp3(ga[k][j], gb[k][j], gd[k][j], gw0, gw1, gw2);
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int ch = FPW_CH(sub, k0 + k);
+                *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = ga[k];
+            }
         }
     };
     auto g_store_p1 = [&]() {
