@@ -928,62 +928,43 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     // ---------------- gather role: state of the tile being fetched ----------------
     const int gt = tid & (NTG - 1);
     constexpr int XIT = TM * (D1 / 4) / NTG;
-    // LSDM_FPW_ROWS (default): one wave instruction fetches ONE WHOLE Y ROW -- 64 lanes x 16 bytes = 1 KB = eight full cache lines, its
-    // address wave-uniform (index and weights of the point read out of a lane with v_readlane: scalar address arithmetic, weights as SGPR
-    // operands) -- and the interpolated row is one conflict-free 1 KB LDS store.  0 = the round-3 mapping (four lanes per point, each lane 16
-    // bytes of every other 32: an instruction touches 16 rows and HALF of each of their lines; every line is requested by two instructions).
-    // The stage is bound by the L1's access rate (TCP busy 62 %, TA 68 %, profiles/r04_a_pmc_mem.json): the row form halves its accesses.
-#ifndef LSDM_FPW_ROWS
-#define LSDM_FPW_ROWS 1
-#endif
-    constexpr bool ROWS = LSDM_FPW_ROWS != 0;
-    constexpr int PIECES = C1 / (4 * TPP), GB = PIECES / 2;        // two batches per thread: GB pieces x 3 rows (ROWS: GB points x 3 rows)
-    constexpr int PPW = TM / (NTG / 64);                            // ROWS: points per gather wave
-    static_assert(!ROWS || (C1 == 4 * 64 && PPW == 2 * GB && 3 * PPW <= 64), "a Y row is one wave-wide 16-byte load; two batches of GB points");
-    [[maybe_unused]] const int arow = gt / TPP, sub = gt % TPP;
-    [[maybe_unused]] const int gwv = wave - NWM;                    // gather wave 0 .. 3: points PPW gwv .. of the tile
-    int gi0 = 0, gi1 = 0, gi2 = 0, gc = 0, gn0 = 0;
-    float gw0 = 0.0f, gw1 = 0.0f, gw2 = 0.0f;
-    int xrow[XIT];
+    // One wave instruction fetches ONE WHOLE Y ROW -- 64 lanes x 16 bytes = 1 KB = eight full cache lines, its address wave-uniform (index
+    // and weights of the point are read out of a lane with v_readlane: scalar address arithmetic, weights as SGPR operands) -- and the
+    // interpolated row is one conflict-free 1 KB LDS store.  (The round-3 mapping of fp_pre_kernel -- four lanes per point, each lane 16 bytes
+    // of every other 32: an instruction touches 16 rows and HALF of each of their lines, every line is requested by two instructions --
+    // measured 255 against 244 us here.)
+    constexpr int PPW = TM / (NTG / 64), GB = PPW / 2;               // points per gather wave; two batches of GB points x 3 rows per tile
+    static_assert(C1 == 4 * 64 && 3 * PPW <= 64, "a Y row is one wave-wide 16-byte load; a wave's indices fit its lanes");
+    const int gwv = wave - NWM;                                      // gather wave 0 .. 3: points PPW gwv .. of the tile
+    // state of the tile being fetched (gc, gn0, gi, gw, xrow) and of the one after it (*_nx: requested a whole tile ahead, so that no phase
+    // starts by waiting for an index)
+    int gc = 0, gn0 = 0, gi = 0, gc_nx = 0, gn0_nx = 0, gi_nx = 0;   // gi / gw: lane L < 3 PPW holds (point L / 3, neighbour L % 3) of the wave's points
+    float gw = 0.0f, gw_nx = 0.0f;
+    int xrow[XIT], xrow_nx[XIT];
     f32x4 gx[XIT], ga[GB], gb[GB], gd[GB];
-#define FPW_CH(sub, k) (4 * (2 * (sub) + ((k) & 1) + 2 * TPP * ((k) >> 1)))
-    auto g_indices = [&](int t) {
-        gc = t / tpc;
-        gn0 = (t - gc * tpc) * TM;
+    auto g_indices_request = [&](int t) {
+        gc_nx = t / tpc;
+        gn0_nx = (t - gc_nx * tpc) * TM;
         if (p1_remap) {
 #pragma unroll
-            for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)gc * N + gn0 + (gt + it * NTG) / (D1 / 4)];
+            for (int it = 0; it < XIT; ++it) xrow_nx[it] = p1_remap[(size_t)gc_nx * N + gn0_nx + (gt + it * NTG) / (D1 / 4)];
         }
-        if constexpr (ROWS) {       // lane L < 3 PPW: index / weight of (point L / 3, neighbour L % 3) of the wave's points -- one coalesced load each
-            const size_t ao = ((size_t)gc * N + gn0 + PPW * gwv) * 3 + (lane < 3 * PPW ? lane : 3 * PPW - 1);
-            gi0 = nn_idx[ao];
-            gw0 = nn_w[ao];
-        } else {
-            const size_t ao = ((size_t)gc * N + gn0 + arow) * 3;
-            gi0 = nn_idx[ao + 0]; gi1 = nn_idx[ao + 1]; gi2 = nn_idx[ao + 2];
-            gw0 = nn_w[ao + 0]; gw1 = nn_w[ao + 1]; gw2 = nn_w[ao + 2];
-        }
+        const size_t ao = ((size_t)gc_nx * N + gn0_nx + PPW * gwv) * 3 + (lane < 3 * PPW ? lane : 3 * PPW - 1);      // one coalesced load each
+        gi_nx = nn_idx[ao];
+        gw_nx = nn_w[ao];
     };
-    auto g_request = [&](int k0) {
-        if constexpr (ROWS) {
-            const float* yb = y + (size_t)gc * S * C1 + 4 * lane;
-            const int q0 = k0 ? GB : 0;
+    auto g_indices_take = [&]() {
+        gc = gc_nx; gn0 = gn0_nx; gi = gi_nx; gw = gw_nx;
 #pragma unroll
-            for (int q = 0; q < GB; ++q) {
-                const int ia = __builtin_amdgcn_readlane(gi0, 3 * (q0 + q) + 0), ib = __builtin_amdgcn_readlane(gi0, 3 * (q0 + q) + 1),
-                          ic = __builtin_amdgcn_readlane(gi0, 3 * (q0 + q) + 2);
-                ga[q] = load4f(yb + (size_t)ia * C1); gb[q] = load4f(yb + (size_t)ib * C1); gd[q] = load4f(yb + (size_t)ic * C1);
-            }
-        } else {
-            const float* yb = y + (size_t)gc * S * C1;
-            const float* r0 = yb + (size_t)gi0 * C1;
-            const float* r1 = yb + (size_t)gi1 * C1;
-            const float* r2 = yb + (size_t)gi2 * C1;
+        for (int it = 0; it < XIT; ++it) xrow[it] = xrow_nx[it];
+    };
+    auto g_request = [&](int q0) {
+        const float* yb = y + (size_t)gc * S * C1 + 4 * lane;
 #pragma unroll
-            for (int k = 0; k < GB; ++k) {
-                const int ch = FPW_CH(sub, k0 + k);
-                ga[k] = load4f(r0 + ch); gb[k] = load4f(r1 + ch); gd[k] = load4f(r2 + ch);
-            }
+        for (int q = 0; q < GB; ++q) {
+            const int ia = __builtin_amdgcn_readlane(gi, 3 * (q0 + q) + 0), ib = __builtin_amdgcn_readlane(gi, 3 * (q0 + q) + 1),
+                      ic = __builtin_amdgcn_readlane(gi, 3 * (q0 + q) + 2);
+            ga[q] = load4f(yb + (size_t)ia * C1); gb[q] = load4f(yb + (size_t)ib * C1); gd[q] = load4f(yb + (size_t)ic * C1);
         }
     };
     auto g_request_p1 = [&]() {
@@ -995,31 +976,17 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
             else gx[it] = load4f(points1 + ((size_t)gc * N + gn0) * D1 + (size_t)e * 4);
         }
     };
-    auto g_interp = [&](int k0) {
-        if constexpr (ROWS) {
-            const int gwf = __builtin_bit_cast(int, gw0);
-            const int q0 = k0 ? GB : 0;
+    auto g_interp = [&](int q0) {
+        const int gwf = __builtin_bit_cast(int, gw);
 #pragma unroll
-            for (int q = 0; q < GB; ++q) {
-                const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 0)),
-                            wb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 1)),
-                            wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 2));
+        for (int q = 0; q < GB; ++q) {
+            const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 0)),
+                        wb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 1)),
+                        wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 2));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ga[q][j] = interp3(ga[q][j], gb[q][j], gd[q][j], wa, wb, wc);
-                const int row = PPW * gwv + q0 + q;
-                *reinterpret_cast<f32x4*>(tile + row * LDT + ((4 * lane) ^ tile_swz(row))) = ga[q];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < GB; ++k) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ga[k][j] = interp3(ga[k][j], gb[k][j], gd[k][j], gw0, gw1, gw2);
-            }
-#pragma unroll
-            for (int k = 0; k < GB; ++k) {
-                const int ch = FPW_CH(sub, k0 + k);
-                *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = ga[k];
-            }
+            for (int j = 0; j < 4; ++j) ga[q][j] = interp3(ga[q][j], gb[q][j], gd[q][j], wa, wb, wc);
+            const int row = PPW * gwv + q0 + q;
+            *reinterpret_cast<f32x4*>(tile + row * LDT + ((4 * lane) ^ tile_swz(row))) = ga[q];
         }
     };
     auto g_store_p1 = [&]() {
@@ -1038,27 +1005,31 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     // other loads in that phase: 52 back-to-back requests per thread are throttled at the texture addresser; two batches spread over the
     // three phases keep more of them in flight.)
     if (gath) {
-        // prologue: the first tile of the work-group, and the indices of the second
+        // prologue: the first tile of the work-group, the indices of the second and the first batch of its rows
         if (R.first < R.end) {
-            g_indices(R.first);
+            g_indices_request(R.first);
+            g_indices_take();
             g_request(0);
             g_request_p1();
+            const bool second = R.first + R.stride < R.end;
+            if (second) g_indices_request(R.first + R.stride);
             g_interp(0);
             g_request(GB);
             g_interp(GB);
             g_store_p1();
-            if (R.first + R.stride < R.end) g_indices(R.first + R.stride);
+            g_indices_take();
+            if (second) g_request(0);
         }
         WS_T0();
         [[maybe_unused]] int ntl = 0;
 #pragma unroll 1
         for (int t = R.first; t < R.end; t += R.stride) {
-            const bool has_next = t + R.stride < R.end;
-            wg_sync();                                   // B1
+            const bool has_next = t + R.stride < R.end, has_next2 = t + 2 * R.stride < R.end;
+            wg_sync();                                   // B1   (batch 1 of tile t + stride is in flight since the end of phase 3)
             WS_MARK(0);
             if (has_next) {
-                g_request(0);
                 g_request_p1();
+                if (has_next2) g_indices_request(t + 2 * R.stride);
             }
             WS_MARK(1);
             wg_sync();                                   // B2
@@ -1073,10 +1044,10 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
             if (has_next) {
                 g_interp(GB);
                 g_store_p1();
-                if (t + 2 * R.stride < R.end) g_indices(t + 2 * R.stride);
+                g_indices_take();
+                if (has_next2) g_request(0);             // (the registers are free: the first batch of the tile after next, a phase early)
             }
 #ifdef LSDM_PHASE_TIMING
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             ++ntl;
 #endif
             WS_MARK(5);
@@ -1230,7 +1201,6 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
         WS_MARK(5);
     }
     WS_FLUSH(0, ntl);
-#undef FPW_CH
 }
 
 // ---------------------------------------------------------------------------------------------
