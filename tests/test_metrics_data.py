@@ -181,6 +181,38 @@ def test_bert_text_encoder_hook_with_stub_transformers(monkeypatch):
         SceneDiffusionModel(clip_dim=512, pcd_dim=3, use_cuda=False, text_encoder_type="BERT")._encode_text(["x"], 1, torch.device("cpu"))
 
 
+def test_bert_text_encoder_hook_runs_the_real_transformers_package(tmp_path, monkeypatch):
+    """SURVEY §8 A10 with the REAL third-party package: `transformers` is installed here, its weights are not (no network).  A local
+    directory named like the checkpoint the reference asks for (model/sdm.py:279-285 `bert-base-uncased`) with a small WordPiece vocabulary
+    and a randomly initialised two-layer, 768-wide BertModel makes `from_pretrained` resolve offline, so the hook runs the package's own
+    tokenizer (padding, attention mask, token types) and the model's pooler, and is compared with the reference's three lines executed
+    directly.  What stays unpinned is only the published WEIGHTS."""
+    transformers = pytest.importorskip("transformers")
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    monkeypatch.chdir(tmp_path)
+    d = tmp_path / "bert-base-uncased"
+    d.mkdir()
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + "a the chair table sofa bed sit on in next to person lying ##s ##ing stand walk near".split()
+    (d / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    cfg = transformers.BertConfig(vocab_size=len(vocab), hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1024)
+    torch.manual_seed(0)
+    transformers.BertModel(cfg).save_pretrained(str(d))
+    from lsdm_amd.model.sdm import SceneDiffusionModel
+    texts = ["a person sitting on the chair", "lying in bed", "walk"]
+    m = SceneDiffusionModel(clip_dim=768, pcd_dim=3, use_cuda=False, text_encoder_type="BERT")
+    feats = m._encode_text(texts, 3, torch.device("cpu"))
+    assert feats.shape == (3, 768) and feats.dtype == torch.float32 and bool(torch.isfinite(feats).all())
+    # the reference's _load_and_freeze_bert / _encode_text_bert, line for line, on the same checkpoint directory
+    tokenizer = transformers.BertTokenizer.from_pretrained("bert-base-uncased")
+    model = transformers.BertModel.from_pretrained("bert-base-uncased").eval()
+    enc = tokenizer(list(texts), padding=True, return_tensors="pt")
+    assert enc["input_ids"].shape[1] == 8 and int(enc["attention_mask"][2].sum()) == 3        # ragged prompts: padded to the longest
+    with torch.no_grad():
+        want = model(**enc).pooler_output
+    assert torch.equal(feats, want.float())
+    assert torch.equal(m._encode_text(texts, 3, torch.device("cpu")), feats)                   # frozen, eval mode: repeatable
+
+
 def test_missing_clip_package_is_reported(monkeypatch):
     monkeypatch.setitem(sys.modules, "clip", None)
     from lsdm_amd.model.sdm import _default_clip_encoder
