@@ -17,3 +17,10 @@ def test_repeated_forward_is_bit_identical_at_b16(precision):
     from determinism_stress import stress
     counts = stress(B=16, N=60 if precision == "bf16x3" else 12, precision=precision)
     assert not any(counts.values()), counts
+
+
+@pytest.mark.parametrize("entry", ["invariant", "strict", "hoisted"])
+def test_repeated_sampler_calls_are_bit_identical_at_b64(entry):
+    """The benched configuration (B = 64: 576 clouds, 36 tiles per persistent work-group), six steps per call through each bulk entry point."""
+    from determinism_stress import stress_loop
+    assert stress_loop(B=64, K=6, N=12, precision="bf16x3", entry=entry) == 0

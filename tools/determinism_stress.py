@@ -64,6 +64,28 @@ def stress(B=16, N=200, precision="bf16x3", device="cuda:0", verbose=False):
     return counts
 
 
+def stress_loop(B=64, K=6, N=30, precision="bf16x3", device="cuda:0", entry="invariant"):
+    """The benched entry points: N calls of K sampler steps from the same x_T and RNG streams (lsdm_sample_steps_invariant, lsdm_sample_steps
+    or lsdm_sample_steps_hoisted); the final sample, predicted x_0, guiding points and class logits compared with the first call's."""
+    torch.set_grad_enabled(False)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import Runner
+    dev = torch.device(device)
+    r = Runner(precision, B, 13, K, 1, dev.index or 0, dev)
+    x0 = r.x.clone()
+    ref, bad = None, 0
+    for it in range(N):
+        x = x0.clone()
+        r.run(r.T - 1, 0, K, x=x, invariant=entry == "invariant", hoisted=entry == "hoisted")
+        torch.cuda.synchronize()
+        cur = [x.clone(), r.out_x0.clone(), r.out_g.clone(), r.out_cat.clone()]
+        if ref is None:
+            ref = cur
+        elif not all(torch.equal(a, b) for a, b in zip(cur, ref)):
+            bad += 1
+    return bad
+
+
 if __name__ == "__main__":
     B = int(os.environ.get("B", 16))
     N = int(os.environ.get("N", 200))
@@ -71,4 +93,9 @@ if __name__ == "__main__":
     c = stress(B, N, prec, verbose=bool(os.environ.get("VERBOSE")))
     bad = {k: v for k, v in c.items() if v}
     print("determinism stress (%s, B=%d, %d runs): %s" % (prec, B, N, "all tensors identical in every run" if not bad else "DIFFERENCES (runs per tensor): %s" % bad), flush=True)
-    sys.exit(1 if bad else 0)
+    nb = 0
+    for entry in ("invariant", "strict", "hoisted"):
+        k = stress_loop(B=int(os.environ.get("LOOP_B", 64)), K=6, N=int(os.environ.get("LOOP_N", 30)), precision=prec, entry=entry)
+        print("loop stress (%s, %s entry point, B=%s, 6 steps per call): %d calls differ from the first" % (prec, entry, os.environ.get("LOOP_B", 64), k), flush=True)
+        nb += k
+    sys.exit(1 if bad or nb else 0)
