@@ -8,7 +8,7 @@ tools/round_profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
 tools/pmc_mem.sh $TAG > gpurun_out/${TAG}_pmc_mem.txt 2>&1
 python tools/make_traffic.py bf16x3=gpurun_out/pmc_$TAG.json > /dev/null 2>&1 && cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
 python bench.py --steps 50 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-python bench.py > gpurun_out/${TAG}_bench_k20.json 2>> gpurun_out/${TAG}_bench.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_k20.json 2>> gpurun_out/${TAG}_bench.err
 python tools/loop_wall.py > gpurun_out/${TAG}_loop_wall.txt 2>&1
 tail -2 gpurun_out/${TAG}_loop_wall.txt
 python - <<PY
