@@ -109,7 +109,9 @@ __device__ __forceinline__ float interp3(float a, float b, float d, float w0, fl
 // the interpolated tile before the stores had landed (a few hundred wrong elements per launch under load; round 4, tools/race_hunt.py).
 // Only lgkmcnt: the gather loads in flight across the barrier must not be waited for.
 __device__ __forceinline__ void wg_sync() {
+#ifndef LSDM_WGSYNC_BARE      // (defined only to show tools/barrier_wait_check.py the compiler's own output)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 }
 

@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -199,3 +200,26 @@ def test_metrics_known_answers():
     assert (f, p, r) == (0.5, 0.5, 0.5)
     out = torch.tensor([[0.1, 0.5, 0.2, 0.2], [0.7, 0.1, 0.1, 0.1]])
     assert [float(v) for v in accuracy(out, torch.tensor([2, 0]), topk=(1, 3))] == [50.0, 100.0]
+
+
+def test_generated_code_has_no_barrier_without_the_lds_wait(tmp_path):
+    """hipcc (ROCm 7.2, gfx950) emitted a loop-header s_barrier WITHOUT `s_waitcnt lgkmcnt(0)` after the loop latch's LDS stores in round 4
+    (fp_ws_kernel: another wave read the tile before the stores had landed; common.hpp::wg_sync now waits explicitly).
+    tools/barrier_wait_check.py walks the control-flow graph of every compiled kernel backwards from each barrier; the negative control
+    compiles the same source with the explicit wait removed and must be flagged."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or shutil.which("make") is None:
+        pytest.skip("no hipcc / make")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "lsdm_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j8", "check-barriers", "ASMDIR=%s" % (tmp_path / "asm")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "0 unguarded barrier(s)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    bare = tmp_path / "bare"
+    bare.mkdir()
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-inline-asm", "-DLSDM_WGSYNC_BARE",
+                    "--save-temps=obj", "-c", os.path.join(csrc, "encoder_u.hip"), "-o", str(bare / "encoder_u.o")], capture_output=True, timeout=900, check=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "barrier_wait_check.py")] + [str(p) for p in bare.glob("*-gfx950.s")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "fp_ws_kernel" in r.stdout, r.stdout[-2000:]
