@@ -137,8 +137,11 @@ class HipObjective(torch.autograd.Function):
             raise RuntimeError("HipObjective.backward: the session's gradient buffers were rewritten by a later training_losses() call "
                                "(step %d, this loss is step %d) -- call backward() before the next objective, or evaluate the other one under "
                                "torch.no_grad()" % (ctx.session.step_id, ctx.step_id))
-        grads = tuple(None if n in DEAD else ctx.session.grads[n] * g_loss for n in ctx.names)
-        return (None, None, None) + grads
+        # one multi-tensor launch per ~30 parameters instead of one elementwise kernel per parameter (157 of them per step); the products
+        # are fresh tensors, which torch's AccumulateGrad adopts as p.grad without another copy
+        live = [n for n in ctx.names if n not in DEAD]
+        scaled = dict(zip(live, torch._foreach_mul([ctx.session.grads[n] for n in live], g_loss)))
+        return (None, None, None) + tuple(scaled.get(n) for n in ctx.names)
 
 
 def training_losses(diffusion, model, x_start, mask, t, given_objs, given_cats, target_cat, y=None, noise=None, *, fps_starts=None,

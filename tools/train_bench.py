@@ -16,11 +16,13 @@ from lsdm_amd.util.model_util import create_model_and_diffusion  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=6)
 ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--device-rng", action="store_true", help="draws (noise, FPS starts, dropout mask) from the device generator")
+ap.add_argument("--host-rng", action="store_true", help="draws (noise, FPS starts, the 7 M-element dropout mask) from the HOST generator in the order "
+                "a CPU run of the reference makes them (the parity mode of the tests: the mask alone costs 25 - 65 ms of host time per step); default: the "
+                "device generator, as run/train_sdm.py does")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 model, diffusion = create_model_and_diffusion("proxd", device=0)
-if a.device_rng:
+if not a.host_rng:
     from lsdm_amd.util.model_util import create_gaussian_diffusion, get_default_diffusion
     diffusion = create_gaussian_diffusion(get_default_diffusion(), host_rng=False)
 model.load_state_dict(make_synthetic_state_dict(seed=0))
@@ -46,5 +48,5 @@ for i in range(a.steps + 1):
     times.append(time.perf_counter() - t0)
     print("step %d: loss %.4f  %.1f ms" % (i, float(terms["loss"]), times[-1] * 1e3), flush=True)
 ts = sorted(times[1:])
-print("B = %d: median %.1f ms per training step (forward with all activations kept + backward + AdamW), %.2f samples/s; algorithmic %.1f GFLOP "
-      "(3 x 14.58 per sample) -> %.1f TFLOP/s fp32" % (B, ts[len(ts) // 2] * 1e3, B / ts[len(ts) // 2], 3 * 14.58 * B, 3 * 14.58 * B / ts[len(ts) // 2] / 1e3))
+print("(%s RNG) B = %d: median %.1f ms per training step (forward with all activations kept + backward + AdamW), %.2f samples/s; algorithmic %.1f GFLOP "
+      "(3 x 14.58 per sample) -> %.1f TFLOP/s fp32" % ("host" if a.host_rng else "device", B, ts[len(ts) // 2] * 1e3, B / ts[len(ts) // 2], 3 * 14.58 * B, 3 * 14.58 * B / ts[len(ts) // 2] / 1e3))
