@@ -391,11 +391,29 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
         ci_n = cent_idx[ce];
         if (remap) { idx_n = remap[(size_t)cc * NSRC + idx_n]; ci_n = remap[(size_t)cc * NSRC + ci_n]; }
     };
-    if (cbeg + wave < cend) request(cbeg + wave);
+    // LSDM_SAUR_PREFETCH (default): the 32 U rows of the NEXT centroid are requested between this centroid's layers 2 and 3 -- its indices,
+    // requested a centroid ahead, have landed by then -- so that their L2 round trip runs under layer 3's matrix instructions instead of in
+    // front of the next centroid's (the kernel has no barrier in its loop, but at four waves per SIMD a wave's own gather latency was a third of
+    // its iteration).  32 more registers (126: still four waves per SIMD).
+#ifndef LSDM_SAUR_PREFETCH
+#define LSDM_SAUR_PREFETCH 1
+#endif
+    constexpr bool PF = LSDM_SAUR_PREFETCH != 0;
+    [[maybe_unused]] f32x4 un0[KS2], un1[KS2];
+    auto cloud_of = [&](int cent) { return src_mod > 0 ? (cent / S) % src_mod : cent / S; };
+    auto request_u = [&]() {        // the rows of the centroid whose indices `request` fetched last
+        const float* urow = U + ((size_t)cloud_of(cent_n) * NSRC + idx_n) * C1 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) { un0[s] = load4f(urow + 16 * s); un1[s] = load4f(urow + 16 * s + 4); }
+    };
+    if (cbeg + wave < cend) {
+        request(cbeg + wave);
+        if constexpr (PF) request_u();
+    }
     for (int kk = cbeg + wave; kk < cend; kk += cstep) {
         const int cent = cent_n;
         // (src_mod > 0: a launch over the clouds of several steps whose U / V are per-CALL tensors in source order)
-        const int c = src_mod > 0 ? (cent / S) % src_mod : cent / S;
+        const int c = cloud_of(cent);
         const int idx = idx_n, ci = ci_n;
         const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
         const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 8 * h;
@@ -404,7 +422,8 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
             f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
-                u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
+                if constexpr (PF) { u0[s] = un0[s]; u1[s] = un1[s]; }
+                else { u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4); }
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
             if (kk + cstep < cend) request(kk + cstep);
@@ -444,6 +463,9 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                 split8u<NP>(v, zh[2 * nb + s2], zl[2 * nb + s2]);
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (PF) {
+            if (kk + cstep < cend) request_u();
         }
         // ---- layer 3, direct orientation, max over the 32 neighbours (ReLU(x + b) is monotone: pool first)
 #pragma unroll
