@@ -5,7 +5,9 @@ sampler, ``diffusion.training_losses`` -> ``(losses["loss"] * weights).mean()`` 
 (:110-183: ``model.eval()``, p_sample_loop, squared error / chamfer / category accuracy, the reference's report line); checkpoints
 ``<out_dir>/<experiment>/model_ckpt/epoch_%04d.pt`` + ``best_model_valid_loss.pt`` / ``best_model_cfd.pt`` every ``save_interval``
 epochs (:296-330).  The objective and its gradients come from ``lsdm_train_step`` (lsdm_amd/training.py); the optimizer is torch's
-AdamW on the device tensors the library reads in place.  No tensorboard writer (the package is absent; the scalars are printed).
+AdamW on the device tensors the library reads in place.  The scalars the reference hands to its SummaryWriter (run/train_sdm.py:104,176-178,
+292) go to ``<out_dir>/<experiment>/tb_log``: through ``torch.utils.tensorboard`` when the package is importable, as ``scalars.jsonl`` (one
+``{"tag", "value", "step"}`` object per line) otherwise -- and are printed like the reference prints them.
 Additions: ``--synthetic N``, ``--device``, ``--forward_only`` (report the eval-mode objective of every batch without stepping),
 ``--valid_skip_timesteps`` (shorter validation chains for smoke runs; 0 = the reference's full T = 1000), ``--batch_size``."""
 import argparse
@@ -111,6 +113,29 @@ def validate(model, diffusion, loader, device, skip_timesteps=0):
     return out
 
 
+class ScalarLog:
+    """writer.add_scalar of run/train_sdm.py:292 -- tensorboard's SummaryWriter when importable, a JSON-lines file with the same tags otherwise."""
+
+    def __init__(self, log_dir):
+        os.makedirs(log_dir, exist_ok=True)
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.writer, self.file = SummaryWriter(log_dir), None
+        except Exception:
+            self.writer, self.file = None, open(os.path.join(log_dir, "scalars.jsonl"), "a")
+
+    def add_scalar(self, tag, value, step):
+        if self.writer is not None:
+            self.writer.add_scalar(tag, value, step)
+        else:
+            import json
+            self.file.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+            self.file.flush()
+
+    def close(self):
+        (self.writer or self.file).close()
+
+
 def main(argv=None):
     from ..synthetic import make_synthetic_state_dict
     from ..util.model_util import create_model_and_diffusion
@@ -144,6 +169,7 @@ def main(argv=None):
         model.text_encoder = text_encoder
     save_dir = os.path.join(args.out_dir, args.experiment, "model_ckpt")
     best_valid, best_cfd = float('inf'), float('inf')
+    writer = ScalarLog(os.path.join(args.out_dir, args.experiment, "tb_log"))
     for e in range(starting_epoch, args.epochs):
         print('Training epoch {}'.format(e))
         t0 = time.time()
@@ -154,8 +180,12 @@ def main(argv=None):
         else:
             total = train(model, diffusion, train_loader, device, args.lr)
         print('training_time = {:.4f}'.format(time.time() - t0))
+        writer.add_scalar('total/train_total_loss', total, e)
         if e % args.save_interval == args.save_interval - 1 or (args.forward_only and e == args.epochs - 1):
-            valid_loss, cfd, _ = validate(model, diffusion, valid_loader, device, args.valid_skip_timesteps)
+            valid_loss, cfd, acc = validate(model, diffusion, valid_loader, device, args.valid_skip_timesteps)
+            writer.add_scalar('recon_loss_semantics/validate', valid_loss, e)
+            writer.add_scalar('total_cfd/validate', cfd, e)
+            writer.add_scalar('total_acc/validate', acc, e)
             if args.forward_only:
                 continue
             os.makedirs(save_dir, exist_ok=True)
@@ -169,6 +199,7 @@ def main(argv=None):
                 print("Updated best model due to new highest total_cfd. Current epoch: {}".format(e))
                 best_cfd = cfd
                 torch.save(dict(data, total_cfd=cfd), os.path.join(save_dir, 'best_model_cfd.pt'))
+    writer.close()
     return 0
 
 

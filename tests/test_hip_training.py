@@ -244,6 +244,16 @@ def test_train_cli_steps_the_optimizer_and_the_loss_goes_down(tmp_path, capsys):
     model.load_state_dict(ck["model_state_dict"])
     best = torch.load(tmp_path / "out" / "t" / "model_ckpt" / "best_model_cfd.pt", map_location="cpu")
     assert "total_cfd" in best and best["epoch"] == 2                 # run/train_sdm.py:326-335
+    # the scalars of the reference's SummaryWriter (run/train_sdm.py:104, 176-178), with its tags, under <out_dir>/<experiment>/tb_log
+    logd = tmp_path / "out" / "t" / "tb_log"
+    if (logd / "scalars.jsonl").exists():         # tensorboard absent: the JSON-lines fallback
+        import json
+        recs = [json.loads(l) for l in (logd / "scalars.jsonl").read_text().splitlines()]
+        assert [r["step"] for r in recs if r["tag"] == "total/train_total_loss"] == [0, 1, 2]
+        assert [abs(r["value"] - t) < 1e-3 for r, t in zip([r for r in recs if r["tag"] == "total/train_total_loss"], totals)] == [True] * 3
+        assert {r["tag"] for r in recs if r["step"] == 2} == {"total/train_total_loss", "recon_loss_semantics/validate", "total_cfd/validate", "total_acc/validate"}
+    else:
+        assert any(f.name.startswith("events.out.tfevents") for f in logd.iterdir())
     # --load_ckpt resumes at checkpoint['epoch'] + 1 (run/train_sdm.py:284-289): epochs 3..4 run, epoch_0002.pt is not rewritten
     before = os.path.getmtime(tmp_path / "out" / "t" / "model_ckpt" / "epoch_0002.pt")
     rc = cli.main(["--train_data_dir", str(tmp_path / "tr"), "--valid_data_dir", str(tmp_path / "va"), "--synthetic", "8", "--epochs", "5",
