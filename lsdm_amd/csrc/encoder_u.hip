@@ -927,13 +927,16 @@ __device__ unsigned long long g_ws_phase[64 * 16];   // 64 spread copies of 16 s
 #define WS_MARK(slot) do {} while (0)
 #define WS_FLUSH(base, ntiles) do {} while (0)
 #endif
-template <int D1, int C1, int C2>
+// TM_ = 32 (LSDM_FP2_WS=3): half the tile, and the layer-1 weight fragments (64 KB as hi + lo) RESIDENT IN LDS next to it -- with the layer-2
+// fragments in the matrix waves' registers a tile then pulls nothing but its own rows through the L1.
+template <int D1, int C1, int C2, int TM_ = 64>
 __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                     const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                     const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
                                                     float* __restrict__ out, int p1_mod, int total_tiles) {
-    constexpr int TM = 64, NWM = 4, NP = 2, NTG = 256, TPP = NTG / TM;
-    static_assert(TPP == 4 && C1 % 64 == 0, "four gather threads per fine point; tile rows are whole bank rounds");
+    constexpr int TM = TM_, NWM = 4, NP = 2, NTG = 256;
+    constexpr bool W1LDS = TM_ == 32;
+    static_assert((TM == 64 || TM == 32) && C1 % 64 == 0, "tile rows are whole bank rounds");
     constexpr int LDT = C1;
     auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
     constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
@@ -941,9 +944,12 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
     __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
     __shared__ __attribute__((aligned(16))) __bf16 bufB[NP * PB];
     __shared__ __attribute__((aligned(16))) float b1s[C1];
+    __shared__ __attribute__((aligned(16))) __bf16 w1s[W1LDS ? (D1 / 16) * C1 * NP * 16 : 8];      // l1.w as it lies in memory: [k-step][channel][plane][16]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bool gath = wave >= NWM;
     for (int e = tid; e < C1; e += 512) b1s[e] = l1.b[e];
+    if constexpr (W1LDS)
+        for (int e = tid; e < (D1 / 16) * C1 * NP * 2; e += 512) *reinterpret_cast<bf16x8*>(w1s + (size_t)e * 8) = gload<bf16x8>(l1.w + (size_t)e * 8);
     const int tpc = N / TM;
     const XcdRounds R = xcd_rounds(total_tiles);
 
@@ -1166,6 +1172,30 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
                         acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xh[rb], acc[q][rb], 0, 0, 0);
                     }
                 }
+        } else if constexpr (W1LDS) {
+            // layer 1 against the weight fragments resident in LDS (same instruction order)
+            const __bf16* xp = bufX + pv * LDX + 8 * hv;
+#pragma unroll
+            for (int q = 0; q < NCB; ++q) {
+                const __bf16* wq = w1s + ((size_t)((cb0 + q * TS::CSTEP) * 32 + pv) * NP) * 16 + 8 * hv;
+#pragma unroll
+                for (int u = 0; u < D1 / 16; ++u) {
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wq + (size_t)u * C1 * NP * 16);
+                    const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wq + (size_t)u * C1 * NP * 16 + 16);
+                    bf16x8 xh[RB1], xl[RB1];
+#pragma unroll
+                    for (int rb = 0; rb < RB1; ++rb) {
+                        xh[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16);
+                        xl[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16 + PX);
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < RB1; ++rb) {
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[rb], acc[q][rb], 0, 0, 0);
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh[rb], acc[q][rb], 0, 0, 0);
+                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[rb], acc[q][rb], 0, 0, 0);
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lv);
@@ -1500,6 +1530,11 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
     if (which == 2 && fp2_ws() == 2) {
         const int total = 1024 / 64 * nc;
         hipLaunchKernelGGL((fp_rw_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
+                           out, p1_mod, total);
+    }
+    else if (which == 2 && fp2_ws() == 3) {
+        const int total = 1024 / 32 * nc;
+        hipLaunchKernelGGL((fp_ws_kernel<64, 256, 128, 32>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
                            out, p1_mod, total);
     }
     else if (which == 2 && fp2_ws()) {
