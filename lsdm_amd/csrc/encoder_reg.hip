@@ -398,11 +398,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
     static_assert(NB % PH == 0 && (NL * PH) % 2 == 0, "panel split");
     constexpr int GK = NW > 8 ? 2 : 4;                       // k-steps per batch of gather requests (staging registers)
     __shared__ __attribute__((aligned(16))) __bf16 wl[2][FPN * 512];
-    // conv2's padded block: resident in LDS, or (PH > 1: two work-groups share a CU's LDS) read from global memory through the L1
-    __shared__ __attribute__((aligned(16))) __bf16 w5[PH == 1 ? F * 512 : 8];
+    // LSDM_FP1_ROWS = 1 (A/B, round 4; default 0): the gather fetches WHOLE rows -- one wave instruction = two 512-byte rows, lanes 0-31 one
+    // point's row, lanes 32-63 the next point's: 8 full lines per instruction -- interpolates and splits them in that layout and turns them
+    // into the operand layout (lane (p, h) <- channels 16 s + 8 h .. of ITS point p) through a 2 KB LDS slot of the wave, four points at a
+    // time; conv2's block moves out of LDS to make room (read through the L1, as with PH > 1).  The direct form has every lane fetch its own
+    // operand slices: an instruction touches 32 rows and 32 bytes of each of their lines, every line is requested by four instructions.
+    // Bit-identical results; measured the SAME time (271.5 / 273.1 against 270.5 / 270.2 us, same box): the repeated requests of a line are
+    // L1 hits and cost nothing that shows -- what bounds the stage's gather is the round trip of its first touch, not the number of touches.
+#ifndef LSDM_FP1_ROWS
+#define LSDM_FP1_ROWS 0
+#endif
+    constexpr bool ROWS = LSDM_FP1_ROWS != 0 && NP == 2;
+    constexpr bool W5LDS = PH == 1 && !ROWS;
+    constexpr int TRP = 4 * C;                                  // plane stride of a wave's transposition slot [plane][4 points][C]
+    __shared__ __attribute__((aligned(16))) __bf16 tr[ROWS ? NW * NP * TRP : 8];
+    // conv2's padded block: resident in LDS, or (PH > 1: two work-groups share a CU's LDS; ROWS) read from global memory through the L1
+    __shared__ __attribute__((aligned(16))) __bf16 w5[W5LDS ? F * 512 : 8];
     __shared__ __attribute__((aligned(16))) float bl[NL * C + 32];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if constexpr (PH == 1)
+    if constexpr (W5LDS)
         for (int e = tid; e < F * 64; e += NT) *reinterpret_cast<bf16x8*>(w5 + (size_t)e * 8) = gload<bf16x8>(blob_w + (size_t)NL * FL * 512 + (size_t)e * 8);
     const __bf16* w5g = blob_w + (size_t)NL * FL * 512;
     for (int e = tid; e < NL * C + 32; e += NT) bl[e] = blob_b[e];
@@ -459,11 +473,58 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
     for (long long rd = rbeg; rd < rend; rd += rstep) {
         const long long pt = rd * (32 * NW) + wave * 32 + p;    // this lane's point (both halves of the wave: same point)
         const long long c = pt / N;
-        const float* r0 = points2 + ((size_t)c * S + ni[0]) * C + 8 * h;
+        [[maybe_unused]] const float* r0 = points2 + ((size_t)c * S + ni[0]) * C + 8 * h;
         const float* r1 = points2 + ((size_t)c * S + ni[1]) * C + 8 * h;
         const float* r2 = points2 + ((size_t)c * S + ni[2]) * C + 8 * h;
         const float w0 = nw[0], w1 = nw[1], w2 = nw[2];
         bf16x8 yh[KS], yl[KS], zh[KS], zl[KS];
+        if constexpr (ROWS) {
+            // ---- row-wise gather: chunk ch = points 4 ch .. 4 ch + 3 of the wave as two instructions per neighbour (pair g: lanes 0-31 <- point
+            // 4 ch + 2 g, lanes 32-63 <- the next); four chunks (24 loads, 96 registers) in flight
+            __bf16* trw = tr + (size_t)wave * NP * TRP;
+            const float* pb = points2 + (size_t)c * S * C + 4 * p;
+            auto pick_i = [&](int v, int la) { const int a = __builtin_amdgcn_readlane(v, la), b = __builtin_amdgcn_readlane(v, la + 1); return h ? b : a; };
+            auto pick_f = [&](float v, int la) { return __builtin_bit_cast(float, pick_i(__builtin_bit_cast(int, v), la)); };
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 a[4][2], b[4][2], d[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int la = 4 * (4 * half + q) + 2 * g;          // lane (= point of the wave) that holds pair g's first point
+                        a[q][g] = load4f(pb + (size_t)pick_i(ni[0], la) * C);
+                        b[q][g] = load4f(pb + (size_t)pick_i(ni[1], la) * C);
+                        d[q][g] = load4f(pb + (size_t)pick_i(ni[2], la) * C);
+                    }
+                // (the weights of this round are still needed below: the next round's indices are requested after the last chunk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = 4 * half + q;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int la = 4 * ch + 2 * g;
+                        const float u0 = pick_f(nw[0], la), u1 = pick_f(nw[1], la), u2 = pick_f(nw[2], la);
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = interp3(a[q][g][j], b[q][g][j], d[q][g][j], u0, u1, u2);
+                        store_split4<NP>(trw + (2 * g + h) * C + 4 * p, TRP, v[0], v[1], v[2], v[3]);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if ((p >> 2) == ch) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            yh[s] = *reinterpret_cast<const bf16x8*>(trw + (p & 3) * C + 16 * s + 8 * h);
+                            yl[s] = *reinterpret_cast<const bf16x8*>(trw + (p & 3) * C + 16 * s + 8 * h + TRP);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (rd + rstep < rend) request(rd + rstep);
+        } else {
         // ---- interpolated operand, k-step s = channels 16 s + 8 h .. + 7 of this lane's point (four k-steps per batch of loads)
 #pragma unroll
         for (int s0 = 0; s0 < KS; s0 += GK) {
@@ -493,6 +554,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
                         v[4 * q + j] = interp3(a[s][q][j], b[s][q][j], d[s][q][j], w0, w1, w2);
                 split8<NP>(v, yh[s0 + s], yl[s0 + s]);
             }
+        }
         }
         // one channel block of a layer: accumulators start from the bias, MFMAs against the resident panel, ReLU + split into the
         // next layer's two k-step fragments
@@ -557,9 +619,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 wh = PH == 1 ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 0, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP) * 64 + lane) * 8);
+                const bf16x8 wh = W5LDS ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 0, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP) * 64 + lane) * 8);
                 if constexpr (NP == 2) {
-                    const bf16x8 wlo = PH == 1 ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 1, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP + 1) * 64 + lane) * 8);
+                    const bf16x8 wlo = W5LDS ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 1, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP + 1) * 64 + lane) * 8);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], wh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], wlo, acc, 0, 0, 0);
                 }
