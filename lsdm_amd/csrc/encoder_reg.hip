@@ -648,6 +648,8 @@ void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* n
     const long long tot = (long long)nc * 1024;
     // (12 waves -- three per SIMD, as sa3 runs -- do not fit: two 128-channel operand sets + accumulators + fragments need ~172 VGPRs against
     // the 168 of that occupancy and the build spills 95 of them)
+    // (two work-groups of four waves per CU on half-layer panels -- fp_s_kernel<4, 2, 2>, grid 512: the two groups drift out of phase, one gathers
+    // while the other multiplies, for twice the panel traffic -- measured 290 against 271 us, round 4)
     hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
 }
 
