@@ -66,7 +66,9 @@ __device__ __forceinline__ void relu_split_pair_u(const f32x16& acc, const float
 // ---------------------------------------------------------------------------------------------
 // rows are independent (the source points of all clouds, flattened): X (R,K) fp32, xyz (R,3) -> U (R,N), V (R,N) fp32
 // (V only for the centroids, compact, from a launch of its own -- one row in four is ever read, 75 + 38 MB of writes per step saved -- was
-// measured: sa3 317 vs 318 us, sa4 344 vs 340 incl. the U / V launches: the stage is not bound by that write; not kept)
+// measured: sa3 317 vs 318 us, sa4 344 vs 340 incl. the U / V launches: the stage is not bound by that write; not kept.  A persistent form -- 461 work-groups
+// walking five tiles each, the next tile's rows requested before this tile's matrix instructions -- measured slower as well, sa3 stage 323 vs 320 us, strict sa2
+// 363 vs 356, round 4: two one-tile work-groups per CU already overlap each other's loads and stores)
 template <int K, int N, bool XYZ = true>
 __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__ X, const float* __restrict__ xyz, int R, DenseH W,
                                                        const float* __restrict__ wx, float* __restrict__ U, float* __restrict__ V) {
