@@ -469,6 +469,20 @@ def main():
                                   "executed_gflop": round(q["ex_gflop_step"], 3), "tflops_executed": round(q["ex_tflops"], 2),
                                   "frac_executed": round(q["ex_tflops"] / peak, 4), "mfma_issue_frac": round(q["ex_tflops"] * issue / peak, 4)} for q in rows]},
     }
+    if a.precision == "bf16x3":
+        # The other roof these stages touch (DESIGN.md "The roofline of the gathers, measured"): bytes a launch pulls through the CUs' fill path
+        # (gathered rows + weight fragments / panels streamed per tile or round; per cloud, x 9 B clouds) / stage time, against what
+        # tools/ubench/gather_bw.hip measures for L2-resident rows with four gathering waves per CU (profiles/r04_gather_bw.txt)
+        fill_mb_per_cloud = {"fp_kernel<fp2>": 1024 * (3 * 1024 + 256) / 1e6 + 16 * 65536 / 1e6,             # Y rows + p1 rows, layer-1 fragments per 64-row tile
+                             "sa_kernel<256,256,256,512>": 16 * 32 * 1024 / 1e6 + 4 * 786432 / 1e6,         # U rows, twelve 64 KB panels per four centroids
+                             "fp_kernel<fp1+head>": 1024 * 3 * 512 / 1e6 + 4 * 262144 / 1e6,                # rows, four 64 KB panels per 256 points
+                             "sa_kernel<128,128,128,256>": 64 * 32 * 512 / 1e6 + (64 / 12.0) * 131072 / 1e6}   # U rows, layer-3 panels per twelve centroids
+        by_name = {q["name"]: q for q in rows}
+        res["fill_path"] = {"unit": "TB/s", "ceiling_l2_resident_4_waves_per_cu": 11.0, "ceiling_infinity_cache": 9.0,
+                            "source": "tools/ubench/gather_bw.hip (profiles/r04_gather_bw.txt); bytes = gathered rows + streamed weight fragments / panels per launch",
+                            "stages": {n: {"gb_per_launch": round(mb * 9 * B / 1e3, 3), "tb_per_s": round(mb * 9 * B / 1e3 / by_name[n]["avg_ms"], 2),
+                                           "frac_of_11": round(mb * 9 * B / 1e3 / by_name[n]["avg_ms"] / 11.0, 3)}
+                                       for n, mb in fill_mb_per_cloud.items() if n in by_name and by_name[n]["avg_ms"] > 0}}
     if hoisted:
         res["hoisted_conditioning"] = hoisted
     res["forward_only"] = fwd
