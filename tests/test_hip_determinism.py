@@ -24,3 +24,27 @@ def test_repeated_sampler_calls_are_bit_identical_at_b64(entry):
     """The benched configuration (B = 64: 576 clouds, 36 tiles per persistent work-group), six steps per call through each bulk entry point."""
     from determinism_stress import stress_loop
     assert stress_loop(B=64, K=6, N=12, precision="bf16x3", entry=entry) == 0
+
+
+def test_bench_json_line_carries_the_contract_fields():
+    """`python bench.py` as the driver runs it (N = 1; short): ONE JSON line with the contract's fields, the roofline of the dominant kernel with
+    its three fractions, the fill-path figures of the gather-bound stages, and value = 1000 / ms_per_step."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-others", "--no-hoisted", "--no-cpu-baseline",
+                        "--no-parity"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 4 and r["warmup"] == 2 and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["vs_baseline"] is None and r["dtype"] == "bf16x3" and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 1e3 / r["ms_per_step"]) <= 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 0 < rf["frac_executed"] < rf["frac"] < rf["mfma_issue_frac"] < 1.0          # executed < reference FLOPs; x3 matrix instructions per product
+    assert set(r["fill_path"]["stages"]) >= {"fp_kernel<fp2>", "fp_kernel<fp1+head>"} and 0 < r["fill_path"]["stages"]["fp_kernel<fp2>"]["frac_of_11"] < 1.2
+    assert r["repeats"]["final_sample_bit_identical_to_timed_region"] is True
