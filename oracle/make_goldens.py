@@ -30,6 +30,8 @@ Golden sets:
       boundary is its (B,768) feature, like CLIP's (B,512).)
   G14 BASELINE configs[1] at depth: B = 16, C = 43, first K = 5 steps (t = 999..995) and last K = 5 steps (init_image + skip_timesteps
       = 995, t = 4..0) of p_sample_loop, per-step samples + saved_cat + guiding points.
+  G15 error accumulation at BASELINE configs[1]'s shape beyond ten steps (SURVEY.md 8(d) "Config 2" (ii)): B = 16, C = 43, K = 25 steps in the
+      middle of the schedule (init_image + skip_timesteps = 475: q_sample to t = 524, then t = 524..500), every fifth sample.
   long  full T=1000 chain at B=1 (every 100th step + final); ~20 min of CPU.
 """
 import argparse
@@ -524,6 +526,30 @@ def g14():
         print("g14 %s: %.1f s" % (tag, time.time() - t0))
         save("g14_config2_%s" % tag, steps_sub=torch.stack(got)[:, :, ::8], final=got[-1], saved_cat=m.saved_cat,
              guiding_sub=m.saved_guiding_points[:, ::2], meta=np.array([B, C, K, seed, 141]), **extra)
+
+
+def g15():
+    """Mid-schedule accumulation at configs[1]'s shape: B = 16, C = 43, K = 25 consecutive steps from t = 524 (gaussian_diffusion.py:684-759:
+    init_image + skip_timesteps = 475 draws q_sample's noise first, then the stock loop).  Every fifth sample on every 4th point, the 25th in
+    full; saved_cat and every 2nd guiding point after the last forward.  ~20 min of CPU; one file < 1 MB."""
+    diff = ref_diffusion()
+    B, C, K, SKIP = 16, 43, 25, 475
+    m = ref_model(C)
+    bt = make_synthetic_batch(B, seed=151, max_cats=C)
+    clip._model.features = bt["text_features"]
+    g = torch.Generator().manual_seed(154)
+    init = 0.7 * torch.randn(B, 1024, 3, generator=g)
+    torch.manual_seed(152)
+    t0, got = time.time(), []
+    for i, out in enumerate(diff.p_sample_loop_progressive(m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], ["p"] * B,
+                                                           clip_denoised=False, skip_timesteps=SKIP, init_image=init)):
+        if i % 5 == 4:
+            got.append(out["sample"].clone())
+            print("g15 step %d: %.1f s" % (i + 1, time.time() - t0), flush=True)
+        if i + 1 == K:
+            break
+    save("g15_config2_mid", steps_sub=torch.stack(got)[:, :, ::4], final=got[-1], saved_cat=m.saved_cat,
+         guiding_sub=m.saved_guiding_points[:, ::2], meta=np.array([B, C, K, 152, 151, SKIP, 154]))
 
 
 def long_chain(steps):

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../lsdm_amd/csrc" || exit 1
 files=("$@"); [ ${#files[@]} -eq 0 ] && files=(*.hip)
 for f in "${files[@]}"; do
-  extra=""; [ "$f" = geometry.hip ] && extra="-ffp-contract=off"
+  extra="-Xclang -target-feature -Xclang -packed-fp32-ops"; [ "$f" = geometry.hip ] && extra="-ffp-contract=off"; [ "$f" = api.hip -o "$f" = metrics.hip ] && extra=""
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c "$f" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 |
   awk -v F="$f" '/Function Name:/ {n=$0; sub(/.*Function Name: /,"",n); sub(/ \[.*/,"",n)}
        / VGPRs:/ {v=$(NF-1)} /AGPRs:/ {a=$(NF-1)} /ScratchSize/ {s=$(NF-1)} /Occupancy/ {o=$(NF-1)}
