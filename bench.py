@@ -53,7 +53,8 @@ STAGE_KERNELS_BF16X3 = {
     "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y); one launch per "
                       "group of steps (up to LSDM_GROUP, default 28 / 32) in the loop-invariant schedule",
     "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
-    "fp_kernel<fp2>": "fp_pre_kernel<64,256,128>",
+    "fp_kernel<fp2>": "fp_d_kernel<1024,256,64,256,128> (two-stage persistent kernel over Morton-ordered 32-point tiles, each distinct Y row landed once by "
+                      "LDS-DMA) + its tile plans (fp_plan_kernel: one launch per group of steps in the loop-invariant schedule, its time inside this stage)",
     "fp_kernel<fp1+head>": "fp_s_kernel<8,2>",
     "denoise_kernel": "denoise_r_kernel (one launch per group of steps and the guiding-point pass on the call's last forward only in the "
                       "loop-invariant schedule)",
@@ -128,18 +129,26 @@ def parity_check(precision, dev):
 class Runner:
     """Model + resident inputs + RNG streams of one precision; run(t_first, k0, k) = k steps in one C-ABI call."""
 
-    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev):
+    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev, datatype="proxd", respacing="", ddim=False, surface=False, prompts_per_scene=1):
         from lsdm_amd import _lib
         from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
-        from lsdm_amd.util.model_util import create_model_and_diffusion
+        from lsdm_amd.util.model_util import create_gaussian_diffusion, create_model_and_diffusion, get_default_diffusion
         self._lib = _lib
         self.B, self.C = B, C
-        self.model, self.diffusion = create_model_and_diffusion("proxd", device=local_rank, precision=precision)
+        self.mode = _lib.MODE_DDIM if ddim else _lib.MODE_P_SAMPLE
+        self.model, self.diffusion = create_model_and_diffusion(datatype, device=local_rank, precision=precision, max_cats=C)
+        if respacing:
+            self.diffusion = create_gaussian_diffusion(get_default_diffusion(), timestep_respacing=respacing)
         self.model.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C))
         self.ctx = self.model._context()
         self.model._reserve(B)
         self.model._set_schedule(self.diffusion._schedule_key(), self.diffusion._device_tables())
-        self.bt = {k: v.to(dev).contiguous() for k, v in make_synthetic_batch(B, seed=seed, max_cats=C, num_objects=8).items()}
+        bt = make_synthetic_batch(B // prompts_per_scene, seed=seed, max_cats=C, num_objects=8, surface=surface)
+        if prompts_per_scene > 1:      # HUMANISE (BASELINE configs[4]): chains 2 s, 2 s + 1 share scene s and differ in the prompt
+            text = make_synthetic_batch(B, seed=seed + 1000, max_cats=C, num_objects=1)["text_features"]
+            bt = {k: v.repeat_interleave(prompts_per_scene, dim=0) for k, v in bt.items()}
+            bt["text_features"] = text
+        self.bt = {k: v.to(dev).contiguous() for k, v in bt.items()}
         # RNG stream of the reference: x_T, then per step 4 FPS randints + randn (SURVEY.md H1), host generator
         torch.manual_seed(seed)
         x = torch.randn(B, 1024, 3)
@@ -160,9 +169,112 @@ class Runner:
         bt = self.bt
         x = self.x if x is None else x
         entry = "lsdm_sample_steps_hoisted" if hoisted else ("lsdm_sample_steps_invariant" if invariant else "lsdm_sample_steps")
-        self.ctx.call(entry, self._lib.MODE_P_SAMPLE, 0.0, self.B, t_first, k,
+        self.ctx.call(entry, self.mode, 0.0, self.B, t_first, k,
                       p(x), p(bt["mask"]), p(bt["given_objs"]), p(bt["given_cats"]), p(bt["text_features"]), p(self.starts[k0]),
                       p(self.noise[k0] if noise is None else noise), p(self.out_cat), p(self.out_x0), p(self.out_g), self.stream)
+
+
+class StubRunner:
+    """--stub-runner (tests/test_parallel_gloo.py: world-8 plumbing test on CPU, no GPU in the loop): the Runner interface with NO work behind
+    it -- run() sleeps 2 ms per step (rank r: + 10 % per rank, so the slowest rank is known) and stamps the sample with the rank's seed.
+    Everything around it (rank environment, seeds, barriers, the packed all-gather, max-over-ranks timing, the JSON contract fields) is
+    bench.py's real code on the gloo backend.  Its `value` measures nothing and the line says so ("data": "stub")."""
+
+    class _Ctx:
+        def profile_begin(self): pass
+        def profile_end(self): return []
+
+    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev, **_):
+        self.B, self.C, self.T, self.seed = B, C, 1000, seed
+        g = torch.Generator().manual_seed(seed)
+        self.x = torch.randn(B, 1024, 3, generator=g)
+        self.out_cat = torch.zeros(B, 1, C)
+        self.out_x0, self.out_g = torch.zeros_like(self.x), torch.zeros_like(self.x)
+        self.ctx = StubRunner._Ctx()
+        self.rank = int(os.environ.get("RANK", 0))
+
+    def run(self, t_first, k0, k, hoisted=False, x=None, noise=None, invariant=False):
+        time.sleep(0.002 * k * (1.0 + 0.1 * self.rank))
+        (self.x if x is None else x).fill_(float(self.seed))
+        self.out_cat.fill_(float(self.seed))
+        self.out_g.fill_(-float(self.seed))
+
+
+def contract_fields(a, world, K, W, B, C, dt, per_rank_dt, allgather_us, T, inv, data="synthetic"):
+    """The bench contract's fields of the JSON line (driver: value = whole-job steps/s over the slowest rank's time)."""
+    from lsdm_amd.parallel import shard_seed
+    step_ms = dt / K * 1e3
+    return {
+        "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
+        "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch per GPU; value sums the GPUs)",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.precision, "data": data,
+        "sample_steps_per_s": world * B * K / dt,
+        "config": {"workload": "BASELINE configs[2]: B=%d chains/GPU, 8 objects + human x 1024 pts (8192-pt scene cloud), C=13, random CLIP-text "
+                               "features, cosine T=1000, p_sample steps t=%d..%d in ONE %s call on one caller stream, host-replayed RNG; %s"
+                               % (B, T - 1 - W, T - W - K, "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
+                                  "per-step recompute of the conditioning MLPs and of PointNet++ (FPS with fresh starts, levels 2-4, all FP "
+                                  "stages); what does NOT depend on the FPS order is evaluated once per call INSIDE the timed call and "
+                                  "re-ordered / copied per step: the level-1 work (balls, sa1 features, 3-NN candidates) and sa2's output of "
+                                  "the points with fewer than 32 points within r = 0.2 (their ball is the same set every step; the others -- "
+                                  "45 % of the centroids on this data -- go through sa2 every step) -- results bit-identical to the strict "
+                                  "schedule, whose figure is under strict_recompute" if inv else
+                                  "strict per-step recompute of everything the reference recomputes"),
+                   "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
+                   "global_batch": B * world, "chains_per_gpu": B,
+                   "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples + saved_cat + guiding points (one packed buffer)" % world},
+        "schedule": "loop-invariant (level-1 encoder work and the order-free part of sa2 once per %d-step call, inside the timed call; bit-identical to strict)" % K if inv
+                    else "strict (every stage every step)",
+        "rccl_ranks": world, "per_rank_seeds": [shard_seed(a.seed, q) for q in range(world)], "allgather_us": allgather_us,
+        "allgather_bytes_per_rank": int(B * (2 * 3072 + C) * 4) if world > 1 else 0,
+        "per_rank_ms_per_step": [round(v / K * 1e3, 4) for v in per_rank_dt],
+    }
+
+
+def config_legs(a, dev, local_rank, inv):
+    """Short legs (never `value`) for the BASELINE configs that are not the headline but fit one GPU, through the same entry point:
+    configs[1] (B = 16, C = 43: f32 -- its stated precision -- and bf16x3), configs[4]'s shapes on one GPU (HUMANISE defaults C = 11, 32 scenes x
+    2 prompts, DDIM on the 'ddim250' schedule, reference util/model_util.py:56-85 + diffusion/gaussian_diffusion.py:790-811) and the headline
+    workload on SURFACE-sampled objects (points on the box faces: PROX-like scans, posa/dataset.py:424-470) with sa2's memo hit rate."""
+    import ctypes
+    out = {}
+
+    def leg(name, precision, B, C, K, note, **kw):
+        r = Runner(precision, B, C, 2 + K, a.seed, local_rank, dev, **kw)
+        T = r.T
+        r.run(T - 1, 0, 2, invariant=inv)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r.run(T - 3, 2, K, invariant=inv)
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t1
+        e = {"value": K / d, "unit": "denoising-steps/sec (batch of %d chains)" % B, "ms_per_step": d / K * 1e3, "steps": K, "batch": B, "max_cats": C,
+             "dtype": precision, "sample_steps_per_s": B * K / d, "schedule_T": T, "sampler": "ddim" if kw.get("ddim") else "p_sample",
+             "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps", "finite": bool(torch.isfinite(r.x).all()), "workload": note}
+        if kw.get("surface") or name == "headline_volume_reference":
+            # sa2's memo (DESIGN.md 8b): memo_cnt = {uncrowded source points of the call, crowded centroids of the call's last group}; the K steps are one group
+            try:
+                ptr, n = r.ctx.workspace_tensor("memo_cnt")
+                cnt = (ctypes.c_int * 2)()
+                hip = ctypes.CDLL("libamdhip64.so")
+                if n >= 2 and hip.hipMemcpy(cnt, ctypes.c_void_p(ptr), ctypes.c_size_t(8), 2) == 0:
+                    e["sa2_memo"] = {"uncrowded_source_points_frac": cnt[0] / float(B * 9 * 1024),
+                                     "centroid_hit_rate": 1.0 - cnt[1] / float(B * 9 * 256 * K),
+                                     "note": "fraction of the steps' sa2 centroids served by the per-call memo (fewer than 32 points within r = 0.2)"}
+            except Exception as ex:     # (the memo is off: LSDM_SA2_MEMO=0 or a non-default schedule)
+                e["sa2_memo"] = {"error": str(ex)}
+        out[name] = e
+        del r
+        torch.cuda.empty_cache()
+
+    leg("configs[1]_f32", "f32", 16, 43, 6, "BASELINE configs[1]: B=16, C=43 (655-vertex human branch), cosine T=1000, p_sample, exact f32 MFMA")
+    leg("configs[1]_bf16x3", "bf16x3", 16, 43, 10, "BASELINE configs[1]'s shapes in the headline precision")
+    leg("configs[4]_one_gpu", "bf16x3", 64, 11, 10, "BASELINE configs[4]'s shapes on ONE GPU: HUMANISE defaults (C=11), 32 scenes x 2 prompts (chains 2s, 2s+1 share "
+        "given_objs), DDIM (eta = 0) on the 'ddim250' respaced schedule, steps t'=247..238", datatype="humanise", respacing="ddim250", ddim=True, prompts_per_scene=2)
+    leg("headline_surface_sampled", "bf16x3", 64, 13, 10, "the headline workload with the 8 objects' points ON their box faces (surface scans) instead of in the "
+        "volume: sparser balls, higher sa2-memo hit rate", surface=True)
+    leg("headline_volume_reference", "bf16x3", 64, 13, 10, "the headline workload (volume-filled boxes) through the same 10-step leg, for the memo hit rate beside it")
+    return out
 
 
 def respawn_ranks(n):
@@ -197,6 +309,9 @@ def main():
     ap.add_argument("--no-others", action="store_true", help="skip the short runs in the other two precisions")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check against the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configs (configs[1], configs[4] shapes, surface-sampled clouds)")
+    ap.add_argument("--stub-runner", action="store_true",
+                    help="plumbing test on CPU (gloo): no GPU work behind the Runner interface; the line's value measures nothing")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps at --cpu-batch after 1 warm-up (BASELINE.md §3); one more step is timed at B=16")
     a = ap.parse_args()
@@ -209,15 +324,21 @@ def main():
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch one rank per GPU (python -m torch.distributed.run "
                  "--nproc-per-node %d bench.py --gpus %d ...) or run `python bench.py --gpus %d` directly" % (a.gpus, world, a.gpus, a.gpus, a.gpus))
-    if torch.cuda.device_count() < a.gpus:
+    stub = a.stub_runner
+    if torch.cuda.device_count() < a.gpus and not stub:
         sys.exit("bench.py: --gpus %d but only %d visible device(s) -- refusing to run ranks on shared GPUs" % (a.gpus, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not stub:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
     torch.set_grad_enabled(False)
 
     from lsdm_amd.parallel import gather_results
@@ -230,17 +351,17 @@ def main():
 
     from lsdm_amd.parallel import shard_seed
     inv = a.mode == "invariant"
-    r = Runner(a.precision, B, C, W + K, shard_seed(a.seed, rank), local_rank, dev)
+    r = (StubRunner if stub else Runner)(a.precision, B, C, W + K, shard_seed(a.seed, rank), local_rank, dev)
     T = r.T
     log("inputs resident; warm-up %d steps" % W)
     if W:
         r.run(T - 1, 0, W, invariant=inv)
     if dist:
         gather_results(r.x, r.out_cat, r.out_g, dist)   # untimed: RCCL communicator set-up + shard-size agreement belong to the warm-up
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     # Per-stage HIP events (lsdm_profile_*: one event between consecutive stages, recorded on the launch stream) of the SAME call --
     # same inputs, same RNG draws, from the same x -- in a pass of its own between the warm-up and the timed region, on every rank:
     # per-kernel durations need the kernels one at a time, so under instrumentation the library keeps every stage on the caller's
@@ -251,37 +372,41 @@ def main():
     # it 2.22 ms/step, after 20 warm steps 2.16, every later repeat 2.15.)
     x_start = r.x.clone()
     xi = x_start.clone()
-    torch.cuda.synchronize()
+    sync()
     r.ctx.profile_begin()
     t1 = time.perf_counter()
     r.run(T - 1 - W, W, K, x=xi, invariant=inv)
-    torch.cuda.synchronize()
+    sync()
     dt_instr = time.perf_counter() - t1
     prof = r.ctx.profile_end()
     x_instr = xi
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     log("timing %d steps (%s, %s)" % (K, a.precision, a.mode))
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev = [None, None] if stub else [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
     r.run(T - 1 - W, W, K, invariant=inv)
-    ev[0].record()
+    tg0 = time.perf_counter()
+    if not stub:
+        ev[0].record()
     # the path's only collective (RCCL all-gather over xGMI; sizes agreed in the warm-up): what run/test_sdm.py:184-202 reads after the
     # loop -- final samples, saved_cat and the guiding points of every chain -- packed into one buffer (lsdm_amd/parallel.py)
     gathered, gathered_cat, gathered_guid = gather_results(r.x, r.out_cat, r.out_g, dist, agree=False)
-    ev[1].record()
-    torch.cuda.synchronize()
+    tg1 = time.perf_counter()
+    if not stub:
+        ev[1].record()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    allgather_us = ev[0].elapsed_time(ev[1]) * 1e3 if dist else 0.0
+    allgather_us = ((tg1 - tg0) * 1e6 if stub else ev[0].elapsed_time(ev[1]) * 1e3) if dist else 0.0
     log("timed region %.3f s" % dt)
     per_rank_dt = [dt]
     if dist:
         assert dist.get_world_size() == a.gpus
-        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)      # (every rank's own wall time of the timed region)
         every = torch.empty(world, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(every, mine)
         per_rank_dt = [float(v) for v in every.cpu()]
@@ -289,6 +414,18 @@ def main():
     assert gathered.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered).all())
     assert gathered_cat.shape == (B * world, 1, C) and gathered_guid.shape == (B * world, 1024, 3) and bool(torch.isfinite(gathered_guid).all())
     x_final = r.x.clone()
+    if stub:
+        # the contract fields from the real bookkeeping; the gathered rows must be every rank's stamp in rank order
+        stamps = [float(gathered[q * B, 0, 0]) for q in range(world)]
+        assert stamps == [float(shard_seed(a.seed, q)) for q in range(world)], stamps
+        if rank == 0:
+            res = contract_fields(a, world, K, W, B, C, dt, per_rank_dt, allgather_us, T, inv, data="stub (no GPU work: plumbing test)")
+            res["stub"] = True
+            print(json.dumps(res), flush=True)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank != 0:
         dist.barrier()                 # rank 0 finishes its untimed reporting legs, then everyone tears down together
@@ -415,30 +552,8 @@ def main():
     issue = 3.0 if a.precision == "bf16x3" else 1.0          # matrix instructions issued per executed product
     ex_step_gflop = sum(q["ex_gflop_step"] for q in mfma_rows)
     whole_ex = ex_step_gflop / step_ms
-    res = {
-        "metric": "denoising-steps/sec (B=64, 1024-pt clouds x 9 slots incl. the 655-vertex human branch, T=1000)",
-        "value": world * K / dt, "unit": "denoising-steps/sec (one step = p_sample of a 64-chain batch per GPU; value sums the GPUs)",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-        "sample_steps_per_s": world * B * K / dt,
-        "config": {"workload": "BASELINE configs[2]: B=%d chains/GPU, 8 objects + human x 1024 pts (8192-pt scene cloud), C=13, random CLIP-text "
-                               "features, cosine T=1000, p_sample steps t=%d..%d in ONE %s call on one caller stream, host-replayed RNG; %s"
-                               % (B, T - 1 - W, T - W - K, "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
-                                  "per-step recompute of the conditioning MLPs and of PointNet++ (FPS with fresh starts, levels 2-4, all FP "
-                                  "stages); what does NOT depend on the FPS order is evaluated once per call INSIDE the timed call and "
-                                  "re-ordered / copied per step: the level-1 work (balls, sa1 features, 3-NN candidates) and sa2's output of "
-                                  "the points with fewer than 32 points within r = 0.2 (their ball is the same set every step; the others -- "
-                                  "45 % of the centroids on this data -- go through sa2 every step) -- results bit-identical to the strict "
-                                  "schedule, whose figure is under strict_recompute" if inv else
-                                  "strict per-step recompute of everything the reference recomputes"),
-                   "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps",
-                   "global_batch": B * world, "chains_per_gpu": B,
-                   "parallelism": "chains sharded over %d rank(s); one RCCL all-gather of final samples + saved_cat + guiding points (one packed buffer)" % world},
-        "schedule": "loop-invariant (level-1 encoder work and the order-free part of sa2 once per %d-step call, inside the timed call; bit-identical to strict)" % K if inv
-                    else "strict (every stage every step)",
-        "rccl_ranks": world, "per_rank_seeds": [shard_seed(a.seed, q) for q in range(world)], "allgather_us": allgather_us,
-        "allgather_bytes_per_rank": int(B * (2 * 3072 + C) * 4) if world > 1 else 0,
-        "per_rank_ms_per_step": [round(v / K * 1e3, 4) for v in per_rank_dt],
+    res = contract_fields(a, world, K, W, B, C, dt, per_rank_dt, allgather_us, T, inv)
+    res.update({
         "roofline": {"bound": "mfma", "kernel": dom["name"],
                      "launches_of_the_stage": STAGE_KERNELS_BF16X3.get(dom["name"], dom["name"]) if a.precision == "bf16x3" else dom["name"],
                      "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
@@ -468,20 +583,23 @@ def main():
                                   "ms_per_step": round(q["total_ms"] / K, 4), "tflops": round(q["tflops"], 2),
                                   "executed_gflop": round(q["ex_gflop_step"], 3), "tflops_executed": round(q["ex_tflops"], 2),
                                   "frac_executed": round(q["ex_tflops"] / peak, 4), "mfma_issue_frac": round(q["ex_tflops"] * issue / peak, 4)} for q in rows]},
-    }
+    })
     if a.precision == "bf16x3":
-        # The other roof these stages touch (DESIGN.md "The roofline of the gathers, measured"): bytes a launch pulls through the CUs' fill path
-        # (gathered rows + weight fragments / panels streamed per tile or round; per cloud, x 9 B clouds) / stage time, against what
-        # tools/ubench/gather_bw.hip measures for L2-resident rows with four gathering waves per CU (profiles/r04_gather_bw.txt)
-        fill_mb_per_cloud = {"fp_kernel<fp2>": 1024 * (3 * 1024 + 256) / 1e6 + 16 * 65536 / 1e6,             # Y rows + p1 rows, layer-1 fragments per 64-row tile
+        # The other roof these stages touch (DESIGN.md "The roofline of the gathers"): bytes a launch pulls through the CUs' fill path (gathered rows +
+        # weight fragments / panels streamed per tile or round; per cloud, x 9 B clouds) / stage time, against what tools/ubench/gather2_bw.hip
+        # measures for random 1 KB rows with four gathering waves per CU and precomputed indices (profiles/r05_gather2_bw.txt: 25 TB/s L2-resident,
+        # 8.7 TB/s out of the Infinity Cache; round 4's gather_bw.hip measured its own address arithmetic at four waves: 11 TB/s).  fp2 (round 5,
+        # fp_d_kernel) lands every DISTINCT row of a Morton-ordered 32-point tile once (~26 of the 96 requested on this data; the figure below
+        # assumes 26) -- it is no longer a fill-path kernel and is listed for the comparison with round 4's 2.56 GB per launch only.
+        fill_mb_per_cloud = {"fp_kernel<fp2>": 32 * 26 * 1024 / 1e6 + 1024 * 256 / 1e6,                       # distinct Y rows per tile (estimate) + p1 rows
                              "sa_kernel<256,256,256,512>": 16 * 32 * 1024 / 1e6 + 4 * 786432 / 1e6,         # U rows, twelve 64 KB panels per four centroids
                              "fp_kernel<fp1+head>": 1024 * 3 * 512 / 1e6 + 4 * 262144 / 1e6,                # rows, four 64 KB panels per 256 points
                              "sa_kernel<128,128,128,256>": 64 * 32 * 512 / 1e6 + (64 / 12.0) * 131072 / 1e6}   # U rows, layer-3 panels per twelve centroids
         by_name = {q["name"]: q for q in rows}
-        res["fill_path"] = {"unit": "TB/s", "ceiling_l2_resident_4_waves_per_cu": 11.0, "ceiling_infinity_cache": 9.0,
-                            "source": "tools/ubench/gather_bw.hip (profiles/r04_gather_bw.txt); bytes = gathered rows + streamed weight fragments / panels per launch",
+        res["fill_path"] = {"unit": "TB/s", "ceiling_l2_resident_4_waves_per_cu": 25.0, "ceiling_infinity_cache": 8.7,
+                            "source": "tools/ubench/gather2_bw.hip (profiles/r05_gather2_bw.txt); bytes = gathered rows + streamed weight fragments / panels per launch",
                             "stages": {n: {"gb_per_launch": round(mb * 9 * B / 1e3, 3), "tb_per_s": round(mb * 9 * B / 1e3 / by_name[n]["avg_ms"], 2),
-                                           "frac_of_11": round(mb * 9 * B / 1e3 / by_name[n]["avg_ms"] / 11.0, 3)}
+                                           "frac_of_l2_ceiling": round(mb * 9 * B / 1e3 / by_name[n]["avg_ms"] / 25.0, 3)}
                                        for n, mb in fill_mb_per_cloud.items() if n in by_name and by_name[n]["avg_ms"] > 0}}
     if hoisted:
         res["hoisted_conditioning"] = hoisted
@@ -511,6 +629,9 @@ def main():
             del ro
             torch.cuda.empty_cache()
         res["other_precisions"] = others
+    if not a.no_configs and world == 1:
+        log("short legs of the other BASELINE configs")
+        res["configs"] = config_legs(a, dev, local_rank, inv)
     if not a.no_parity:
         log("parity check vs the CPU oracle")
         res["parity"] = parity_check(a.precision, dev)

@@ -63,6 +63,10 @@ struct lsdm_ctx {
     // index 0: fp3, 1: fp2
     DenseH fp_a[3], fp_y[3];     // first FP layer split at the concat boundary: [0] fp3, [1] fp2, [2] fp4
     float* fp_ybuf[3] = {};
+    int* fp2_plan = nullptr;     // fp2's tile plan (encoder_d.hip::fp_plan_kernel) of a single step, rewritten by every such step
+    int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
+    int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
+    int fp1_order = getenv("LSDM_FP1_ORDER") ? atoi(getenv("LSDM_FP1_ORDER")) : 1;   // A/B switch: fp1 + head walks the source points along that order
     int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
     int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
     const float* sa_wx[3] = {};
@@ -161,6 +165,7 @@ struct lsdm_ctx {
     // output -- for the steps that run on the side stream)
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr;
                      struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3];
+                     int* plan = nullptr;     // fp2's tile plans of every step of a group (one fp_plan_kernel launch per group)
                      // memo of sa2 (geometry.hip: memo_src_kernel): r = 0.2 balls of the source points, flags, F2 rows, work lists, counters
                      int *memo_ball2 = nullptr, *memo_src_list = nullptr, *memo_list = nullptr, *memo_cnt = nullptr, *memo_ident = nullptr;
                      unsigned char *memo_unc = nullptr, *memo_crowd = nullptr; float* memo_F2 = nullptr;
@@ -654,8 +659,14 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         const bool src = skip_sa1 && inv_in_source_order(c);   // level-1 features in source order, read through f.idx[0]
         const float* p1 = src ? static_cast<const float*>(c->inv_F1) : c->feat[0];
         const int* remap = src ? f.idx[0] : nullptr;
+        const bool planned = fp2_ws() == 4;
+        if (planned) {
+            // tiles along the Z curve of the step's level-1 points, each tile's distinct coarse rows (encoder_d.hip)
+            launch_morton_order(nc, f.xyz[0], c->fp2_order, st);
+            launch_fp_plan(nc, c->fp2_order, 0, nullptr, f.nn_idx[2], remap, c->fp2_plan, st);
+        }
         launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
-                      DenseH{nullptr, nullptr}, nullptr, true, st);
+                      DenseH{nullptr, nullptr}, nullptr, true, st, 0, planned ? c->fp2_plan : nullptr);
     } else
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_exec(c, K_FP2, nc * (np == 2 && c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
@@ -681,7 +692,10 @@ bool group_batched(const lsdm_ctx* c) {
 
 bool ensure_group_ws(lsdm_ctx* c, int B) {
     lsdm_ctx::GroupWs& g = c->gws;
-    if (g.cap_B >= B) return true;
+    if (g.cap_B >= B) {
+        if (g.memo_cnt) c->ws_named["memo_cnt"] = {g.memo_cnt, 2};     // (lsdm_reserve clears the names; the group workspace outlives it)
+        return true;
+    }
     for (void* p : g.allocs) (void)hipFree(p);
     g.allocs.clear();
     g.cap_B = 0;
@@ -697,7 +711,7 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
     bool ok = true;
     for (int l = 1; l < 4 && ok; ++l) ok = (g.feat[l] = al(nc * kS[l] * kFeatC[l])) != nullptr;
     ok = ok && (g.ybuf[0] = al(nc * 64 * 256)) && (g.ybuf[2] = al(nc * 16 * 256));
-    ok = ok && (g.pcd = al(nc * kN * 3)) && (g.o12 = al(nc * 12));
+    ok = ok && (g.pcd = al(nc * kN * 3)) && (g.o12 = al(nc * 12)) && (g.plan = reinterpret_cast<int*>(al(nc * fp_plan_ints(1024))));
     if (ok && c->streams > 1) {
         const size_t n1 = (size_t)B * kO;
         for (int k = 0; k < c->nside() && ok; ++k) {
@@ -721,6 +735,7 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
         g.memo_F2 = al(n1 * kN * 128);
         g.memo_crowd = reinterpret_cast<unsigned char*>(al((nc * 256 + 3) / 4));
         ok = g.memo_crowd && g.memo_ball2 && g.memo_src_list && g.memo_list && g.memo_cnt && g.memo_ident && g.memo_unc && g.memo_F2;
+        if (ok) c->ws_named["memo_cnt"] = {g.memo_cnt, 2};      // (lsdm_workspace_tensor: {uncrowded source points of the call, crowded centroids of its last group})
         if (ok) {
             std::vector<int> ident(n1 * kN);
             for (size_t i = 0; i < ident.size(); ++i) ident[i] = (int)(i % kN);
@@ -772,6 +787,12 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
         launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
         prof_exec(c, K_SA1 + 1, nc * 256 * xm::SA2_CENT);
     }
+    // fp2's tile plans of every step of the group in one launch: the source clouds' Z-curve order (once per call) read through each step's
+    // level-1 FPS order
+    if (fp2_ws() == 4) {
+        prof_mark(c, K_FP2, st, 0);      // (timed with the stage, not counted as launches of it: avg_ms stays per step)
+        launch_fp_plan(nc, c->inv_order, nc1, f.idx[0], f.nn_idx[2], f.idx[0], g.plan, st);
+    }
     // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were
     // measured: fp2 337 -> 323 us, but fp1 275 -> 295, fp3 165 -> 190, sa3 / sa4 slower as well -- the extra launch ramps and tails cost
     // more than the cache residency gains)
@@ -818,6 +839,7 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
     const int nc1 = B * kO;
     float* const ybuf1 = lane ? g.alt[lane - 1].ybuf1 : c->fp_ybuf[1];
     float* const fpo2 = lane ? g.alt[lane - 1].fpo2 : c->fpo2;
+    const int* const plan = fp2_ws() == 4 ? g.plan + (size_t)j * nc1 * fp_plan_ints(1024) : nullptr;
     // (fp3 / fp2 / fp1 in two or three cloud slices, so that fp2's 302 MB output stays in the Infinity Cache until fp1 has read it, were
     // measured: fp2 329 us either way, fp3 164 -> 186 -- not kept)
     {
@@ -829,10 +851,12 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         prof_exec(c, K_FP3, ncp * (xm::FP3_PRE + xm::FP3_NEXT_Y));
         prof_mark(c, K_FP2, st);
         launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], ybuf1, fj.nn_idx[2] + o * 1024 * 3,
-                      fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st);
+                      fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st, 0, plan);
         prof_exec(c, K_FP2, ncp * xm::FP2_PRE);
         prof_mark(c, K_FP1, st);
-        launch_fp_s(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st);
+        // (fp1's fine level is the source cloud: walked along the Z curve sorted once per call, LSDM_FP1_ORDER=0: in index order)
+        launch_fp_s(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
+                    c->fp1_order ? c->inv_order + o * 1024 : nullptr, 0);
         prof_exec(c, K_FP1, ncp * xm::FP1);
     }
 }
@@ -1404,7 +1428,9 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->fp_ybuf[0] = ws_alloc<float>(c, "fp3_y", nc * 64 * 256)) && (c->fp_ybuf[2] = ws_alloc<float>(c, "fp4_y", nc * 16 * 256)) &&
          (c->h2x = ws_alloc<float>(c, "h2x", (size_t)B * 128 * 512)) && (c->ctext = ws_alloc<float>(c, "ctext", (size_t)B * kN * 128)) &&
          (c->ct_time = ws_alloc<float>(c, "ct_time", (size_t)(B > lsdm_ctx::kGroup ? B : lsdm_ctx::kGroup) * kN * 128)) &&
-         (c->s_stash = ws_alloc<float>(c, "s_stash", (size_t)B * (kN / 32) * 6 * 16 * 64));
+         (c->s_stash = ws_alloc<float>(c, "s_stash", (size_t)B * (kN / 32) * 6 * 16 * 64)) &&
+         (c->fp2_plan = ws_alloc<int>(c, "fp2_plan", nc * fp_plan_ints(1024))) && (c->fp2_order = ws_alloc<int>(c, "fp2_order", nc * kN)) &&
+         (c->inv_order = ws_alloc<int>(c, "inv_order", nc * kN));
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)
@@ -1504,6 +1530,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         }
         prof_mark(c, K_NN1, si);
         launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, si);
+        launch_morton_order(nc, given_objs, c->inv_order, si);      // fp2's walking order of the source points (encoder_d.hip)
         prof_mark(c, -1, si);
         if (si != st) {
             (void)hipEventRecord(c->ev_join[0], si);

@@ -391,7 +391,7 @@ template <int NW, int NP, int PH = 1>
 __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, long long total_points,
                                                         const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
-                                                        float* __restrict__ out, int dbg) {
+                                                        float* __restrict__ out, int dbg, const int* __restrict__ order, int order_mod) {
     constexpr int C = 128, NT = NW * 64, KS = C / 16, NB = C / 32, F = KS * NP;
     constexpr int NL = 4, FL = NB * F;                       // fragments (1 KiB) per layer
     constexpr int FPN = FL / PH, NBP = NB / PH;              // PH panels per layer: fragments / channel blocks per panel
@@ -460,19 +460,37 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
     const XcdRounds sched = xcd_rounds((int)rounds);       // the work-groups of an XCD walk the rounds together (common.hpp)
     const long long rbeg = sched.first, rend = sched.end, rstep = sched.stride;
     // neighbour indices / weights of a round are requested during the previous one
+    // order (optional; round 5): the points of a cloud are walked along its Z curve (encoder_d.hip::morton_order_kernel, once per call on the
+    // source clouds) instead of in index order, so that the 32 points of a wave are neighbours in space and share their level-1 neighbours:
+    // ~49 distinct rows per wave and round instead of ~93 of the 96 requested -- half the first-touch round trips of the gather.  Position k of
+    // cloud c is point order[(c % order_mod) * N + k]; its neighbour list and its output row are addressed by the point.  Rows of the stack
+    // are independent: results do not depend on the walking order.  The point number of a round is requested two rounds ahead, its neighbour
+    // list one round ahead.
     int ni[3] = {0, 0, 0};
     float nw[3] = {0.0f, 0.0f, 0.0f};
-    auto request = [&](long long rd) {
-        const size_t o = ((size_t)rd * (32 * NW) + wave * 32 + p) * 3;
+    int pn_next = 0, pn_cur = 0;            // point (within its cloud) of this lane in the next round / in the round whose list is in ni, nw
+    auto point_of = [&](long long rd) -> int {
+        const long long k = rd * (32 * NW) + wave * 32 + p;
+        const long long c = k / N;
+        return order ? order[(size_t)(order_mod > 0 ? c % order_mod : c) * N + (k - c * N)] : (int)(k - c * N);
+    };
+    auto request = [&](long long rd, int pn) {
+        const long long c = (rd * (32 * NW) + wave * 32 + p) / N;
+        const size_t o = ((size_t)c * N + pn) * 3;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { ni[j] = nn_idx[o + j]; nw[j] = nn_w[o + j]; }
         if (dbg == 1) { ni[0] = ni[1] = ni[2] = (int)((o / 3) % S); }          // experiment: sequential rows
         if (dbg == 2) { ni[0] = ni[1] = ni[2] = (int)(wave * 4); }               // experiment: one row per wave
     };
-    if (rbeg < rend) request(rbeg);
+    if (rbeg < rend) {
+        pn_cur = point_of(rbeg);
+        request(rbeg, pn_cur);
+        if (rbeg + rstep < rend) pn_next = point_of(rbeg + rstep);
+    }
     for (long long rd = rbeg; rd < rend; rd += rstep) {
-        const long long pt = rd * (32 * NW) + wave * 32 + p;    // this lane's point (both halves of the wave: same point)
+        const long long pt = rd * (32 * NW) + wave * 32 + p;    // this lane's walking position (both halves of the wave: same point)
         const long long c = pt / N;
+        const int pn_this = pn_cur;                             // the point at that position
         [[maybe_unused]] const float* r0 = points2 + ((size_t)c * S + ni[0]) * C + 8 * h;
         const float* r1 = points2 + ((size_t)c * S + ni[1]) * C + 8 * h;
         const float* r2 = points2 + ((size_t)c * S + ni[2]) * C + 8 * h;
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if (rd + rstep < rend) request(rd + rstep);
+            if (rd + rstep < rend) { request(rd + rstep, pn_next); pn_cur = pn_next; if (rd + 2 * rstep < rend) pn_next = point_of(rd + 2 * rstep); }
         } else {
         // ---- interpolated operand, k-step s = channels 16 s + 8 h .. + 7 of this lane's point (four k-steps per batch of loads)
 #pragma unroll
@@ -543,7 +561,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
             for (int s = 0; s < GK; ++s)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) d[s][q] = load4f(r2 + 16 * (s0 + s) + 4 * q);
-            if (s0 + GK >= KS && rd + rstep < rend) request(rd + rstep);
+            if (s0 + GK >= KS && rd + rstep < rend) { request(rd + rstep, pn_next); pn_cur = pn_next; if (rd + 2 * rstep < rend) pn_next = point_of(rd + 2 * rstep); }
 #pragma unroll
             for (int s = 0; s < GK; ++s) {
                 float v[8];
@@ -627,18 +645,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __re
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], wh, acc, 0, 0, 0);
             }
-            if (p < 3) {
-                const float bv = bl[lz + NL * C + p];
-                const long long pt0 = rd * (32 * NW) + wave * 32;
+            {
+                // accumulator r of lane (p, h) = channel p of the wave's point acc_row(r, lane): its output row is that point's -- read out of the
+                // lane that owns it
+                const float bv = bl[lz + NL * C + (p < 3 ? p : 0)];
+                const size_t cb = (size_t)c * N;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[(size_t)(pt0 + acc_row(r, lane)) * 3 + p] = acc[r] + bv;
+                for (int r = 0; r < 16; ++r) {
+                    const int pr = __shfl(pn_this, acc_row(r, lane));
+                    if (p < 3) out[(cb + pr) * 3 + p] = acc[r] + bv;
+                }
             }
         }
     }
 }
 
 void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
-                 hipStream_t st) {
+                 hipStream_t st, const int* order, int order_mod) {
     // timing experiment (compile-time only, `make TIMING=1`; results are wrong with it): 1 sequential rows, 2 one row per wave
 #ifdef LSDM_TIMING_EXPERIMENTS
     static const int dbg = getenv("LSDM_DBG_GATHER") ? atoi(getenv("LSDM_DBG_GATHER")) : 0;
@@ -650,7 +673,7 @@ void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* n
     // the 168 of that occupancy and the build spills 95 of them)
     // (two work-groups of four waves per CU on half-layer panels -- fp_s_kernel<4, 2, 2>, grid 512: the two groups drift out of phase, one gathers
     // while the other multiplies, for twice the panel traffic -- measured 290 against 271 us, round 4)
-    hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg);
+    hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg, order, order_mod);
 }
 
 void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,

@@ -1496,12 +1496,13 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
     hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
 }
 
-// LSDM_FP2_WS: fp2 on 2 = the persistent kernel with register-resident weights (fp_rw_kernel), 1 = the persistent wave-specialised kernel
-// (fp_ws_kernel), 0 = the tile-per-work-group form (fp_pre_kernel).  Same results bit for bit.
+// LSDM_FP2_WS: fp2 on 4 = the two-stage persistent kernel over Morton-ordered tiles with deduplicated rows (fp_d_kernel, encoder_d.hip; the default),
+// 2 = the persistent kernel with register-resident weights (fp_rw_kernel), 1 / 3 = the persistent wave-specialised kernel (fp_ws_kernel, 64- / 32-row
+// tiles), 0 = the tile-per-work-group form (fp_pre_kernel).  Same results bit for bit.
 #ifndef LSDM_FP2_DEFAULT
-#define LSDM_FP2_DEFAULT 1
+#define LSDM_FP2_DEFAULT 4
 #endif
-static int fp2_ws() {
+int fp2_ws() {
     const char* e = getenv("LSDM_FP2_WS");      // (read per launch: the A/B tests flip it inside one process)
     return e ? atoi(e) : LSDM_FP2_DEFAULT;
 }
@@ -1519,7 +1520,7 @@ static int fp2_ws() {
 #endif
 void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
-                   bool keep_out, hipStream_t st, int p1_mod) {
+                   bool keep_out, hipStream_t st, int p1_mod, const int* plan) {
     const int S = which == 2 ? 256 : (which == 3 ? 64 : 16);
     const DenseH none{nullptr, nullptr};
     if (which == 4) {
@@ -1530,7 +1531,10 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
         return;
     }
     if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
-    if (which == 2 && fp2_ws() == 2) {
+    if (which == 2 && plan) {
+        launch_fp_d(nc, points1, ybuf, nn_w, l1a, l2, out, plan, st, p1_mod);
+    }
+    else if (which == 2 && fp2_ws() == 2) {
         const int total = 1024 / 64 * nc;
         hipLaunchKernelGGL((fp_rw_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
                            out, p1_mod, total);

@@ -105,8 +105,9 @@ void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const 
 // y = coarse-level FP output x Wb^T (the pre-multiplied interpolation operand of the next finer FP stage), R rows of 256 channels
 void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
 // fp1 + head as one register-chained stack (bf16x3): points2 (nc,1024,128) fp32, out (nc,1024,3)
+// order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
 void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b,
-                 float* out, hipStream_t st);
+                 float* out, hipStream_t st, const int* order = nullptr, int order_mod = 0);
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
 // point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
 // ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
@@ -126,7 +127,19 @@ void launch_sa_u(int level, int num_clouds, const float* U, const float* V, cons
 // fp2's pre-multiplied operand ynext = out x wb_next^T, and stores `out` itself only when keep_out (parity taps)
 void launch_fp_pre(int which, int num_clouds, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
-                   bool keep_out, hipStream_t st, int p1_mod = 0);      // p1_mod > 0 (with p1_remap): points1 is a per-CALL tensor, cloud c % p1_mod
+                   bool keep_out, hipStream_t st, int p1_mod = 0,      // p1_mod > 0 (with p1_remap): points1 is a per-CALL tensor, cloud c % p1_mod
+                   const int* plan = nullptr);
+// (plan, which = 2: the tile plan of the launch's clouds, written by launch_fp_plan -- fp2 then runs on fp_d_kernel)
+// encoder_d.hip: fp2 with the gathered rows deduplicated through LDS (Morton-ordered tiles, each distinct row landed once by LDS-DMA)
+//   launch_morton_order: order (nc,1024) <- the Z-curve order of each cloud's points
+//   launch_fp_plan     : plan (nc, fp_plan_ints(1024)) <- tiles of 32 points along `order` (of cloud c % order_mod when order_mod > 0), their distinct
+//                        coarse rows and every point's slots / weights; idx1 != NULL: `order` sorts SOURCE points and the fine level is idx1's order
+size_t fp_plan_ints(int N);
+int fp2_ws();      // LSDM_FP2_WS (read per launch): 4 = fp_d_kernel
+void launch_morton_order(int num_clouds, const float* xyz, int* order, hipStream_t st);
+void launch_fp_plan(int num_clouds, const int* order, int order_mod, const int* idx1, const int* nn_idx, const int* p1_remap, int* plan, hipStream_t st);
+void launch_fp_d(int num_clouds, const float* points1, const float* ybuf, const float* nn_w, DenseH l1a, DenseH l2, float* out, const int* plan, hipStream_t st,
+                 int p1_mod);
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)
 void launch_cond(const CondParams& P, const int64_t* t, const float* text, const float* given_cats, const float* mask, int B, int G, int C,

@@ -867,6 +867,9 @@ void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const f
     const int rows = (int)X.rows, K = X.C;
     if (need_dx && X.g) {
         const bool first = X.gs && *X.gs == 0 && X.ld == K;       // lazy buffer, whole tensor: this GEMM stores it
+        // (a column slice of a lazy buffer as the FIRST writer would accumulate into memory that was never zeroed: no call site does that
+        // today -- the protocol is checked here instead of held by convention)
+        if (X.gs && *X.gs == 0 && X.ld != K) { tfail(s, LSDM_ERR_STATE, "training: first writer of a lazy gradient buffer is a column slice (%d of %lld columns)", K, X.ld); return; }
         gemm(s, dZ, N, 1, W.w, K, 1, X.g, X.ld, 1, rows, K, N, nullptr, first ? 0 : 1);
         if (X.gs) *X.gs = 1;
     }
@@ -980,8 +983,13 @@ const char* lsdm_train_last_error(const lsdm_train* s) { return s ? s->err.c_str
 
 int lsdm_train_bind(lsdm_train* s, const char* name, float* param, float* grad, int64_t numel) {
     if (!s || !name || !param || numel <= 0) return tfail(s, LSDM_ERR_ARG, "lsdm_train_bind: bad argument");
-    s->bound[name] = lsdm_train::Bound{param, grad, numel};
-    s->zl_dirty = true;
+    // (re-binding the same tensors -- the Python side binds every parameter on every step -- leaves the device-side gradient list alone: it is
+    // rebuilt, with two hipFree / hipMalloc / blocking copies, only when an entry is new or one of its pointers or its size changed)
+    auto it = s->bound.find(name);
+    if (it == s->bound.end() || it->second.p != param || it->second.g != grad || it->second.n != numel) {
+        s->bound[name] = lsdm_train::Bound{param, grad, numel};
+        s->zl_dirty = true;
+    }
     return LSDM_OK;
 }
 

@@ -245,11 +245,13 @@ class SceneDiffusionModel(nn.Module):
         ring = getattr(self, "_t_ring", None)
         if ring is None:
             ring = self._t_ring = [torch.zeros(1, dtype=torch.uint8).pin_memory() for _ in range(8)]
-            self._t_pending, self._t_next = [], 0
-        if len(self._t_pending) >= len(ring):          # every slot still in flight: wait for the oldest (never in practice)
+            self._t_pending = []
+        if len(self._t_pending) >= len(ring):          # every slot still in flight: wait for all of them (never in practice)
             self.check_timesteps(block=True)
-        host = ring[self._t_next % len(ring)]
-        self._t_next += 1
+        # a slot that NO pending check refers to (checks of calls on different streams can retire out of order: "the next in the ring"
+        # could still be in flight and its verdict would be overwritten)
+        busy = {id(h) for _, h, _ in self._t_pending}
+        host = next(h for h in ring if id(h) not in busy)
         host.copy_(((t < 0) | (t >= t_max)).any().to(torch.uint8).reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(t.device))

@@ -20,7 +20,7 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_samples(local, dist=None, total=None, agree=True):
+def gather_samples(local, dist=None, total=None, agree=True, _invalid=None):
     """All-gathers (B_local, ...) tensors into (sum of B_local, ...) in rank order.  ``dist`` is the initialised
     ``torch.distributed`` module or None for a single process.  Equal shard sizes (the bench: 64 chains per rank) take one
     ``all_gather_into_tensor``; with ``total`` = the job's unit count split by ``shard_range`` (sizes differing by one when
@@ -29,16 +29,23 @@ def gather_samples(local, dist=None, total=None, agree=True):
     the wrong shard makes EVERY rank raise instead of leaving the others waiting in the collective; a caller that has already agreed
     on the sizes (bench.py: the untimed warm-up gather) passes ``agree=False`` and issues exactly one collective."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if _invalid:
+            raise ValueError(_invalid)
         return local
     world = dist.get_world_size()
     sizes = [local.shape[0]] * world if total is None else [shard_range(total, r, world)[1] - shard_range(total, r, world)[0]
                                                             for r in range(world)]
     # validity is agreed on COLLECTIVELY: a rank that raised alone would leave the others waiting in the all-gather
-    if agree:
-        held = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    # (_invalid: a local precondition of the caller that failed -- it travels as a held size of -1, so that every rank raises together)
+    if agree or _invalid:
+        held = torch.tensor([-1 if _invalid else local.shape[0]], dtype=torch.int64, device=local.device)
         every = torch.empty(world, dtype=torch.int64, device=local.device)
         dist.all_gather_into_tensor(every, held)
         every = [int(v) for v in every.cpu()]
+        if _invalid:
+            raise ValueError(_invalid)
+        if -1 in every:
+            raise ValueError("rank(s) %s hold inconsistent tensors (their own error says which)" % [r for r, v in enumerate(every) if v < 0])
         if every != sizes:
             raise ValueError("shard sizes per rank %s, expected %s (%s)" % (every, sizes, "shard_range(%d)" % total if total is not None
                                                                               else "equal shards: pass total= for a ragged split"))
@@ -61,16 +68,24 @@ def gather_results(sample, saved_cat=None, guiding=None, dist=None, total=None, 
     entries passed as None come back as None.  8 x 64 chains: 6.3 MB with the guiding points -- latency-, not bandwidth-bound."""
     parts = [("sample", sample)] + [(n, t) for n, t in (("saved_cat", saved_cat), ("guiding", guiding)) if t is not None]
     B = sample.shape[0]
+    # local preconditions (every part holds B chains of fp32 values): a failure is AGREED ON with the other ranks inside gather_samples' size
+    # exchange -- raising here alone would leave them waiting in the collective
+    invalid = None
     for n, t in parts:
         if t.shape[0] != B:
-            raise ValueError("%s holds %d chains, the sample %d" % (n, t.shape[0], B))
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            invalid = "%s holds %d chains, the sample %d" % (n, t.shape[0], B)
+        elif t.dtype != torch.float32:
+            invalid = "%s is %s: the packed collective carries float32 rows only" % (n, t.dtype)
+    single = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    if single and not invalid:
         return sample, saved_cat, guiding
-    flat = [t.reshape(B, -1).to(torch.float32) for _, t in parts]
+    if invalid:
+        gather_samples(sample.new_zeros((B, 1), dtype=torch.float32), dist, total=total, _invalid=invalid)     # raises on every rank
+    flat = [t.reshape(B, -1) for _, t in parts]
     packed = gather_samples(flat[0] if len(flat) == 1 else torch.cat(flat, dim=1), dist, total=total, agree=agree)
     out, col = {}, 0
     for (n, t), f in zip(parts, flat):
         w = f.shape[1]
-        out[n] = packed[:, col:col + w].reshape((packed.shape[0],) + tuple(t.shape[1:])).to(t.dtype)
+        out[n] = packed[:, col:col + w].reshape((packed.shape[0],) + tuple(t.shape[1:]))
         col += w
     return out["sample"], out.get("saved_cat"), out.get("guiding")

@@ -83,11 +83,13 @@ def make_synthetic_state_dict(seed=0, gain=DEFAULT_GAIN, max_cats=13, **spec_kwa
 
 
 def make_synthetic_batch(batch, seed=1, max_cats=13, num_slots=9, num_points=1024, all_ones_mask=False,
-                         num_objects=None, text_dim=512):
+                         num_objects=None, text_dim=512, surface=False):
     """Returns dict(mask (B,O), given_objs (B,O,N,3), given_cats (B,O,C), text_features (B,text_dim)), fp32.
 
     ``num_objects``: fixed k for every sample (e.g. 8 = BASELINE config 3's "8192-pt scene cloud");
-    default k ~ U{1..8} per sample."""
+    default k ~ U{1..8} per sample.  ``surface``: the object points lie ON the six faces of their box (area-weighted) instead of
+    in its volume -- PROX objects are surface scans (posa/dataset.py:424-440 loads sampled mesh vertices), sparser within a ball than
+    the volume-filling default (a different random stream from the first object on)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     B, O, N, C = batch, num_slots, num_points, max_cats
     objs = np.zeros((B, O, N, 3), dtype=np.float32)
@@ -100,7 +102,13 @@ def make_synthetic_batch(batch, seed=1, max_cats=13, num_slots=9, num_points=102
         for o in range(1, k + 1):
             centre = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(0, 1)])
             half = rng.uniform(0.2, 0.8, size=3)
-            objs[b, o] = centre + rng.uniform(-1, 1, size=(N, 3)) * half
+            pts = rng.uniform(-1, 1, size=(N, 3))
+            if surface:
+                # one coordinate of every point pinned to +-1: the face's axis drawn with probability proportional to the face area
+                area = np.array([half[1] * half[2], half[0] * half[2], half[0] * half[1]])
+                axis = rng.choice(3, size=N, p=area / area.sum())
+                pts[np.arange(N), axis] = rng.choice([-1.0, 1.0], size=N)
+            objs[b, o] = centre + pts * half
             mask[b, o] = 1.0
             cats[b, o, int(rng.integers(1, C))] = 1.0
     if all_ones_mask:

@@ -28,7 +28,8 @@ def test_repeated_sampler_calls_are_bit_identical_at_b64(entry):
 
 def test_bench_json_line_carries_the_contract_fields():
     """`python bench.py` as the driver runs it (N = 1; short): ONE JSON line with the contract's fields, the roofline of the dominant kernel with
-    its three fractions, the fill-path figures of the gather-bound stages, and value = 1000 / ms_per_step."""
+    its three fractions, the fill-path figures of the gather-bound stages, value = 1000 / ms_per_step, and a short leg for every BASELINE config
+    that fits one GPU beside the headline (configs[1] in f32 and bf16x3, configs[4]'s HUMANISE / DDIM-250 shapes, surface-sampled clouds)."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,5 +47,12 @@ def test_bench_json_line_carries_the_contract_fields():
     rf = r["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert 0 < rf["frac_executed"] < rf["frac"] < rf["mfma_issue_frac"] < 1.0          # executed < reference FLOPs; x3 matrix instructions per product
-    assert set(r["fill_path"]["stages"]) >= {"fp_kernel<fp2>", "fp_kernel<fp1+head>"} and 0 < r["fill_path"]["stages"]["fp_kernel<fp2>"]["frac_of_11"] < 1.2
+    assert set(r["fill_path"]["stages"]) >= {"fp_kernel<fp2>", "fp_kernel<fp1+head>"} and 0 < r["fill_path"]["stages"]["fp_kernel<fp1+head>"]["frac_of_l2_ceiling"] < 1.0
     assert r["repeats"]["final_sample_bit_identical_to_timed_region"] is True
+    cf = r["configs"]
+    assert set(cf) >= {"configs[1]_f32", "configs[1]_bf16x3", "configs[4]_one_gpu", "headline_surface_sampled"}
+    for e in cf.values():
+        assert e["value"] > 0 and e["finite"] is True and abs(e["value"] - 1e3 / e["ms_per_step"]) <= 1e-6 * e["value"]
+    assert cf["configs[1]_f32"]["batch"] == 16 and cf["configs[1]_f32"]["max_cats"] == 43 and cf["configs[1]_f32"]["dtype"] == "f32"
+    assert cf["configs[4]_one_gpu"]["sampler"] == "ddim" and cf["configs[4]_one_gpu"]["schedule_T"] == 250 and cf["configs[4]_one_gpu"]["max_cats"] == 11
+    assert 0.0 < cf["headline_surface_sampled"]["sa2_memo"]["centroid_hit_rate"] <= 1.0

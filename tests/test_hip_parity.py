@@ -526,6 +526,50 @@ def test_config2_b16_c43_first_and_last_five_steps_vs_reference_golden(golden, p
         assert torch.equal(out_cat, cat_loop) and torch.equal(out_g, guid_loop), entry
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_config2_b16_c43_mid_schedule_25_steps_vs_reference_golden(golden, precision):
+    """Error accumulation at BASELINE configs[1]'s shape beyond ten steps (SURVEY.md 8(d) "Config 2" (ii); G15, recorded from the real
+    reference): B = 16, C = 43, K = 25 consecutive steps from t = 524 (init_image + skip_timesteps = 475), every fifth sample, saved_cat
+    and the guiding points -- through the per-step progressive loop, and the drop-in bulk call bit-equal to it."""
+    from test_oracle_golden import g15_args, g15_check
+    g = golden("g15_config2_mid")
+    B, C_, K, seed, bt_seed, kw = g15_args(g)
+    kw["init_image"] = kw["init_image"].to(DEV)
+    m, diff = create_model_and_diffusion("proxd", max_cats=C_, precision=precision)
+    m.load_state_dict(make_synthetic_state_dict(seed=0, max_cats=C_))
+    bt = {k: v.to(DEV) for k, v in make_synthetic_batch(B, seed=bt_seed, max_cats=C_).items()}
+    args = (m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"])
+    torch.manual_seed(seed)
+    fifths, last = [], None
+    for i, o in enumerate(diff.p_sample_loop_progressive(*args, clip_denoised=False, **kw)):
+        if i % 5 == 4:
+            fifths.append(o["sample"].clone())
+        if i + 1 == K:
+            break
+    worst = g15_check(g, fifths, m.saved_cat, m.saved_guiding_points, 1e-4)
+    print("g15 %s: worst deviation over 25 steps, relative to the sample's magnitude (15 .. 95): %.2e" % (precision, worst))
+    # the same 25 steps as ONE library call per schedule (what a chunk of the bulk loop is): draws in the reference's order (SURVEY H1)
+    torch.manual_seed(seed)
+    x_T = torch.randn(B, 1024, 3)
+    t0 = 1000 - kw["skip_timesteps"] - 1
+    x_t = diff.q_sample(kw["init_image"], torch.full((B,), t0, dtype=torch.long, device=DEV), x_T.to(DEV))
+    starts, noise = [], []
+    for _ in range(K):
+        starts.append(torch.stack(cpu_ref.draw_fps_starts(B * 9)))
+        noise.append(torch.randn(B, 1024, 3))
+    d_starts, d_noise = torch.stack(starts).to(DEV).contiguous(), torch.stack(noise).to(DEV).contiguous()
+    for entry in ("lsdm_sample_steps", "lsdm_sample_steps_invariant"):
+        x = x_t.clone().contiguous()
+        out_cat = torch.empty(B, 1, C_, device=DEV)
+        out_x0, out_g = torch.empty_like(x), torch.empty_like(x)
+        m._ctx.call(entry, _lib.MODE_P_SAMPLE, 0.0, B, t0, K, x.data_ptr(), bt["mask"].data_ptr(), bt["given_objs"].data_ptr(),
+                    bt["given_cats"].data_ptr(), bt["text_features"].data_ptr(), d_starts.data_ptr(), d_noise.data_ptr(),
+                    out_cat.data_ptr(), out_x0.data_ptr(), out_g.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert torch.equal(x, fifths[-1]), entry
+        assert torch.equal(out_cat, m.saved_cat) and torch.equal(out_g, m.saved_guiding_points), entry
+
+
 def test_sample_steps_entry_point_equals_python_loop(sd13):
     """lsdm_sample_steps (device-resident RNG draws, K steps in one call) == K calls of lsdm_step."""
     B, K = 2, 3

@@ -190,6 +190,39 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert "respawn_ranks(a.gpus)" in src and "torch.distributed.run" in src
 
 
+def test_bench_rank_bookkeeping_world8_gloo_stub():
+    """The driver's 8-GPU command line -- `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W` -- with the GPU
+    work stubbed at the Runner boundary (--stub-runner: gloo, CPU, no library call): everything AROUND the kernels is bench.py's real code.  Eight
+    ranks read RANK / LOCAL_RANK / WORLD_SIZE, seed = base + rank, pass the barriers, run the packed all-gather of samples + saved_cat + guiding
+    points (rank order checked inside bench.py), take the max over the ranks' times, and rank 0 prints ONE line: value = 8 x steps / slowest rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    K, W = 4, 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(K), "--warmup", str(W), "--stub-runner"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["stub"] is True and r["data"].startswith("stub")
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["steps"] == K and r["warmup"] == W and r["scaling"] == "weak"
+    assert r["per_rank_seeds"] == [1, 2, 3, 4, 5, 6, 7, 8]
+    assert r["config"]["global_batch"] == 512 and r["config"]["chains_per_gpu"] == 64
+    assert len(r["per_rank_ms_per_step"]) == 8 and r["allgather_us"] > 0 and r["allgather_bytes_per_rank"] == 64 * (2 * 3072 + 13) * 4
+    slowest = max(r["per_rank_ms_per_step"])
+    assert abs(r["ms_per_step"] - slowest) <= 1e-3 * slowest                       # the job's time is its slowest rank's
+    assert abs(r["value"] - 8 * 1e3 / r["ms_per_step"]) <= 1e-6 * r["value"]      # whole-job steps/s: the sum over the GPUs
+    assert r["per_rank_ms_per_step"][7] >= r["per_rank_ms_per_step"][0]            # (the stub's rank 7 sleeps 1.7x rank 0's time)
+    assert abs(r["sample_steps_per_s"] - 64 * r["value"]) <= 1e-6 * r["sample_steps_per_s"]
+
+
 def test_metrics_known_answers():
     from lsdm_amd.metrics import accuracy, calculate_fscore, chamfer_distance, emd
     a = torch.tensor([[[0.0, 0, 0], [1, 0, 0]]])

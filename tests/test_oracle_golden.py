@@ -163,6 +163,58 @@ def test_g14_config2_depth(golden, tag):
     g14_check(g, got, smp.saved_cat, smp.saved_guiding_points, 1e-4)
 
 
+def g15_args(g):
+    """The call oracle/make_goldens.py::g15 made on the reference: (B, C, K, seed, batch seed, loop keyword arguments)."""
+    B, C, K, seed, bt_seed, skip, init_seed = [int(v) for v in g["meta"]]
+    gen = torch.Generator().manual_seed(init_seed)
+    return B, C, K, seed, bt_seed, dict(init_image=0.7 * torch.randn(B, 1024, 3, generator=gen), skip_timesteps=skip)
+
+
+def g15_check(g, fifths, saved_cat, guiding, rel, upto=None):
+    """fifths: the samples after steps 5, 10, ... (B,1024,3) -- every 4th point of each against the record of the real reference, the
+    25th in full with saved_cat and every 2nd guiding point (only when all five are given).  Mid-schedule states are not O(1): with the
+    synthetic gains |x| grows from 15 to 95 over these 25 steps (t = 524..500), so a sample is held to ``rel`` of ITS magnitude (as the
+    T = 1000 chain's intermediate samples are); the guiding points are O(1) and take ``rel`` as an absolute bar x 10.
+    Returns the worst relative deviation."""
+    n = len(g["steps_sub"]) if upto is None else upto
+    assert len(fifths) == n
+    worst = 0.0
+    for k in range(n):
+        mag = max(1.0, float(np.abs(g["steps_sub"][k]).max()))
+        worst = max(worst, maxabs(fifths[k][:, ::4].cpu(), g["steps_sub"][k]) / mag)
+        assert worst <= rel, (k, worst, mag)
+    if n == len(g["steps_sub"]):
+        mag = max(1.0, float(np.abs(g["final"]).max()))
+        assert maxabs(fifths[-1].cpu(), g["final"]) / mag <= rel
+        assert maxabs(saved_cat.cpu(), g["saved_cat"]) <= 1e-6
+        assert maxabs(guiding[:, ::2].cpu(), g["guiding_sub"]) <= 10 * rel
+    return worst
+
+
+def test_g15_config2_mid_schedule(golden):
+    """BASELINE configs[1]'s shape in the middle of the schedule (G15: init_image + skip_timesteps = 475, t = 524..500, recorded from the
+    real reference).  The CPU suite follows the first five steps only (the oracle needs ~20 s per step at B = 16); the GPU suite runs all 25."""
+    g = golden("g15_config2_mid")
+    B, C, K, seed, bt_seed, kw = g15_args(g)
+    assert (B, C, K) == (16, 43, 25)
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    bt = make_synthetic_batch(B, seed=bt_seed, max_cats=C)
+    smp = cpu_ref.Sampler(sd)
+    got = []
+
+    def on_step(i, o):
+        got.append(o["sample"].clone())
+        if len(got) == 5:
+            raise _Enough
+
+    torch.manual_seed(seed)
+    try:
+        smp.sample_loop([B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"], on_step=on_step, **kw)
+    except _Enough:
+        pass
+    g15_check(g, got[4:5], None, None, 1e-5, upto=1)
+
+
 @pytest.mark.parametrize("tag", ["b1", "b3"])
 def test_g4_short_chain(golden, tag):
     g = golden("g4_chain_%s" % tag)

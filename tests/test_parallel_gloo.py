@@ -102,6 +102,13 @@ def _ragged_worker(rank, world, port, q):
         raise AssertionError("mismatched chain counts accepted")
     except ValueError:
         pass
+    # ... and when only ONE rank holds mismatched / non-fp32 tensors: the failure travels in the size exchange, BOTH ranks raise (no hang)
+    for bad_cats in (cats[:1 + hi - lo] if rank == 1 else cats[lo:hi], cats[lo:hi].double() if rank == 0 else cats[lo:hi]):
+        try:
+            gather_results(units[lo:hi], bad_cats, None, dist, total=total)
+            raise AssertionError("a rank with inconsistent tensors went through on rank %d" % rank)
+        except ValueError:
+            pass
     dist.barrier()
     if rank == 0:
         q.put((got.numpy(), bad))
