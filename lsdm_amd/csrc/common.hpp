@@ -89,8 +89,15 @@ __device__ __forceinline__ unsigned lds_addr(const T* p) {
 //    interpolated rows visible in fp2's output: got = a w0 + d w2 exactly).  88 of 100 forwards at B = 16 had a few such rows in fp2, 4
 //    of 400 in fp1; nothing else changes run to run.  With scalar instructions: 0 of 400 (tools/determinism_stress.py,
 //    tests/test_hip_determinism.py).  Same speed: the gather waves have VALU slots to spare.
+// LSDM_INTERP_PACKED (hazard experiments only, tools/pk_hazard_variants.sh -- needs a build WITHOUT the Makefile's -packed-fp32-ops):
+//   1  plain expression: hipcc packs it with SGPR weight pairs and op_sel (the failing form of round 4)
+//   2  the same with the weights first moved to VGPRs (no scalar operand, no cross operand selection in the packed instructions)
 __device__ __forceinline__ float interp3(float a, float b, float d, float w0, float w1, float w2) {
-#ifdef LSDM_INTERP_PACKED
+#if defined(LSDM_INTERP_PACKED) && LSDM_INTERP_PACKED == 2
+    float v0 = w0, v1 = w1, v2 = w2;
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));
+    return __builtin_fmaf(d, v2, __builtin_fmaf(b, v1, a * v0));
+#elif defined(LSDM_INTERP_PACKED)
     return __builtin_fmaf(d, w2, __builtin_fmaf(b, w1, a * w0));       // (A/B only: reproduces the lost updates)
 #else
     float t = a * w0;

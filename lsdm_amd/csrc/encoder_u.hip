@@ -1007,6 +1007,9 @@ __global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ po
         }
     };
     auto g_interp = [&](int q0) {
+#if defined(LSDM_PK_NOPS)      // (hazard experiment: idle cycles between the wave's wake-up from its load wait and the first packed instruction)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#endif
         const int gwf = __builtin_bit_cast(int, gw);
 #pragma unroll
         for (int q = 0; q < GB; ++q) {

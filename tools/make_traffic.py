@@ -21,7 +21,7 @@ STAGES = {
     "sa_kernel<256,256,256,512>": ["lin_u_kernel<256, 256, true>", "sa_w_kernel", "sa_x_kernel", "sa_h_kernel<256, 256, 256, 512"],
     "fp_kernel<fp4>": ["lin_u_kernel<512, 256, false>", "fp_pre_kernel<256, 256, 256", "fp_h_kernel<256, 512"],
     "fp_kernel<fp3>": ["fp_pre_kernel<128, 256, 256", "fp_h_kernel<128, 256"],
-    "fp_kernel<fp2>": ["fp_ws_kernel", "fp_rw_kernel", "fp_pre_kernel<64, 256, 128", "fp_ps_kernel", "fp_h_kernel<64, 256"],
+    "fp_kernel<fp2>": ["fp_d_kernel", "fp_ws_kernel", "fp_rw_kernel", "fp_pre_kernel<64, 256, 128", "fp_ps_kernel", "fp_h_kernel<64, 256"],
     "fp_kernel<fp1+head>": ["fp_s_kernel", "fp_h_kernel<0, 128"],
     "fps_chain_kernel": ["fps_chain"],
     "denoise_kernel": ["denoise_r_kernel", "denoise_h_kernel", "denoise_kernel"],
@@ -48,5 +48,6 @@ for arg in sys.argv[1:]:
         if parts:
             out[prec][stage] = {"fetch_bytes": f, "fetch_bytes_x2": 2 * f, "write_bytes": w, "unit": "bytes per launch (B=64)", "launches": parts}
     out[prec]["_source"] = os.path.basename(path)
+    out[prec]["_kernels"] = sorted({p for st in out[prec].values() if isinstance(st, dict) for p in st["launches"]})
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1)[:1800])

@@ -11,7 +11,13 @@ python bench.py --steps 50 --warmup 7 > gpurun_out/${TAG}_bench.json 2>> gpurun_
 python tools/loop_wall.py > gpurun_out/${TAG}_loop_wall.txt 2>&1
 tools/round_profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
 tools/pmc_mem.sh $TAG > gpurun_out/${TAG}_pmc_mem.txt 2>&1
+# profiles/traffic.json is what bench.py's roofline.traffic reads: regenerated from THIS tag's PMC pass (and copied back with the run's outputs --
+# the GPU box's working copy is scratch); the round fails loudly if the file does not name this tag as its source
 python tools/make_traffic.py bf16x3=gpurun_out/pmc_$TAG.json > /dev/null 2>&1 && cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
+python - <<PY || { echo "round_all: profiles/traffic.json was NOT regenerated from pmc_$TAG.json"; exit 1; }
+import json, sys
+sys.exit(0 if json.load(open("profiles/traffic.json")).get("bf16x3", {}).get("_source") == "pmc_$TAG.json" else 1)
+PY
 tail -2 gpurun_out/${TAG}_loop_wall.txt
 python - <<PY
 import json
