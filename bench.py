@@ -243,16 +243,21 @@ def config_legs(a, dev, local_rank, inv):
         r = Runner(precision, B, C, 2 + K, a.seed, local_rank, dev, **kw)
         T = r.T
         r.run(T - 1, 0, 2, invariant=inv)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        r.run(T - 3, 2, K, invariant=inv)
-        torch.cuda.synchronize()
-        d = time.perf_counter() - t1
-        e = {"value": K / d, "unit": "denoising-steps/sec (batch of %d chains)" % B, "ms_per_step": d / K * 1e3, "steps": K, "batch": B, "max_cats": C,
+        x0 = r.x.clone()
+        ds = []
+        for _ in range(3):                       # median of three repeats of the same K-step call (a fresh context's first long call can hiccup)
+            r.x.copy_(x0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            r.run(T - 3, 2, K, invariant=inv)
+            torch.cuda.synchronize()
+            ds.append(time.perf_counter() - t1)
+        d = sorted(ds)[1]
+        e = {"value": K / d, "value_is": "median of 3 repeats", "value_min": K / max(ds), "value_max": K / min(ds), "unit": "denoising-steps/sec (batch of %d chains)" % B, "ms_per_step": d / K * 1e3, "steps": K, "batch": B, "max_cats": C,
              "dtype": precision, "sample_steps_per_s": B * K / d, "schedule_T": T, "sampler": "ddim" if kw.get("ddim") else "p_sample",
              "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps", "finite": bool(torch.isfinite(r.x).all()), "workload": note}
         if kw.get("surface") or name == "headline_volume_reference":
-            # sa2's memo (DESIGN.md 8b): memo_cnt = {uncrowded source points of the call, crowded centroids of the call's last group}; the K steps are one group
+            # sa2's memo (DESIGN.md 10): memo_cnt = {uncrowded source points of the call, crowded centroids of the call's last group}; the K steps are one group
             try:
                 ptr, n = r.ctx.workspace_tensor("memo_cnt")
                 cnt = (ctypes.c_int * 2)()
@@ -585,7 +590,7 @@ def main():
                                   "frac_executed": round(q["ex_tflops"] / peak, 4), "mfma_issue_frac": round(q["ex_tflops"] * issue / peak, 4)} for q in rows]},
     })
     if a.precision == "bf16x3":
-        # The other roof these stages touch (DESIGN.md "The roofline of the gathers"): bytes a launch pulls through the CUs' fill path (gathered rows +
+        # The other roof these stages touch: bytes a launch pulls through the CUs' fill path (gathered rows +
         # weight fragments / panels streamed per tile or round; per cloud, x 9 B clouds) / stage time, against what tools/ubench/gather2_bw.hip
         # measures for random 1 KB rows with four gathering waves per CU and precomputed indices (profiles/r05_gather2_bw.txt: 25 TB/s L2-resident,
         # 8.7 TB/s out of the Infinity Cache; round 4's gather_bw.hip measured its own address arithmetic at four waves: 11 TB/s).  fp2 (round 5,

@@ -32,7 +32,7 @@ __device__ __forceinline__ float reluf(float v) {
 
 // Activations of the split-bf16 dense stacks (bf16x3 / bf16 modes): the same functions evaluated with the hardware
 // exp2 / reciprocal (1 ulp each) instead of libm's erff / expf / IEEE division -- the denoiser applies ~640 GELU / sigmoid
-// evaluations per point and VALU time adds to MFMA time on gfx950 (DESIGN.md "What a SIMD does ...").
+// evaluations per point and VALU time adds to MFMA time on gfx950.
 //   GELU: Phi(v) through Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), written so that the negative branch has no
 //   cancellation: Phi(-|v|) = P(t) e^{-x^2} / 2,  Phi(|v|) = 1 - P(t) e^{-x^2} / 2,  x = |v| / sqrt(2), t = 1 / (1 + p x).
 // Absolute error of gelu_fast <= |v| * 1.1e-7, of sigmoid_fast <= 3e-7; the exact-f32 mode keeps gelu / sigmoidf above.

@@ -1,7 +1,7 @@
 """Run-to-run determinism of the whole forward under load (B = 16, 144 clouds: every persistent kernel runs several tiles per
 work-group).  The reference is deterministic (models/sdm.py, pointnet2_utils.py have no atomics); so is every kernel here by
 construction -- this test is the net for intra-kernel races and hardware hazards, which only show with the chip full
-(tools/determinism_stress.py is the long form; round 4 found one in fp_ws_kernel with it: DESIGN.md "Round 4")."""
+(tools/determinism_stress.py is the long form; round 4 found one in fp_ws_kernel with it: DESIGN.md 5, docs/HISTORY.md)."""
 import os
 import sys
 

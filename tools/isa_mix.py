@@ -3,7 +3,7 @@
     python tools/isa_mix.py encoder_u.hip [name-filter]
 
 Per kernel: MFMA, VALU (by opcode), LDS, VMEM and SALU instruction counts of the whole body (loops counted once) -- the
-quantity the dense kernels are bound by next to the matrix pipe (DESIGN.md "What a SIMD does with VALU work")."""
+quantity the dense kernels are bound by next to the matrix pipe."""
 import collections
 import os
 import re

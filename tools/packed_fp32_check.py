@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static check of the generated gfx950 code: a translation unit whose kernels issue matrix instructions (v_mfma_*) must not contain
 packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Round 4 found a v_pk_fma_f32 with cross operand selection losing
-its update in a gather wave that shares a SIMD with an MFMA wave ("packed fp32"); the library is therefore compiled with
+its update in a gather wave that shares a SIMD with an MFMA wave; the library is therefore compiled with
 -target-feature -packed-fp32-ops for those units (csrc/Makefile: NOPK) and this check keeps it that way.
 
     python tools/packed_fp32_check.py /tmp/lsdm_asm_check/*-gfx950.s        (make -C lsdm_amd/csrc check-packed)
