@@ -66,6 +66,7 @@ struct lsdm_ctx {
     int* fp2_plan = nullptr;     // fp2's tile plan (encoder_d.hip::fp_plan_kernel) of a single step, rewritten by every such step
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
+    int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
     int fp1_order = getenv("LSDM_FP1_ORDER") ? atoi(getenv("LSDM_FP1_ORDER")) : 1;   // A/B switch: fp1 + head walks the source points along that order
     int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
     int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
@@ -671,7 +672,8 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_exec(c, K_FP2, nc * (np == 2 && c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
     prof_mark(c, K_FP1, st);
-    if (np == 2 && c->fp1_reg) launch_fp_s(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
+    if (np == 2 && c->fp1_reg && c->fp1_pipe) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
+    else if (np == 2 && c->fp1_reg) launch_fp_s(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
     else launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
     prof_exec(c, K_FP1, nc * xm::FP1);
 }
@@ -855,8 +857,8 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         prof_exec(c, K_FP2, ncp * xm::FP2_PRE);
         prof_mark(c, K_FP1, st);
         // (fp1's fine level is the source cloud: walked along the Z curve sorted once per call, LSDM_FP1_ORDER=0: in index order)
-        launch_fp_s(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
-                    c->fp1_order ? c->inv_order + o * 1024 : nullptr, 0);
+        (c->fp1_pipe ? launch_fp_c : launch_fp_s)(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
+                                                  c->fp1_order ? c->inv_order + o * 1024 : nullptr, 0);
         prof_exec(c, K_FP1, ncp * xm::FP1);
     }
 }

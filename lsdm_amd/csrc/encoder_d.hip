@@ -27,6 +27,7 @@
 // A tile with more than CAP distinct rows keeps the first CAP (by coarse index) in LDS; the points of the others read them from global
 // memory in the accumulator initialisation (slot < 0: a rare, divergent path -- correctness does not depend on the cloud's geometry).
 #include <cstdlib>
+#include <type_traits>
 
 #include "bf16_core.hpp"
 #include "kernels.hpp"
@@ -56,10 +57,21 @@ extern "C" __attribute__((visibility("default"))) int lsdm_debug_fpd_phase(unsig
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fpd_phase), z, sizeof z) != hipSuccess) return -1;
     return 0;
 }
+__device__ unsigned long long g_fpc_phase[64 * 32];   // fp_c_kernel: 64 spread copies of 4 roles x 8 slots (slot 7 = iterations)
+#define FC_FLUSH(role, iters) do { if (lane == 0 && (wave & 1) == 0) { unsigned long long* g_ = g_fpc_phase + (blockIdx.x & 63) * 32 + (role) * 8; \
+        for (int i_ = 0; i_ < 6; ++i_) atomicAdd(g_ + i_, wd_[i_]); atomicAdd(g_ + 7, (unsigned long long)(iters)); } } while (0)
+extern "C" __attribute__((visibility("default"))) int lsdm_debug_fpc_phase(unsigned long long* out32, int reset) {
+    static unsigned long long h[64 * 32], z[64 * 32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fpc_phase), sizeof h) != hipSuccess) return -1;
+    for (int s = 0; s < 32; ++s) { out32[s] = 0; for (int c = 0; c < 64; ++c) out32[s] += h[c * 32 + s]; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fpc_phase), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
 #else
 #define FD_T0() do {} while (0)
 #define FD_MARK(slot) do {} while (0)
 #define FD_FLUSH(base, ntiles) do {} while (0)
+#define FC_FLUSH(role, iters) do {} while (0)
 #endif
 
 size_t fp_plan_ints(int N) { return (size_t)N * fpd::PT + (size_t)(N / fpd::TM) * fpd::HDR; }
@@ -490,6 +502,303 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
         if (t >= R.end) break;
     }
     FD_FLUSH(8, i);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp1 + head as a PIPELINE OF STAGES (round 5): fp_c_kernel.
+//
+// fp_s_kernel (encoder_reg.hip) carries 32 points per wave through the five layers in registers and streams every layer's 64 KB of weight
+// fragments through LDS: each 1 KB fragment read feeds two or three matrix instructions, so eight waves read 2 MB of fragments per round -- the
+// LDS port is ~90 % busy against the matrix time -- and one barrier per layer keeps all waves of a CU in the same phase (MFMA pipe 37 %).
+// Here the roles are swapped once more: the WEIGHTS stay in registers and the ACTIVATIONS move.  A persistent work-group of eight waves per CU;
+// wave 2 s + f owns channel blocks 2 f, 2 f + 1 of layer s (128 registers of hi + lo fragments, loaded once) for s = 0 .. 3 (the three fp1
+// layers and conv1); a 32-point tile moves from stage to stage through double-buffered LDS tiles (bf16 hi / lo planes, stored in the k-slot
+// order the next layer's fragments expect: one 16-byte piece per lane, k-step and plane), ONE barrier per tile, every stage working on a
+// different tile at the same time:
+//   iteration i:  gather (waves 0..5: six / four points each): rows of tile i (three 512-byte rows per point, two points per wave instruction,
+//                 requested at the top of the iteration), interp3 + split -> X0[i & 1] at its end;
+//                 stage s (waves 2 s, 2 s + 1): tile i - 1 - s from X_s[(i - 1) & 1] -> X_{s+1}[i & 1];
+//                 conv2 (128 -> 3, zero-padded block): its k-steps are the fragments conv1's two waves hold in registers -- wave 6 contracts
+//                 k-steps 0..3 of tile i - 4 and parks the accumulators in LDS, wave 7 continues with k-steps 4..7 an iteration later (the same
+//                 accumulation order as one wave doing all eight) and stores the tile's rows.
+// Same arithmetic in the same order as fp_s_kernel on the same fragment blob (api.hip::build_chain_blob): bit-identical.
+// The points of a cloud are walked along `order` (see fp_s_kernel); position -> point -> neighbour list -> rows is a chain of three dependent
+// loads, each link requested one iteration ahead of the next.
+namespace fpc {
+constexpr int TM = 32, C = 128, KS = C / 16, NB = C / 32, NP = 2, NL = 4;
+constexpr int ROWE = C + 8;              // bf16 elements per point and plane in an LDS tile (272 bytes: consecutive points start 4 banks apart)
+constexpr int PLANE = TM * ROWE;
+constexpr int FL = NB * KS * NP;         // 1 KiB fragments per layer in the blob
+}  // namespace fpc
+
+template <int N, int S>
+__global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx, const float* __restrict__ nn_w,
+                                                   const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out,
+                                                   const int* __restrict__ order, int order_mod, int total_tiles) {
+    using namespace fpc;
+    constexpr int TPC = N / TM;
+    __shared__ __attribute__((aligned(16))) __bf16 X[NL][2][NP * PLANE];          // X[s]: input tile of stage s
+    __shared__ __attribute__((aligned(16))) float part[2][64 * 16];               // conv2's accumulators between its two halves
+    __shared__ __attribute__((aligned(16))) float bl[NL * C + 32];
+    __shared__ __attribute__((aligned(16))) int nring[8][TM];                     // point numbers of the tiles in flight
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int p = lane & 31, h = lane >> 5;
+    for (int e = tid; e < NL * C + 32; e += 512) bl[e] = blob_b[e];
+    const XcdRounds R = xcd_rounds(total_tiles);
+    const int ntile = R.first < R.end ? (R.end - R.first + R.stride - 1) / R.stride : 0;       // tiles of this work-group: R.first + i * R.stride
+    const int stage = wave >> 1, half = wave & 1;
+
+    // ---- resident weights: channel blocks 2 half, 2 half + 1 of layer `stage`; waves 6 / 7 also conv2's k-steps 0..3 / 4..7
+    bf16x8 wh[2][KS], wl[2][KS];
+    {
+        const __bf16* wb = blob_w + (size_t)stage * FL * 512;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                wh[q][s] = gload<bf16x8>(wb + ((size_t)(((2 * half + q) * KS + s) * NP + 0) * 64 + lane) * 8);
+                wl[q][s] = gload<bf16x8>(wb + ((size_t)(((2 * half + q) * KS + s) * NP + 1) * 64 + lane) * 8);
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wh[q][s]), "+v"(wl[q][s]));
+    }
+    // one stage step: acc <- bias, eight k-steps against the input tile (two channel blocks as two interleaved chains), ReLU + split; the
+    // resulting fragments (k-steps 4 half .. 4 half + 3 of the next layer) go to `xout` or, for conv1, stay in yh / yl
+    auto stage_step = [&](const __bf16* xin, __bf16* xout, bf16x8 (&yh)[4], bf16x8 (&yl)[4], int pv, int hv) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + stage * C + 32 * (2 * half) + 8 * qq + 4 * hv);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + stage * C + 32 * (2 * half + 1) + 8 * qq + 4 * hv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[4 * qq + j] = b0[j]; a1[4 * qq + j] = b1[j]; }
+        }
+        const __bf16* xp = xin + pv * ROWE + 8 * hv;
+        bf16x8 xh = *reinterpret_cast<const bf16x8*>(xp), xl = *reinterpret_cast<const bf16x8*>(xp + PLANE);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 ch = xh, cl = xl;
+            if (s + 1 < KS) { xh = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 1)); xl = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 1) + PLANE); }
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][s], cl, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][s], cl, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[0][s], ch, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[1][s], ch, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][s], ch, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][s], ch, a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = reluf(q == 0 ? a0[8 * s2 + j] : a1[8 * s2 + j]);
+                split8_h<NP>(v, yh[2 * q + s2], yl[2 * q + s2]);
+                if (xout) {      // k-step 2 (2 half + q) + s2 of the next layer, this lane's 8 k-slots: one 16-byte piece per plane
+                    __bf16* d = xout + pv * ROWE + 16 * (2 * (2 * half + q) + s2) + 8 * hv;
+                    *reinterpret_cast<bf16x8*>(d) = yh[2 * q + s2];
+                    *reinterpret_cast<bf16x8*>(d + PLANE) = yl[2 * q + s2];
+                }
+            }
+    };
+
+    if (wave < 6) {
+        // ================= waves 0..5: gather + their stage =================
+        // The rows are dealt over SIX waves -- waves 0..3 three pairs of points each, waves 4, 5 two.  The two waves of a SIMD (w and w + 4) run
+        // their phases in OPPOSITE order so that one issues its matrix instructions while the other issues memory instructions:
+        //   waves 0..3 ("early"): requests of tile i -> stage step -> interpolation of tile i
+        //   waves 4, 5 ("late") : stage step -> interpolation of tile i (rows requested an iteration ago) -> requests of tile i + 1
+        // (waves 6, 7 have no gather and start with their stage step as well).  With all gathering waves requesting first, both waves of SIMD 0 / 1
+        // sat in their memory phase together and then contended for the matrix pipe: 2.8 us per iteration, tools/fpc_phase.py.
+      auto gather_role = [&](auto npair_c, auto late_c) {        // (compile-time pair count and phase order: the row registers are sized by it)
+        constexpr bool late = decltype(late_c)::value;
+        constexpr int npair = decltype(npair_c)::value;           // pairs of points this wave gathers
+        const int gp0 = wave < 4 ? 6 * wave : 24 + 4 * (wave - 4);  // its first point of the tile
+        const int gl = lane & 7;                                  // lanes 0 .. 2 npair - 1 of the wave hold the plan words of its points
+        auto point_load = [&](int g) -> int {                     // point number of the lane's point of tile g
+            const int t = R.first + g * R.stride, c = t / TPC, k = (t % TPC) * TM + gp0 + (gl < 2 * npair ? gl : 0);
+            return order ? order[(size_t)(order_mod > 0 ? c % order_mod : c) * N + k] : k;
+        };
+        auto list_load = [&](int g, int n, int (&ix)[3], float (&w)[3]) {
+            const int t = R.first + g * R.stride;
+            const size_t o = ((size_t)(t / TPC) * N + n) * 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { ix[j] = nn_idx[o + j]; w[j] = nn_w[o + j]; }
+        };
+        // plan words: (nq, ixq, wq) of the tile to be requested next, nq1 / (ixq1, wq1) one / one tile further; (ni, wi) of the tile whose rows are
+        // in the registers
+        int nq = 0, nq1 = 0, nq2 = 0, ni = 0;
+        int ixq[3] = {0, 0, 0}, ixq1[3] = {0, 0, 0};
+        float wq[3] = {0.0f, 0.0f, 0.0f}, wq1[3] = {0.0f, 0.0f, 0.0f}, wi[3] = {0.0f, 0.0f, 0.0f};
+        f32x4 ra[npair], rb[npair], rd[npair];
+        auto request = [&](int g, int pv, int hv) {               // rows of tile g (its list in ixq / wq); then the plan words shift by one tile
+            const int t = R.first + g * R.stride;
+            const float* pb = points2 + (size_t)(t / TPC) * S * C + 4 * pv;
+#if defined(LSDM_X_FPC) && (LSDM_X_FPC & 1)      // (timing experiment: no row loads after the first tile; results are wrong)
+            if (g == 0)
+#endif
+#pragma unroll
+            for (int q = 0; q < npair; ++q) {
+#if defined(LSDM_X_FPC) && (LSDM_X_FPC & 4)      // (timing experiment: row numbers without the cross-lane shuffles; results are wrong)
+                const int src = 2 * q + hv;
+                ra[q] = load4f(pb + (size_t)((ixq[0] + src) & 1023) * C);
+                rb[q] = load4f(pb + (size_t)((ixq[1] + src) & 1023) * C);
+                rd[q] = load4f(pb + (size_t)((ixq[2] + src) & 1023) * C);
+#else
+                const int src = 2 * q + hv;
+                ra[q] = load4f(pb + (size_t)__shfl(ixq[0], src) * C);
+                rb[q] = load4f(pb + (size_t)__shfl(ixq[1], src) * C);
+                rd[q] = load4f(pb + (size_t)__shfl(ixq[2], src) * C);
+#endif
+            }
+            ni = nq;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wi[j] = wq[j];
+#if defined(LSDM_X_FPC) && (LSDM_X_FPC & 2)      // (timing experiment: no plan-word loads; results are wrong)
+            if (g == 0)
+#endif
+            {
+            if (g + 1 < ntile) list_load(g + 1, nq1, ixq1, wq1);
+            if (g + 2 < ntile) nq2 = point_load(g + 2);
+            }
+        };
+        auto shift = [&]() {                                      // (after the loads of request() have been waited for: next iteration's top)
+            nq = nq1; nq1 = nq2;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { ixq[j] = ixq1[j]; wq[j] = wq1[j]; }
+        };
+        auto interp = [&](int i, int pv, int hv) {                // rows in the registers = tile i -> X0[i & 1]
+#pragma unroll
+            for (int q = 0; q < npair; ++q) {
+                const int src = 2 * q + hv;
+                const float u0 = __shfl(wi[0], src), u1 = __shfl(wi[1], src), u2 = __shfl(wi[2], src);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = interp3(ra[q][j], rb[q][j], rd[q][j], u0, u1, u2);
+                store_split4<NP>(&X[0][i & 1][0] + (gp0 + src) * ROWE + 4 * pv, PLANE, v[0], v[1], v[2], v[3]);
+            }
+            if (lane < 2 * npair) nring[i & 7][gp0 + lane] = ni;
+        };
+        if (ntile > 0) { nq = point_load(0); list_load(0, nq, ixq, wq); }
+        if (ntile > 1) nq1 = point_load(1);
+        if (late && ntile > 0) { request(0, p, h); shift(); }     // (late waves enter the loop with tile 0's rows in flight)
+        __syncthreads();
+        bf16x8 yh[4], yl[4];
+        FD_T0();
+#pragma unroll 1
+        for (int i = 0; i < ntile + 6; ++i) {
+            int pv = p, hv = h;
+            asm volatile("" : "+v"(pv), "+v"(hv));
+            const int ti = i - 1 - stage;
+            if (!late) {
+                asm volatile("" :: "v"(nq), "v"(nq1), "v"(ixq[0]), "v"(ixq[1]), "v"(ixq[2]), "v"(wq[0]), "v"(wq[1]), "v"(wq[2]));   // (carried plan words: waited for here)
+                if (i < ntile) request(i, pv, hv);
+                FD_MARK(0);
+                if (ti >= 0 && ti < ntile) stage_step(&X[stage][(i - 1) & 1][0], &X[stage + 1][i & 1][0], yh, yl, pv, hv);
+                FD_MARK(1);
+                if (i < ntile) { interp(i, pv, hv); shift(); }
+                FD_MARK(2);
+            } else {
+                if (ti >= 0 && ti < ntile) stage_step(&X[stage][(i - 1) & 1][0], &X[stage + 1][i & 1][0], yh, yl, pv, hv);
+                FD_MARK(1);
+                if (i < ntile) interp(i, pv, hv);
+                FD_MARK(2);
+                if (i + 1 < ntile) { request(i + 1, pv, hv); shift(); }
+                FD_MARK(0);
+            }
+            wg_sync();
+            FD_MARK(3);
+        }
+        FC_FLUSH(stage, ntile + 6);
+      };
+        if (wave < 4) gather_role(std::integral_constant<int, 3>{}, std::false_type{});
+        else gather_role(std::integral_constant<int, 2>{}, std::true_type{});
+        return;
+    }
+    // ================= waves 6, 7: conv1 on tile i - 4 + conv2 (k-steps 4 half .. 4 half + 3 from the fragments in registers) =================
+    bf16x8 w5h[4], w5l[4];
+    {
+        const __bf16* w5g = blob_w + (size_t)NL * FL * 512;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            w5h[s] = gload<bf16x8>(w5g + ((size_t)((4 * half + s) * NP + 0) * 64 + lane) * 8);
+            w5l[s] = gload<bf16x8>(w5g + ((size_t)((4 * half + s) * NP + 1) * 64 + lane) * 8);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(w5h[s]), "+v"(w5l[s]));
+    }
+    const float bv = blob_b[NL * C + (p < 3 ? p : 0)];
+    __syncthreads();
+    bf16x8 yh[4] = {}, yl[4] = {};
+    FD_T0();
+#pragma unroll 1
+    for (int i = 0; i < ntile + 6; ++i) {
+        int pv = p, hv = h, lv = lane;
+        asm volatile("" : "+v"(pv), "+v"(hv), "+v"(lv));
+        if (half == 1) {
+            // conv2, second half, of tile i - 5: accumulators from wave 6 (parked an iteration ago), k-steps 4..7 = the fragments this wave formed
+            // an iteration ago, then the tile's rows
+            const int tj = i - 5;
+            if (tj >= 0 && tj < ntile) {
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&part[(i - 1) & 1][(size_t)lv * 16 + 4 * g]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 * g + j] = v[j];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], w5h[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5l[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5h[s], acc, 0, 0, 0);
+                }
+                const int t = R.first + tj * R.stride;
+                float* ob = out + (size_t)(t / TPC) * N * 3 + pv;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int4 nl = *reinterpret_cast<const int4*>(&nring[tj & 7][8 * g + 4 * hv]);      // accumulator 4 g + j <-> point 8 g + 4 h + j of the tile
+                    if (pv < 3) {
+                        ob[(size_t)nl.x * 3] = acc[4 * g + 0] + bv;
+                        ob[(size_t)nl.y * 3] = acc[4 * g + 1] + bv;
+                        ob[(size_t)nl.z * 3] = acc[4 * g + 2] + bv;
+                        ob[(size_t)nl.w * 3] = acc[4 * g + 3] + bv;
+                    }
+                }
+            }
+        }
+        const int ti = i - 4;
+        if (ti >= 0 && ti < ntile) {
+            stage_step(&X[3][(i - 1) & 1][0], nullptr, yh, yl, pv, hv);
+            if (half == 0) {
+                // conv2, first half: k-steps 0..3, direct orientation D[point][channel]
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], w5h[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5l[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5h[s], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(&part[i & 1][(size_t)lv * 16 + 4 * g]) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            }
+        }
+        FD_MARK(1);
+        wg_sync();
+        FD_MARK(3);
+    }
+    FC_FLUSH(3, ntile + 6);
+}
+
+void launch_fp_c(int nc, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st,
+                 const int* order, int order_mod) {
+    const int total = 1024 / fpc::TM * nc;
+    hipLaunchKernelGGL((fp_c_kernel<1024, 1024>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points2, nn_idx, nn_w, blob_w, blob_b, out, order, order_mod, total);
 }
 
 void launch_morton_order(int nc, const float* xyz, int* order, hipStream_t st) {

@@ -508,6 +508,24 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
 // (Round 3: the epilogue of panel Q - 1 software-pipelined against panel Q's 96 matrix instructions on a second accumulator set, as in
 // sa_p_kernel, measured no change -- 353 vs 353-355 us: at one wave per SIMD this kernel waits for its 64 KB weight panels, not for
 // its epilogues; skipping the panel copies gives 317 us.)
+#ifdef LSDM_PHASE_TIMING
+__device__ unsigned long long g_saw_phase[64 * 8];   // 64 spread copies: 0 prologue, 1 layer-2 k loops, 2 layer-2 epilogues, 3 layer-3 k loops, 4 max + store, 5 panel wait + barrier, 7 rounds
+#define SAW_T0() unsigned long long st_ = __builtin_amdgcn_s_memtime(); unsigned long long sd_[6] = {}
+#define SAW_MARK(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sd_[slot] += n_ - st_; st_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SAW_FLUSH(nr) do { if (lane == 0 && wave == 0) { unsigned long long* g_ = g_saw_phase + (blockIdx.x & 63) * 8; \
+        for (int i_ = 0; i_ < 6; ++i_) atomicAdd(g_ + i_, sd_[i_]); atomicAdd(g_ + 7, (unsigned long long)(nr)); } } while (0)
+extern "C" __attribute__((visibility("default"))) int lsdm_debug_saw_phase(unsigned long long* out8, int reset) {
+    static unsigned long long h[64 * 8], z[64 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_saw_phase), sizeof h) != hipSuccess) return -1;
+    for (int s = 0; s < 8; ++s) { out8[s] = 0; for (int c = 0; c < 64; ++c) out8[s] += h[c * 8 + s]; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_saw_phase), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#else
+#define SAW_T0() do {} while (0)
+#define SAW_MARK(slot) do {} while (0)
+#define SAW_FLUSH(nr) do {} while (0)
+#endif
 template <int NP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
@@ -574,6 +592,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ci_n = cent_idx[ce];
         request_u(ce / S);
     }
+    SAW_T0();
+    [[maybe_unused]] int nrounds = 0;
     for (long long rd = rbeg; rd < rend; rd += rstep) {
         const long long cent = rd * NW + wave;
         bf16x8 xh[KS], xl[KS], zh[KS], zl[KS];
@@ -597,8 +617,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if (rd + rstep < rend) { const long long ce = (rd + rstep) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
         }
+        SAW_MARK(0);
 #define SAW_BEGIN(Q) { if (!(dbg & 1) && !SPREAD) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
-#define SAW_END(Q) lds_dma_wait(); if (!(dbg & 2)) __syncthreads(); }
+#define SAW_END(Q) lds_dma_wait(); if (!(dbg & 2)) __syncthreads(); SAW_MARK(5); }
         // ---- layer 2 (transposed): two channel blocks per panel as two interleaved accumulator chains
 #pragma unroll
         for (int q = 0; q < NB2 / PB; ++q) {
@@ -638,6 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xh[s], a1, 0, 0, 0);
                 if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
+            SAW_MARK(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float v[8], w[8];
@@ -646,6 +668,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 split8u<NP>(v, zh[4 * q + s2], zl[4 * q + s2]);
                 split8u<NP>(w, zh[4 * q + 2 + s2], zl[4 * q + 2 + s2]);
             }
+            SAW_MARK(2);
             SAW_END(q)
         }
         // ---- layer 3 (direct orientation): max over the 32 rows
@@ -682,6 +705,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w1h, a1, 0, 0, 0);
                 if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
+            SAW_MARK(3);
             float m0 = a0[0], m1 = a1[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, a0[r]); m1 = fmaxf(m1, a1[r]); }
@@ -691,11 +715,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 out[(size_t)cent * C3 + (2 * q) * 32 + lane] = reluf(m0 + bl[lz + C2 + (2 * q) * 32 + lane]);
                 out[(size_t)cent * C3 + (2 * q + 1) * 32 + lane] = reluf(m1 + bl[lz + C2 + (2 * q + 1) * 32 + lane]);
             }
+            SAW_MARK(4);
             SAW_END(NB2 / PB + q)
         }
 #undef SAW_BEGIN
 #undef SAW_END
+#ifdef LSDM_PHASE_TIMING
+        ++nrounds;
+#endif
     }
+    SAW_FLUSH(nrounds);
 }
 
 // ---------------------------------------------------------------------------------------------

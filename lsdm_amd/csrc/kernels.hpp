@@ -108,6 +108,9 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
 // order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
 void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b,
                  float* out, hipStream_t st, const int* order = nullptr, int order_mod = 0);
+// encoder_d.hip: the same stack as a pipeline of stages with register-resident weights (fp_c_kernel; same blob, same results)
+void launch_fp_c(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
+                 hipStream_t st, const int* order = nullptr, int order_mod = 0);
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
 // point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
 // ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
