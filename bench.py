@@ -55,7 +55,8 @@ STAGE_KERNELS_BF16X3 = {
     "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
     "fp_kernel<fp2>": "fp_d_kernel<1024,256,64,256,128> (two-stage persistent kernel over Morton-ordered 32-point tiles, each distinct Y row landed once by "
                       "LDS-DMA) + its tile plans (fp_plan_kernel: one launch per group of steps in the loop-invariant schedule, its time inside this stage)",
-    "fp_kernel<fp1+head>": "fp_s_kernel<8,2>",
+    "fp_kernel<fp1+head>": "fp_c_kernel<1024,1024> (the five layers as a pipeline of stages on different waves, weights register-resident, the points walked along "
+                           "the source cloud's Z curve)",
     "denoise_kernel": "denoise_r_kernel (one launch per group of steps and the guiding-point pass on the call's last forward only in the "
                       "loop-invariant schedule)",
 }
@@ -598,7 +599,7 @@ def main():
         # assumes 26) -- it is no longer a fill-path kernel and is listed for the comparison with round 4's 2.56 GB per launch only.
         fill_mb_per_cloud = {"fp_kernel<fp2>": 32 * 26 * 1024 / 1e6 + 1024 * 256 / 1e6,                       # distinct Y rows per tile (estimate) + p1 rows
                              "sa_kernel<256,256,256,512>": 16 * 32 * 1024 / 1e6 + 4 * 786432 / 1e6,         # U rows, twelve 64 KB panels per four centroids
-                             "fp_kernel<fp1+head>": 1024 * 3 * 512 / 1e6 + 4 * 262144 / 1e6,                # rows, four 64 KB panels per 256 points
+                             "fp_kernel<fp1+head>": 1024 * 3 * 512 / 1e6,                                   # rows (fp_c_kernel: the weights are register-resident)
                              "sa_kernel<128,128,128,256>": 64 * 32 * 512 / 1e6 + (64 / 12.0) * 131072 / 1e6}   # U rows, layer-3 panels per twelve centroids
         by_name = {q["name"]: q for q in rows}
         res["fill_path"] = {"unit": "TB/s", "ceiling_l2_resident_4_waves_per_cu": 25.0, "ceiling_infinity_cache": 8.7,

@@ -506,8 +506,10 @@ def test_chain_on_a_caller_stream_with_work_queued_behind_it():
 _SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "2"}, {"LSDM_SA_REG": "0"}, {"LSDM_SA_REG": "2", "LSDM_SA_SPLIT": "0"},
              {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
              {"LSDM_GROUP": "3"}, {"LSDM_BATCH_ENC": "0"}, {"LSDM_BATCH_DEN": "0"}, {"LSDM_STREAMS": "1"}, {"LSDM_INV_SIDE": "0"}, {"LSDM_SA2_MEMO": "0"},
-             {"LSDM_FP2_WS": "0"}, {"LSDM_FP2_WS": "1"}, {"LSDM_FP2_WS": "2"}, {"LSDM_FP2_WS": "3"}]
-_SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN", "LSDM_STREAMS", "LSDM_INV_SIDE", "LSDM_SA2_MEMO", "LSDM_FP2_WS")      # launch shapes only: bit-identical results
+             {"LSDM_FP2_WS": "0"}, {"LSDM_FP2_WS": "1"}, {"LSDM_FP2_WS": "2"}, {"LSDM_FP2_WS": "3"}, {"LSDM_FP1_PIPE": "0"}, {"LSDM_FP1_ORDER": "0"},
+             {"LSDM_FP1_PIPE": "0", "LSDM_FP1_ORDER": "0"}]
+_SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN", "LSDM_STREAMS", "LSDM_INV_SIDE", "LSDM_SA2_MEMO", "LSDM_FP2_WS", "LSDM_FP1_PIPE",
+                    "LSDM_FP1_ORDER")      # launch shapes / kernel forms with the same arithmetic in the same order: bit-identical results
 
 
 @pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))

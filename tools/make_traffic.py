@@ -22,7 +22,7 @@ STAGES = {
     "fp_kernel<fp4>": ["lin_u_kernel<512, 256, false>", "fp_pre_kernel<256, 256, 256", "fp_h_kernel<256, 512"],
     "fp_kernel<fp3>": ["fp_pre_kernel<128, 256, 256", "fp_h_kernel<128, 256"],
     "fp_kernel<fp2>": ["fp_d_kernel", "fp_ws_kernel", "fp_rw_kernel", "fp_pre_kernel<64, 256, 128", "fp_ps_kernel", "fp_h_kernel<64, 256"],
-    "fp_kernel<fp1+head>": ["fp_s_kernel", "fp_h_kernel<0, 128"],
+    "fp_kernel<fp1+head>": ["fp_c_kernel", "fp_s_kernel", "fp_h_kernel<0, 128"],
     "fps_chain_kernel": ["fps_chain"],
     "denoise_kernel": ["denoise_r_kernel", "denoise_h_kernel", "denoise_kernel"],
     "upsample12_kernel": ["upsample12"],
