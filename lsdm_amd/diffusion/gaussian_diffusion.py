@@ -341,22 +341,26 @@ class GaussianDiffusion:
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
-        for i in indices:
-            t = th.tensor([i] * shape[0], device=device)
-            with th.no_grad():
-                img = img.contiguous()
-                if _step == "ddim":
-                    out = self.ddim_sample(model, img, mask, t, given_objs, given_cats, y, clip_denoised=clip_denoised,
-                                           denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, eta=_eta)
-                else:
-                    out = self.p_sample(model, img, mask, t, given_objs, given_cats, y, clip_denoised=clip_denoised,
-                                        denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
-                                        const_noise=const_noise)
-                yield out
-                img = out["sample"]
         inner = _unwrap(model)
-        if hasattr(inner, "check_timesteps"):
-            inner.check_timesteps()          # the deferred range checks of the loop's device-resident timesteps (model/sdm.py::_run)
+        try:
+            for i in indices:
+                t = th.tensor([i] * shape[0], device=device)
+                with th.no_grad():
+                    img = img.contiguous()
+                    if _step == "ddim":
+                        out = self.ddim_sample(model, img, mask, t, given_objs, given_cats, y, clip_denoised=clip_denoised,
+                                               denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, eta=_eta)
+                    else:
+                        out = self.p_sample(model, img, mask, t, given_objs, given_cats, y, clip_denoised=clip_denoised,
+                                            denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
+                                            const_noise=const_noise)
+                    yield out
+                    img = out["sample"]
+        finally:
+            # the deferred range checks of the loop's device-resident timesteps (model/sdm.py::_run) are resolved when the generator ends --
+            # also when the caller abandons it early (break / close): an out-of-range index must not go unreported
+            if hasattr(inner, "check_timesteps"):
+                inner.check_timesteps()
 
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,

@@ -303,7 +303,11 @@ class SceneDiffusionModel(nn.Module):
         return out_x0
 
     def forward(self, x, mask, timesteps, given_objs, given_cats, y=None, force_mask=False, *, fps_starts=None):
-        """x (B,1024,3) is mutated in place (x += guidance, model/sdm.py:204).  Returns (out_cat, x_out)."""
+        """x (B,1024,3) is mutated in place (x += guidance, model/sdm.py:204).  Returns (out_cat, x_out).
+        ``timesteps`` on the HOST are range-checked here ([0, 5000): the positional table).  DEVICE-resident timesteps are not read back (that
+        would stall the stream every step): the kernels see the index clamped into the table, the verdict travels to the host asynchronously and
+        an out-of-range index raises ValueError from the NEXT call or from ``check_timesteps()`` (which the sampling loops call when they end,
+        also when abandoned early) -- late, never silently.  ``LSDM_CHECK_TIMESTEPS=1`` checks synchronously."""
         out_cat, out_x0, _ = self._run(_lib.MODE_FORWARD, 0.0, x, mask, timesteps, given_objs, given_cats, y, fps_starts)
         return out_cat, out_x0
 
