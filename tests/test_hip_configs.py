@@ -547,6 +547,53 @@ def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
             assert torch.equal(a, b), env
 
 
+def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
+    """fp2's planned kernel (fp_d_kernel: Morton-ordered tiles, rows deduplicated through LDS) and fp1's stage pipeline (fp_c_kernel) against the
+    tile-per-work-group / register-chained forms they replaced, bit for bit, on the clouds that leave their fast paths: all-zero and single-point
+    clouds (the level-1 order is not a permutation: the plan walks them in index order), a two-point cloud, a cloud scattered over 100 m (no two
+    points of a tile share a coarse neighbour: up to 96 distinct rows per tile, beyond the 36 LDS slots -- the rows without a slot are read from
+    global memory), a line, and ordinary clouds beside them."""
+    nc = 9
+    g = torch.Generator().manual_seed(77)
+    clouds = torch.zeros(nc, 1024, 3)
+    clouds[0] = make_synthetic_batch(1, seed=61)["given_objs"][0, 1]
+    # clouds[1]: zeros (a padded slot)
+    clouds[2] = torch.tensor([0.3, -1.2, 0.7]).expand(1024, 3)
+    clouds[3, ::2] = torch.tensor([0.0, 0.0, 0.0]); clouds[3, 1::2] = torch.tensor([0.05, 0.0, 0.1])
+    clouds[4] = (torch.rand(1024, 3, generator=g) - 0.5) * 100.0
+    clouds[5, :, 0] = torch.linspace(-1.0, 1.0, 1024)
+    clouds[6] = make_synthetic_batch(1, seed=62)["given_objs"][0, 0]
+    clouds[7] = torch.randn(1024, 3, generator=g) * 0.02
+    clouds[8] = (torch.rand(1024, 3, generator=g) - 0.5) * 6.0
+    clouds = clouds.to(DEV).contiguous()
+    torch.manual_seed(5)
+    starts = torch.stack([torch.randint(0, n, (nc,)) for n in (1024, 1024, 256, 64)]).to(DEV)
+    sd = make_synthetic_state_dict(seed=0)
+    outs = {}
+    keep = {k: os.environ.get(k) for k in ("LSDM_FP2_WS", "LSDM_FP1_PIPE")}
+    try:
+        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_FP1_PIPE": "1"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_FP1_PIPE": "0"})):
+            os.environ.update(env)
+            m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
+            m.load_state_dict(sd)
+            ctx = m._context()
+            m._reserve(1)
+            out = torch.empty(nc, 1024, 3, device=DEV)
+            ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), nc, out.data_ptr(), None)
+            torch.cuda.synchronize()
+            outs[name] = (out.clone(), ws(m, "fp2", (nc, 1024, 128)).clone())
+            del m, ctx
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert bool(torch.isfinite(outs["new"][0]).all())
+    assert torch.equal(outs["new"][1], outs["old"][1]), "fp2 output differs between fp_d_kernel and fp_pre_kernel"
+    assert torch.equal(outs["new"][0], outs["old"][0]), "encoder output differs between the new and the old kernel forms"
+
+
 # ======================================================================================= clip_dim = 768 (BERT pooler width)
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_forward_with_768_wide_text_features_vs_reference_golden(golden, precision):
