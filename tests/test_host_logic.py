@@ -257,7 +257,7 @@ def test_metrics_known_answers():
     assert [float(v) for v in accuracy(out, torch.tensor([2, 0]), topk=(1, 3))] == [50.0, 100.0]
 
 
-def test_generated_code_has_no_barrier_without_the_lds_wait(tmp_path):
+def test_generated_code_has_no_barrier_without_the_lds_wait_and_no_packed_fp32_next_to_mfma(tmp_path):
     """hipcc (ROCm 7.2, gfx950) emitted a loop-header s_barrier WITHOUT `s_waitcnt lgkmcnt(0)` after the loop latch's LDS stores in round 4
     (fp_ws_kernel: another wave read the tile before the stores had landed; common.hpp::wg_sync now waits explicitly).
     tools/barrier_wait_check.py walks the control-flow graph of every compiled kernel backwards from each barrier; the negative control
@@ -278,3 +278,15 @@ def test_generated_code_has_no_barrier_without_the_lds_wait(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "barrier_wait_check.py")] + [str(p) for p in bare.glob("*-gfx950.s")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "fp_ws_kernel" in r.stdout, r.stdout[-2000:]
+    # The same generated code holds NO packed fp32 arithmetic in any translation unit that issues matrix instructions (round 4's lost updates
+    # came from v_pk_fma_f32 with operand selection in a wave sharing its SIMD with an MFMA wave; the Makefile removes the instruction class
+    # with -packed-fp32-ops).  Negative control: a unit compiled WITHOUT the flag mixes the two and must be flagged.
+    r = subprocess.run(["make", "-C", csrc, "check-packed", "ASMDIR=%s" % (tmp_path / "asm")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "0 unit(s) mix" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    pk = tmp_path / "pk"
+    pk.mkdir()
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-inline-asm",
+                    "--save-temps=obj", "-c", os.path.join(csrc, "denoise_reg.hip"), "-o", str(pk / "denoise_reg.o")], capture_output=True, timeout=900, check=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "packed_fp32_check.py")] + [str(p) for p in pk.glob("*-gfx950.s")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "denoise_r_kernel" in r.stdout, r.stdout[-2000:]
