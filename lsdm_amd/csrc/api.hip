@@ -67,6 +67,7 @@ struct lsdm_ctx {
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
     int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
+    int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = sa3 / sa4 give every ball-query group a 32-row block of its own
     int fp1_order = getenv("LSDM_FP1_ORDER") ? atoi(getenv("LSDM_FP1_ORDER")) : 1;   // A/B switch: fp1 + head walks the source points along that order
     int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
     int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
@@ -167,6 +168,9 @@ struct lsdm_ctx {
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr;
                      struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3];
                      int* plan = nullptr;     // fp2's tile plans of every step of a group (one fp_plan_kernel launch per group)
+                     // item lists of sa3 [0] / sa4 [1] of every step of a group (geometry.hip: sa_pair_*_kernel): U rows, {V rows, output rows},
+                     // items per step, small groups per chunk (scratch)
+                     int *pair_rows[2] = {}, *pair_cnt[2] = {}, *pair_chunk[2] = {}; int4* pair_meta[2] = {};
                      // memo of sa2 (geometry.hip: memo_src_kernel): r = 0.2 balls of the source points, flags, F2 rows, work lists, counters
                      int *memo_ball2 = nullptr, *memo_src_list = nullptr, *memo_list = nullptr, *memo_cnt = nullptr, *memo_ident = nullptr;
                      unsigned char *memo_unc = nullptr, *memo_crowd = nullptr; float* memo_F2 = nullptr;
@@ -267,6 +271,7 @@ void prof_exec_dev(lsdm_ctx* c, int id, const int* counter, double macs_per_coun
 namespace xm {     // per cloud (encoder) / per chain or row (others), split-bf16 kernels in their default configuration
 constexpr double SA1 = 32768.0 * (16 * 32 + 32 * 32 + 32 * 64);
 constexpr double SA2_UV = 1024.0 * 64 * 64, SA2_CENT = 32.0 * (64 * 64 + 64 * 128), SA2_FULL = 8192.0 * (80 * 64 + 64 * 64 + 64 * 128);
+constexpr double SA3_UV = 256.0 * 128 * 128, SA3_ITEM = 32.0 * (128 * 128 + 128 * 256), SA4_UV = 64.0 * 256 * 256, SA4_ITEM = 32.0 * (256 * 256 + 256 * 512);
 constexpr double SA3 = 256.0 * 128 * 128 + 2048.0 * (128 * 128 + 128 * 256), SA3_FULL = 2048.0 * (144 * 128 + 128 * 128 + 128 * 256);
 constexpr double SA4 = 64.0 * 256 * 256 + 512.0 * (256 * 256 + 256 * 512), SA4_FULL = 512.0 * (272 * 256 + 256 * 256 + 256 * 512);
 constexpr double FP4_PRE = 16.0 * 512 * 256 + 64.0 * 3 * 256 * 256, FP4_Y = 64.0 * (768 * 256 + 2 * 256 * 256), FP4_FULL = 64.0 * (768 * 256 + 256 * 256);
@@ -696,6 +701,7 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
     lsdm_ctx::GroupWs& g = c->gws;
     if (g.cap_B >= B) {
         if (g.memo_cnt) c->ws_named["memo_cnt"] = {g.memo_cnt, 2};     // (lsdm_reserve clears the names; the group workspace outlives it)
+        if (g.pair_cnt[0]) { c->ws_named["sa3_items"] = {g.pair_cnt[0], lsdm_ctx::kGroup}; c->ws_named["sa4_items"] = {g.pair_cnt[1], lsdm_ctx::kGroup}; }
         return true;
     }
     for (void* p : g.allocs) (void)hipFree(p);
@@ -714,6 +720,13 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
     for (int l = 1; l < 4 && ok; ++l) ok = (g.feat[l] = al(nc * kS[l] * kFeatC[l])) != nullptr;
     ok = ok && (g.ybuf[0] = al(nc * 64 * 256)) && (g.ybuf[2] = al(nc * 16 * 256));
     ok = ok && (g.pcd = al(nc * kN * 3)) && (g.o12 = al(nc * 12)) && (g.plan = reinterpret_cast<int*>(al(nc * fp_plan_ints(1024))));
+    if (ok && c->sa_pair) {
+        for (int l = 0; l < 2 && ok; ++l) {
+            const size_t S = l ? 16 : 64, T1 = (size_t)B * kO * S;
+            ok = (g.pair_rows[l] = reinterpret_cast<int*>(al(nc * S * 32))) && (g.pair_meta[l] = reinterpret_cast<int4*>(al(nc * S * 4))) &&
+                 (g.pair_cnt[l] = reinterpret_cast<int*>(al(G))) && (g.pair_chunk[l] = reinterpret_cast<int*>(al(G * sa_pair_chunks((int)T1))));
+        }
+    }
     if (ok && c->streams > 1) {
         const size_t n1 = (size_t)B * kO;
         for (int k = 0; k < c->nside() && ok; ++k) {
@@ -744,6 +757,8 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
             ok = hipMemcpy(g.memo_ident, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
         }
     }
+    // (lsdm_workspace_tensor: the blocks each step of the call's last group ran in sa3 / sa4)
+    if (ok && c->sa_pair) { c->ws_named["sa3_items"] = {g.pair_cnt[0], lsdm_ctx::kGroup}; c->ws_named["sa4_items"] = {g.pair_cnt[1], lsdm_ctx::kGroup}; }
     if (ok) g.cap_B = B;
     return ok;
 }
@@ -795,10 +810,18 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
         prof_mark(c, K_FP2, st, 0);      // (timed with the stage, not counted as launches of it: avg_ms stays per step)
         launch_fp_plan(nc, c->inv_order, nc1, f.idx[0], f.nn_idx[2], f.idx[0], g.plan, st);
     }
+    // sa3 / sa4's item lists of every step of the group: groups of at most 16 distinct neighbours two to a block
+    if (c->sa_pair) {
+        prof_mark(c, K_SA1 + 2, st, 0);
+        launch_sa_pair_plan(steps, nc1 * 64, 64, 256, f.ball[2], f.idx[2], g.pair_chunk[0], g.pair_rows[0], g.pair_meta[0], g.pair_cnt[0], st);
+        prof_mark(c, K_SA1 + 3, st, 0);
+        launch_sa_pair_plan(steps, nc1 * 16, 16, 64, f.ball[3], f.idx[3], g.pair_chunk[1], g.pair_rows[1], g.pair_meta[1], g.pair_cnt[1], st);
+    }
     // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were
     // measured: fp2 337 -> 323 us, but fp1 275 -> 295, fp3 165 -> 190, sa3 / sa4 slower as well -- the extra launch ramps and tails cost
     // more than the cache residency gains)
     constexpr int PS = 1;
+    static_assert(PS == 1, "the item lists of sa3 / sa4 cover whole steps");
     const int ncp = nc1;
     if (two) stream_fork(c, st0);
     for (int j = 0; j < steps; ++j) {
@@ -816,12 +839,26 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
             float* const f3 = g.feat[3] + ((size_t)j * nc1 + o) * 16 * 512;
             prof_mark(c, K_SA1 + 2, st);
             launch_lin_u(2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], U0, V0, st);
-            launch_sa_u(2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
-            prof_exec(c, K_SA1 + 2, ncp * xm::SA3);
+            if (c->sa_pair) {
+                const size_t t1 = (size_t)j * nc1 * 64;
+                launch_sa_u_items(2, U0, V0, g.pair_rows[0] + t1 * 32, g.pair_meta[0] + t1, g.pair_cnt[0] + j, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+                prof_exec(c, K_SA1 + 2, ncp * xm::SA3_UV);
+                prof_exec_dev(c, K_SA1 + 2, g.pair_cnt[0] + j, xm::SA3_ITEM, st);     // the blocks that ran
+            } else {
+                launch_sa_u(2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+                prof_exec(c, K_SA1 + 2, ncp * xm::SA3);
+            }
             prof_mark(c, K_SA1 + 3, st);
             launch_lin_u(3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], U1, V1, st);
-            launch_sa_u(3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
-            prof_exec(c, K_SA1 + 3, ncp * xm::SA4);
+            if (c->sa_pair) {
+                const size_t t1 = (size_t)j * nc1 * 16;
+                launch_sa_u_items(3, U1, V1, g.pair_rows[1] + t1 * 32, g.pair_meta[1] + t1, g.pair_cnt[1] + j, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+                prof_exec(c, K_SA1 + 3, ncp * xm::SA4_UV);
+                prof_exec_dev(c, K_SA1 + 3, g.pair_cnt[1] + j, xm::SA4_ITEM, st);
+            } else {
+                launch_sa_u(3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+                prof_exec(c, K_SA1 + 3, ncp * xm::SA4);
+            }
         }
     }
     st = st0;

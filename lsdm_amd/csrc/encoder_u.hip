@@ -160,6 +160,11 @@ __device__ __forceinline__ float max_halves(float m) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return fmaxf(a, b);
 }
+// two maxima at once: lanes 0-31 get max(a[l], a[l + 32]), lanes 32-63 get max(b[l - 32], b[l]) (one swap: afterwards a = [a.lo, b.lo], b = [a.hi, b.hi])
+__device__ __forceinline__ float max_halves2(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
 
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
@@ -181,11 +186,17 @@ __device__ __forceinline__ void sgb_block() {
     });
 }
 
-template <int C1, int C2, int C3, int NW, int NP>
+// PAIR (launch_sa_pair_plan, geometry.hip): the launch walks a list of ITEMS instead of the centroids.  A ball-query group is padded to 32 rows with
+// repeats of its first neighbour; the repeats change nothing under the max, so two groups of at most 16 distinct neighbours share ONE
+// 32-row block: rows 0-15 (accumulator registers 0-7 of both half-waves) belong to the first centroid, rows 16-31 (registers 8-15) to the
+// second, each half with its own V row, its own maximum and its own output row.  `ball` is then the item list's row table (32 U rows per
+// item, numbered over the launch), `pmeta` {V row of rows 0-15, of rows 16-31, output row of each} and *pcount the number of items.
+template <int C1, int C2, int C3, int NW, int NP, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                         const int* __restrict__ cent_idx, const int* __restrict__ ball, int NSRC, int S,
                                                         long long total_centroids, const __bf16* __restrict__ blob_w,
-                                                        const float* __restrict__ blob_b, float* __restrict__ out) {
+                                                        const float* __restrict__ blob_b, float* __restrict__ out,
+                                                        const int4* __restrict__ pmeta, const int* __restrict__ pcount) {
     static_assert(NP == 2, "bf16x3 only");
     constexpr int NT = NW * 64;
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
     lds_dma_wait();
     __syncthreads();
 
-    const int total = (int)total_centroids;
+    const int total = PAIR ? __builtin_amdgcn_readfirstlane(*pcount) : (int)total_centroids;
     const int rounds = (total + NW - 1) / NW;
     // (one contiguous chunk of rounds per work-group; the XCD-cooperative schedule of sa2 / fp1 was measured without effect here and
     // in sa_w: their HBM fetch already equals the unique input)
@@ -229,12 +240,21 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
     constexpr int rstep = 1;
     auto cent_of = [&](int rd) { const int ce = rd * NW + wave; return ce < total ? ce : total - 1; };
     int idx_n = 0, ci_n = 0;
-    if (rbeg < rend) { const int ce = cent_of(rbeg); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
+    int4 mt_n = {0, 0, 0, 0};
+    auto request_idx = [&](int ce) {
+        idx_n = ball[(size_t)ce * kNSample + p];
+        if constexpr (PAIR) mt_n = pmeta[ce];
+        else ci_n = cent_idx[ce];
+    };
+    if (rbeg < rend) request_idx(cent_of(rbeg));
     for (int rd = rbeg; rd < rend; rd += rstep) {
         const int cent = cent_of(rd);        // (a wave past the end repeats the last centroid: same values, same addresses)
         const int c = cent / S;
-        const float* urow = U + ((size_t)c * NSRC + idx_n) * C1 + 8 * h;
-        const float* vrow = V + ((size_t)c * NSRC + ci_n) * C1 + 8 * h;
+        const int4 mt = mt_n;
+        const bool paired = PAIR && mt.z != mt.w;
+        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z) : (size_t)cent;
+        const float* urow = U + (PAIR ? (size_t)idx_n : (size_t)c * NSRC + idx_n) * C1 + 8 * h;
+        const float* vrow = V + (PAIR ? (size_t)(p < 16 ? mt.x : mt.y) : (size_t)c * NSRC + ci_n) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
         {
             f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
                 u0[s] = load4f(urow + 16 * s); u1[s] = load4f(urow + 16 * s + 4);
                 v0[s] = load4f(vrow + 16 * s); v1[s] = load4f(vrow + 16 * s + 4);
             }
-            if (rd + rstep < rend) { const int ce = cent_of(rd + rstep); idx_n = ball[(size_t)ce * kNSample + p]; ci_n = cent_idx[ce]; }
+            if (rd + rstep < rend) request_idx(cent_of(rd + rstep));
 #pragma unroll
             for (int s = 0; s < KS2; ++s) {
                 const float t[8] = {reluf(u0[s][0] - v0[s][0]), reluf(u0[s][1] - v0[s][1]), reluf(u0[s][2] - v0[s][2]), reluf(u0[s][3] - v0[s][3]),
@@ -274,11 +294,22 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
         };
         // max over the 32 rows of block nb (ReLU(x + b) is monotone: pool first); both half-waves store the same values
         auto l3_epi = [&](int nb, const f32x16& a) {
-            float m = a[0];
+            float m;
+            if constexpr (PAIR) {
+                // rows 0-15 are registers 0-7 of both half-waves, rows 16-31 registers 8-15; half-wave 0 stores the first centroid's row,
+                // half-wave 1 the second's (an unpaired item: one maximum, the same row twice as below)
+                float ma = a[0], mb = a[8];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, a[r]);
-            m = max_halves(m);
-            out[(size_t)cent * C3 + nb * 32 + p] = reluf(m + bl[lz + C2 + nb * 32 + p]);
+                for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, a[r]); mb = fmaxf(mb, a[8 + r]); }
+                const float mab = fmaxf(ma, mb);
+                m = max_halves2(paired ? ma : mab, paired ? mb : mab);
+            } else {
+                m = a[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, a[r]);
+                m = max_halves(m);
+            }
+            out[orow * C3 + nb * 32 + p] = reluf(m + bl[lz + C2 + nb * 32 + p]);
         };
         // ---- layer 2 (resident fragments): one stream of NB2 x KS2 k-steps; block nb accumulates in acc[nb & 1] while the
         // epilogue of block nb - 1 reads the other accumulator
@@ -526,10 +557,12 @@ extern "C" __attribute__((visibility("default"))) int lsdm_debug_saw_phase(unsig
 #define SAW_MARK(slot) do {} while (0)
 #define SAW_FLUSH(nr) do {} while (0)
 #endif
-template <int NP>
+// PAIR: the launch walks the item list of sa_pair_plan (see sa_p_kernel): two groups of at most 16 distinct neighbours in one 32-row block.
+template <int NP, bool PAIR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
-    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out, int dbg) {
+    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out, int dbg,
+    const int4* __restrict__ pmeta, const int* __restrict__ pcount) {
     constexpr int C1 = 256, C2 = 256, C3 = 512, NSRC = 64, S = 16, NW = 4, NT = NW * 64;
     constexpr int KS = C1 / 16;
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32, PB = 2, NPANEL = (NB2 + NB3) / PB;
@@ -568,7 +601,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     lds_dma_wait();
     __syncthreads();
 
-    const long long rounds = total_centroids / NW;
+    const long long total = PAIR ? (long long)__builtin_amdgcn_readfirstlane(*pcount) : total_centroids;
+    const long long rounds = (total + NW - 1) / NW;      // (a wave past the end repeats the last item: same values, same addresses)
     const long long rchunk = (rounds + gridDim.x - 1) / gridDim.x;
     const long long rbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
     const long long rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
@@ -577,31 +611,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // lane) at the start of the previous round's layer 3, when x is dead -- with one wave per SIMD nothing else would hide that latency.
     // (The centroid's V row -- the same 1 KB for all 32 rows of the wave -- travels with them: one 16-byte piece per lane, parked in LDS at
     // the top of the round and read from there; fetched at the top of the round it cost two exposed L2 round trips per round.)
-    __shared__ __attribute__((aligned(16))) float vl[NW][C1];
+    constexpr int NV = PAIR ? 2 : 1;                 // V rows of a block: one per centroid in it
+    __shared__ __attribute__((aligned(16))) float vl[NW][NV][C1];
     int idx_n = 0, ci_n = 0;
-    f32x4 un0[KS], un1[KS], vn;
+    int4 mt_n = {0, 0, 0, 0};
+    f32x4 un0[KS], un1[KS], vn[NV];
+    auto item_of = [&](long long rd) { const long long ce = rd * NW + wave; return ce < total ? ce : total - 1; };
+    auto request_idx = [&](long long ce) {
+        idx_n = ball[ce * kNSample + p];
+        if constexpr (PAIR) mt_n = pmeta[ce];
+        else ci_n = cent_idx[ce];
+    };
     auto request_u = [&](long long cc) {
-        const float* urow = U + ((size_t)cc * NSRC + idx_n) * C1 + 8 * h;
+        const float* urow = U + (PAIR ? (size_t)idx_n : (size_t)cc * NSRC + idx_n) * C1 + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) { un0[s] = load4f(urow + 16 * s); un1[s] = load4f(urow + 16 * s + 4); }
-        vn = load4f(V + ((size_t)cc * NSRC + ci_n) * C1 + 4 * lane);
+        if constexpr (PAIR) {
+            vn[0] = load4f(V + (size_t)mt_n.x * C1 + 4 * lane);
+            vn[NV - 1] = load4f(V + (size_t)mt_n.y * C1 + 4 * lane);
+        } else
+            vn[0] = load4f(V + ((size_t)cc * NSRC + ci_n) * C1 + 4 * lane);
     };
     if (rbeg < rend) {
-        const long long ce = rbeg * NW + wave;
-        idx_n = ball[ce * kNSample + p];
-        ci_n = cent_idx[ce];
+        const long long ce = item_of(rbeg);
+        request_idx(ce);
         request_u(ce / S);
     }
     SAW_T0();
     [[maybe_unused]] int nrounds = 0;
     for (long long rd = rbeg; rd < rend; rd += rstep) {
-        const long long cent = rd * NW + wave;
+        const long long cent = item_of(rd);
+        const int4 mt = mt_n;                            // (this round's item; mt_n moves on to the next round's below)
+        const bool paired = PAIR && mt.z != mt.w;
+        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z) : (size_t)cent;
         bf16x8 xh[KS], xl[KS], zh[KS], zl[KS];
         {
-            *reinterpret_cast<f32x4*>(&vl[wave][4 * lane]) = vn;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(&vl[wave][k][4 * lane]) = vn[k];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            const float* vrow = &vl[wave][8 * h];
+            const float* vrow = &vl[wave][PAIR ? p >> 4 : 0][8 * h];
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += 8) {
                 f32x4 v0[8], v1[8];
@@ -615,7 +664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     split8u<NP>(t, xh[s0 + s], xl[s0 + s]);
                 }
             }
-            if (rd + rstep < rend) { const long long ce = (rd + rstep) * NW + wave; idx_n = ball[ce * kNSample + p]; ci_n = cent_idx[ce]; }
+            if (rd + rstep < rend) request_idx(item_of(rd + rstep));
         }
         SAW_MARK(0);
 #define SAW_BEGIN(Q) { if (!(dbg & 1) && !SPREAD) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
@@ -672,7 +721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             SAW_END(q)
         }
         // ---- layer 3 (direct orientation): max over the 32 rows
-        if (rd + rstep < rend) request_u(((rd + rstep) * NW + wave) / S);
+        if (rd + rstep < rend) request_u(item_of(rd + rstep) / S);
 #pragma unroll
         for (int q = 0; q < NB3 / PB; ++q) {
             SAW_BEGIN(NB2 / PB + q)
@@ -706,14 +755,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (s % 2 == 1) __builtin_amdgcn_sched_barrier(0);
             }
             SAW_MARK(3);
-            float m0 = a0[0], m1 = a1[0];
+            if constexpr (PAIR) {
+                // rows 0-15 (registers 0-7) / rows 16-31 (registers 8-15): the two centroids of a paired item; half-wave 0 stores the first
+                // one's row, half-wave 1 the second's (unpaired: one maximum, both half-waves store the same row)
+                float m0a = a0[0], m0b = a0[8], m1a = a1[0], m1b = a1[8];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, a0[r]); m1 = fmaxf(m1, a1[r]); }
-            m0 = fmaxf(m0, __shfl_xor(m0, 32));
-            m1 = fmaxf(m1, __shfl_xor(m1, 32));
-            if (lane < 32) {
-                out[(size_t)cent * C3 + (2 * q) * 32 + lane] = reluf(m0 + bl[lz + C2 + (2 * q) * 32 + lane]);
-                out[(size_t)cent * C3 + (2 * q + 1) * 32 + lane] = reluf(m1 + bl[lz + C2 + (2 * q + 1) * 32 + lane]);
+                for (int r = 1; r < 8; ++r) { m0a = fmaxf(m0a, a0[r]); m0b = fmaxf(m0b, a0[8 + r]); m1a = fmaxf(m1a, a1[r]); m1b = fmaxf(m1b, a1[8 + r]); }
+                const float m0ab = fmaxf(m0a, m0b), m1ab = fmaxf(m1a, m1b);
+                const float m0 = max_halves2(paired ? m0a : m0ab, paired ? m0b : m0ab);
+                const float m1 = max_halves2(paired ? m1a : m1ab, paired ? m1b : m1ab);
+                out[orow * C3 + (2 * q) * 32 + p] = reluf(m0 + bl[lz + C2 + (2 * q) * 32 + p]);
+                out[orow * C3 + (2 * q + 1) * 32 + p] = reluf(m1 + bl[lz + C2 + (2 * q + 1) * 32 + p]);
+            } else {
+                float m0 = a0[0], m1 = a1[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) { m0 = fmaxf(m0, a0[r]); m1 = fmaxf(m1, a1[r]); }
+                m0 = fmaxf(m0, __shfl_xor(m0, 32));
+                m1 = fmaxf(m1, __shfl_xor(m1, 32));
+                if (lane < 32) {
+                    out[(size_t)cent * C3 + (2 * q) * 32 + lane] = reluf(m0 + bl[lz + C2 + (2 * q) * 32 + lane]);
+                    out[(size_t)cent * C3 + (2 * q + 1) * 32 + lane] = reluf(m1 + bl[lz + C2 + (2 * q + 1) * 32 + lane]);
+                }
             }
             SAW_MARK(4);
             SAW_END(NB2 / PB + q)
@@ -1624,7 +1686,7 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
 #else
         constexpr int dbg = 0;
 #endif
-        hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg);
+        hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg, nullptr, nullptr);
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;
         // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
@@ -1633,8 +1695,19 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
                            nullptr, nullptr);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
-        hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out);
+        hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out, nullptr,
+                           nullptr);
     }
+}
+
+// sa3 / sa4 over the item list of launch_sa_pair_plan (geometry.hip): rows = 32 U rows per item, meta = {V rows, output rows}, *count items
+void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
+                       const float* blob_b, float* out, hipStream_t st) {
+    if (level == 3)
+        hipLaunchKernelGGL((sa_w_kernel<2, true>), dim3(256), dim3(256), 0, st, U, V, nullptr, rows, 0LL, blob_w, blob_b, out, 0, meta, count);
+    else
+        hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2, true>), dim3(256), dim3(12 * 64), 0, st, U, V, nullptr, rows, 256, 64, 0LL, blob_w, blob_b, out, meta,
+                           count);
 }
 
 }  // namespace lsdm

@@ -1004,6 +1004,79 @@ __global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Item lists of sa3 / sa4 (sa_p_kernel / sa_w_kernel with PAIR, encoder_u.hip).  query_ball_point (pointnet2_utils.py:107-130) pads a group
+// with fewer than 32 points in the ball with repeats of its FIRST entry; under the stage's max over the group the repeats change nothing.
+// A group's distinct entries come first, in increasing order, so  ball[16] == ball[0]  <=>  at most 16 distinct entries: two such groups
+// share one 32-row block of the stack (rows 0-15 / 16-31, each with its own V row, maximum and output row), every other group keeps a
+// block to itself.  On the bench clouds 18-22 % of the groups of both levels pair up: a tenth fewer blocks, per row the same arithmetic.
+//
+// A SEGMENT is one step's launch (T1 = clouds x S centroids, rows and output numbered within it); a launch covers the segments of a group.
+// Work-group = chunk of 256 consecutive centroids of a segment; pairs are formed inside a chunk (the k-th group of at most 16 with the
+// (k ^ 1)-th: neighbours in index order, usually of the same cloud), an odd one out stays single.  Two passes, no atomics, so that the
+// list's ORDER is a function of the input too: sa_pair_count_kernel -> small groups per chunk; sa_pair_write_kernel -> every chunk adds up
+// the items of the chunks before it, then writes its items: [pairs][odd one out][groups of more than 16, in index order].
+//   rows  (T1 x 32)  U row of every block row, numbered over the segment (cloud x NSRC + ball entry)
+//   meta  (T1) int4  {V row of rows 0-15, V row of rows 16-31, output row of rows 0-15, of rows 16-31} (equal pairs: an unpaired item)
+//   count (1)        items of the segment
+__global__ __launch_bounds__(256) void sa_pair_count_kernel(const int* __restrict__ ball, int T1, int CPS, int* __restrict__ chunk_ns) {
+    const int seg = blockIdx.x / CPS, chunk = blockIdx.x % CPS;
+    const int e = chunk * 256 + (int)threadIdx.x;
+    bool small = false;
+    if (e < T1) {
+        const int* b = ball + ((size_t)seg * T1 + e) * kNSample;
+        small = b[16] == b[0];
+    }
+    const int ns = __syncthreads_count(small);
+    if (threadIdx.x == 0) chunk_ns[blockIdx.x] = ns;
+}
+
+__global__ __launch_bounds__(256) void sa_pair_write_kernel(const int* __restrict__ ball, const int* __restrict__ cent_idx, int T1, int S, int NSRC, int CPS,
+                                                            const int* __restrict__ chunk_ns, int* __restrict__ rows, int4* __restrict__ meta,
+                                                            int* __restrict__ count) {
+    __shared__ int wsum[4], wsmall[4];
+    const int seg = blockIdx.x / CPS, chunk = blockIdx.x % CPS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // items of the chunks before this one
+    int before = 0;
+    for (int k = tid; k < chunk; k += 256) before += 256 - (chunk_ns[seg * CPS + k] >> 1);      // (only the last chunk of a segment can be partial)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    const int e = chunk * 256 + tid;
+    const bool valid = e < T1;
+    const size_t ge = (size_t)seg * T1 + (valid ? e : 0);
+    const int* b = ball + ge * kNSample;
+    const bool small = valid && b[16] == b[0];
+    const unsigned long long m = __ballot(small);
+    if (lane == 0) { wsum[wave] = before; wsmall[wave] = __popcll(m); }
+    __syncthreads();
+    const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int rank = __popcll(m & ((1ull << lane) - 1ull));                 // groups of at most 16 before this one in the chunk
+    for (int w = 0; w < wave; ++w) rank += wsmall[w];
+    const int ns = wsmall[0] + wsmall[1] + wsmall[2] + wsmall[3], npairs = ns >> 1;
+    const int nvalid = T1 - chunk * 256 < 256 ? T1 - chunk * 256 : 256;
+    if (chunk == CPS - 1 && tid == 0) count[seg] = base + nvalid - npairs;
+    if (!valid) return;
+    const bool member = small && rank < 2 * npairs;
+    const int slot = member ? rank >> 1 : (small ? npairs : npairs + (ns & 1) + (tid - rank));
+    const int half = member ? rank & 1 : 0;
+    const size_t gi = (size_t)seg * T1 + base + slot;
+    const int r0 = (e / S) * NSRC;                                     // first U / V row of the centroid's cloud
+    const int vrow = r0 + cent_idx[ge];
+    const int4* src = reinterpret_cast<const int4*>(b);
+    int4* dst = reinterpret_cast<int4*>(rows + gi * kNSample + half * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (member && k >= 4) break;
+        int4 v = src[k];
+        v.x += r0; v.y += r0; v.z += r0; v.w += r0;
+        dst[k] = v;
+    }
+    int* mi = reinterpret_cast<int*>(meta + gi);
+    if (member) { mi[half] = vrow; mi[2 + half] = e; }
+    else meta[gi] = make_int4(vrow, vrow, e, e);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 void launch_fps_chain(const float* clouds, const int64_t* starts, int num_clouds, int nc_step, int* const idx[4], float* const xyz[4],
@@ -1034,6 +1107,14 @@ void launch_memo_src(const int* ball2, long long total, unsigned char* unc, int*
 void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsigned char* unc, const float* F2, int nc1, float* out, int* list, int* count,
                       unsigned char* crowd, hipStream_t st) {
     hipLaunchKernelGGL(memo_cent_kernel, dim3(clouds), dim3(256), 0, st, idx0, idx1, unc, F2, nc1, out, list, count, crowd);
+}
+
+int sa_pair_chunks(int T1) { return (T1 + 255) / 256; }
+void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_ns, int* rows, int4* meta, int* count,
+                         hipStream_t st) {
+    const int cps = sa_pair_chunks(T1);
+    hipLaunchKernelGGL(sa_pair_count_kernel, dim3(segs * cps), dim3(256), 0, st, ball, T1, cps, chunk_ns);
+    hipLaunchKernelGGL(sa_pair_write_kernel, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_ns, rows, meta, count);
 }
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,

@@ -124,6 +124,15 @@ void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx
                       const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count);
 void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod = 0);
+// sa3 / sa4 over ITEM lists (groups of at most 16 distinct neighbours two to a 32-row block; geometry.hip: sa_pair_*_kernel):
+//   launch_sa_pair_plan: `segs` segments of T1 = clouds x S centroids each (ball (segs*T1, 32), cent_idx (segs*T1)) -> rows (segs*T1, 32),
+//                        meta (segs*T1) int4, count (segs); chunk_ns: segs * sa_pair_chunks(T1) ints of scratch
+//   launch_sa_u_items  : one segment's stage (level 2 = sa3, 3 = sa4) over its list
+int sa_pair_chunks(int T1);
+void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_ns, int* rows, int4* meta, int* count,
+                         hipStream_t st);
+void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
+                       const float* blob_b, float* out, hipStream_t st);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
 // p1_remap (optional): row i of a cloud's points1 is points1[p1_remap[i]]
 // y_ready: ybuf was written by the coarser stage's fused extra layer; wb_next / ynext (which = 3, optional): this launch also writes

@@ -507,9 +507,9 @@ _SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "
              {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
              {"LSDM_GROUP": "3"}, {"LSDM_BATCH_ENC": "0"}, {"LSDM_BATCH_DEN": "0"}, {"LSDM_STREAMS": "1"}, {"LSDM_INV_SIDE": "0"}, {"LSDM_SA2_MEMO": "0"},
              {"LSDM_FP2_WS": "0"}, {"LSDM_FP2_WS": "1"}, {"LSDM_FP2_WS": "2"}, {"LSDM_FP2_WS": "3"}, {"LSDM_FP1_PIPE": "0"}, {"LSDM_FP1_ORDER": "0"},
-             {"LSDM_FP1_PIPE": "0", "LSDM_FP1_ORDER": "0"}]
+             {"LSDM_FP1_PIPE": "0", "LSDM_FP1_ORDER": "0"}, {"LSDM_SA_PAIR": "0"}]
 _SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN", "LSDM_STREAMS", "LSDM_INV_SIDE", "LSDM_SA2_MEMO", "LSDM_FP2_WS", "LSDM_FP1_PIPE",
-                    "LSDM_FP1_ORDER")      # launch shapes / kernel forms with the same arithmetic in the same order: bit-identical results
+                    "LSDM_FP1_ORDER", "LSDM_SA_PAIR")      # launch shapes / kernel forms with the same arithmetic in the same order: bit-identical results
 
 
 @pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
@@ -545,6 +545,52 @@ def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
         assert maxabs(a, b) <= 1e-3
         if all(k in _SAME_ARITHMETIC for k in env):
             assert torch.equal(a, b), env
+
+
+def test_sa3_sa4_item_lists_agree_with_one_block_per_group():
+    """sa3 / sa4 over item lists (two ball-query groups of at most 16 distinct neighbours in one 32-row block, geometry.hip: sa_pair_*_kernel)
+    against every group in a block of its own (LSDM_SA_PAIR=0), bit for bit over a 4-step chain, on scenes whose objects cover the
+    extremes: a cloud scattered over 100 m (every group is its centroid alone: all of them pair up), a single point and an all-zero slot
+    (every group has 32 distinct entries: nothing pairs), a line, a 2 cm blob, two points, ordinary objects; and the item counts the
+    planner reports: blocks = groups - pairs, within what the groups' sizes allow."""
+    B = 3
+    bt = make_synthetic_batch(B, seed=41)
+    g = torch.Generator().manual_seed(78)
+    objs = bt["given_objs"].clone()
+    objs[0, 1] = (torch.rand(1024, 3, generator=g) - 0.5) * 100.0
+    objs[0, 2] = torch.tensor([0.3, -1.2, 0.7]).expand(1024, 3)
+    objs[0, 3] = 0.0
+    objs[1, 0, :, 0] = torch.linspace(-1.0, 1.0, 1024); objs[1, 0, :, 1:] = 0.0
+    objs[1, 4] = torch.randn(1024, 3, generator=g) * 0.02
+    objs[2, 5, ::2] = torch.tensor([0.0, 0.0, 0.0]); objs[2, 5, 1::2] = torch.tensor([0.05, 0.0, 0.1])
+    objs[2, 6] = (torch.rand(1024, 3, generator=g) - 0.5) * 6.0
+    bt["given_objs"] = objs
+    bt = {k: v.to(DEV) for k, v in bt.items()}
+    outs, items = {}, {}
+    keep = os.environ.get("LSDM_SA_PAIR")
+    try:
+        for mode in ("1", "0"):
+            os.environ["LSDM_SA_PAIR"] = mode
+            m, diff = _fresh("bf16x3")
+            outs[mode] = _chain(m, diff, bt, B, 4, 23)
+            if mode == "1":
+                items = {lvl: ws(m, name, (4,), torch.int32).clone() for lvl, name in ((3, "sa3_items"), (4, "sa4_items"))}
+            else:
+                with pytest.raises(Exception):
+                    m._ctx.workspace_tensor("sa3_items")
+            del m, diff
+    finally:
+        if keep is None:
+            del os.environ["LSDM_SA_PAIR"]
+        else:
+            os.environ["LSDM_SA_PAIR"] = keep
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    for lvl, S in ((3, 64), (4, 16)):
+        groups = B * 9 * S
+        n = items[lvl]
+        # every step: at least half the groups (everything paired), fewer than all of them (the scattered cloud alone pairs S / 2 blocks away)
+        assert bool((n >= groups // 2).all()) and bool((n <= groups - S // 2).all()), (lvl, n, groups)
 
 
 def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
