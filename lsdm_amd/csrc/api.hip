@@ -65,6 +65,8 @@ struct lsdm_ctx {
     float* fp_ybuf[3] = {};
     int* fp2_plan = nullptr;     // fp2's tile plan (encoder_d.hip::fp_plan_kernel) of a single step, rewritten by every such step
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
+    // item lists of sa3 [0] / sa4 [1] of a single step (geometry.hip: sa_pair_kernel; the groups of the loop-invariant schedule have their own in gws)
+    int *pair_rows[2] = {}, *pair_cnt = nullptr, *pair_chunk[2] = {}; int4* pair_meta[2] = {};
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
     int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
     int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = sa3 / sa4 give every ball-query group a 32-row block of its own
@@ -168,8 +170,8 @@ struct lsdm_ctx {
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr;
                      struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3];
                      int* plan = nullptr;     // fp2's tile plans of every step of a group (one fp_plan_kernel launch per group)
-                     // item lists of sa3 [0] / sa4 [1] of every step of a group (geometry.hip: sa_pair_*_kernel): U rows, {V rows, output rows},
-                     // items per step, small groups per chunk (scratch)
+                     // item lists of sa3 [0] / sa4 [1] of every step of a group (geometry.hip: sa_pair_kernel): U rows, {V rows, output rows},
+                     // items per step, pairs per chunk (scratch)
                      int *pair_rows[2] = {}, *pair_cnt[2] = {}, *pair_chunk[2] = {}; int4* pair_meta[2] = {};
                      // memo of sa2 (geometry.hip: memo_src_kernel): r = 0.2 balls of the source points, flags, F2 rows, work lists, counters
                      int *memo_ball2 = nullptr, *memo_src_list = nullptr, *memo_list = nullptr, *memo_cnt = nullptr, *memo_ident = nullptr;
@@ -625,12 +627,27 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         } else if (np == 2 && l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
             launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
-            launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
-            prof_exec(c, K_SA1 + 2, nc * xm::SA3);
+            if (c->sa_pair) {
+                // the step's item list: two groups whose distinct neighbours fit into 32 rows together share a block
+                launch_sa_pair_plan(1, nc * 64, 64, 256, f.ball[2], f.idx[2], c->pair_chunk[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, st);
+                launch_sa_u_items(2, c->sa_U[0], c->sa_V[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+                prof_exec(c, K_SA1 + 2, nc * xm::SA3_UV);
+                prof_exec_dev(c, K_SA1 + 2, c->pair_cnt, xm::SA3_ITEM, st);
+            } else {
+                launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+                prof_exec(c, K_SA1 + 2, nc * xm::SA3);
+            }
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-            launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
-            prof_exec(c, K_SA1 + 3, nc * xm::SA4);
+            if (c->sa_pair) {
+                launch_sa_pair_plan(1, nc * 16, 16, 64, f.ball[3], f.idx[3], c->pair_chunk[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, st);
+                launch_sa_u_items(3, c->sa_U[1], c->sa_V[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
+                prof_exec(c, K_SA1 + 3, nc * xm::SA4_UV);
+                prof_exec_dev(c, K_SA1 + 3, c->pair_cnt + 1, xm::SA4_ITEM, st);
+            } else {
+                launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
+                prof_exec(c, K_SA1 + 3, nc * xm::SA4);
+            }
         } else {
             if (l < c->sa_reg)
                 launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
@@ -810,7 +827,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
         prof_mark(c, K_FP2, st, 0);      // (timed with the stage, not counted as launches of it: avg_ms stays per step)
         launch_fp_plan(nc, c->inv_order, nc1, f.idx[0], f.nn_idx[2], f.idx[0], g.plan, st);
     }
-    // sa3 / sa4's item lists of every step of the group: groups of at most 16 distinct neighbours two to a block
+    // sa3 / sa4's item lists of every step of the group: two groups whose distinct neighbours fit into 32 rows together share a block
     if (c->sa_pair) {
         prof_mark(c, K_SA1 + 2, st, 0);
         launch_sa_pair_plan(steps, nc1 * 64, 64, 256, f.ball[2], f.idx[2], g.pair_chunk[0], g.pair_rows[0], g.pair_meta[0], g.pair_cnt[0], st);
@@ -1470,6 +1487,13 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->s_stash = ws_alloc<float>(c, "s_stash", (size_t)B * (kN / 32) * 6 * 16 * 64)) &&
          (c->fp2_plan = ws_alloc<int>(c, "fp2_plan", nc * fp_plan_ints(1024))) && (c->fp2_order = ws_alloc<int>(c, "fp2_order", nc * kN)) &&
          (c->inv_order = ws_alloc<int>(c, "inv_order", nc * kN));
+    if (ok && c->sa_pair) {
+        ok = (c->pair_rows[0] = ws_alloc<int>(c, "sa3_rows", nc * 64 * 32)) && (c->pair_rows[1] = ws_alloc<int>(c, "sa4_rows", nc * 16 * 32)) &&
+             (c->pair_meta[0] = reinterpret_cast<int4*>(ws_alloc<int>(c, "sa3_meta", nc * 64 * 4))) &&
+             (c->pair_meta[1] = reinterpret_cast<int4*>(ws_alloc<int>(c, "sa4_meta", nc * 16 * 4))) && (c->pair_cnt = ws_alloc<int>(c, "sa_step_items", 2)) &&
+             (c->pair_chunk[0] = ws_alloc<int>(c, "sa3_chunks", (size_t)sa_pair_chunks((int)nc * 64))) &&
+             (c->pair_chunk[1] = ws_alloc<int>(c, "sa4_chunks", (size_t)sa_pair_chunks((int)nc * 16)));
+    }
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
         for (int l = 0; l < 4 && ok; ++l)

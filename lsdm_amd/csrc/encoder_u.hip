@@ -166,6 +166,19 @@ __device__ __forceinline__ float max_halves2(float a, float b) {
     return fmaxf(a, b);
 }
 
+// the pooled row(s) of a split block (PAIR): lanes 0-31 get the maximum over A's rows, lanes 32-63 over B's (an unpaired item: the maximum
+// over all 32 rows in both).  own[g]: register quartet g of this lane's half-wave belongs to A.
+__device__ __forceinline__ float max_split(const f32x16& a, const bool (&own)[4], bool paired) {
+    float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float m4 = fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), fmaxf(a[4 * g + 2], a[4 * g + 3]));
+        ma = fmaxf(ma, own[g] ? m4 : -INFINITY);
+        mb = fmaxf(mb, own[g] ? -INFINITY : m4);
+    }
+    return max_halves2(ma, paired ? mb : ma);
+}
+
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -186,11 +199,12 @@ __device__ __forceinline__ void sgb_block() {
     });
 }
 
-// PAIR (launch_sa_pair_plan, geometry.hip): the launch walks a list of ITEMS instead of the centroids.  A ball-query group is padded to 32 rows with
-// repeats of its first neighbour; the repeats change nothing under the max, so two groups of at most 16 distinct neighbours share ONE
-// 32-row block: rows 0-15 (accumulator registers 0-7 of both half-waves) belong to the first centroid, rows 16-31 (registers 8-15) to the
-// second, each half with its own V row, its own maximum and its own output row.  `ball` is then the item list's row table (32 U rows per
-// item, numbered over the launch), `pmeta` {V row of rows 0-15, of rows 16-31, output row of each} and *pcount the number of items.
+// PAIR (launch_sa_pair_plan, geometry.hip): the launch walks a list of ITEMS instead of the centroids.  A ball-query group is padded to 32 rows
+// with repeats of its first neighbour; the repeats change nothing under the max, so two groups whose distinct neighbours fit into 32 rows
+// together share ONE 32-row block: rows 0 .. 4k-1 belong to the first centroid ("A"), rows 4k .. 31 to the second ("B"), each with its own
+// V row, its own maximum and its own output row.  Row r of the block is accumulator register (r & 3) + 4 (r >> 3) of half-wave (r >> 2) & 1:
+// register quartet g of half-wave h is A's iff 2 g + h < k.  `ball` is then the item list's row table (32 U rows per item, numbered over
+// the launch), `pmeta` {V row of A, of B, output row of A | k << 24, of B} (k = 8: an unpaired item) and *pcount the number of items.
 template <int C1, int C2, int C3, int NW, int NP, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                         const int* __restrict__ cent_idx, const int* __restrict__ ball, int NSRC, int S,
@@ -251,10 +265,12 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
         const int cent = cent_of(rd);        // (a wave past the end repeats the last centroid: same values, same addresses)
         const int c = cent / S;
         const int4 mt = mt_n;
-        const bool paired = PAIR && mt.z != mt.w;
-        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z) : (size_t)cent;
+        const int ka = PAIR ? mt.z >> 24 : 8;              // A's row quartets
+        const bool paired = ka < 8;
+        const bool own[4] = {h < ka, 2 + h < ka, 4 + h < ka, 6 + h < ka};
+        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z & 0xffffff) : (size_t)cent;
         const float* urow = U + (PAIR ? (size_t)idx_n : (size_t)c * NSRC + idx_n) * C1 + 8 * h;
-        const float* vrow = V + (PAIR ? (size_t)(p < 16 ? mt.x : mt.y) : (size_t)c * NSRC + ci_n) * C1 + 8 * h;
+        const float* vrow = V + (PAIR ? (size_t)(p < 4 * ka ? mt.x : mt.y) : (size_t)c * NSRC + ci_n) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
         {
             f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
@@ -296,13 +312,8 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
         auto l3_epi = [&](int nb, const f32x16& a) {
             float m;
             if constexpr (PAIR) {
-                // rows 0-15 are registers 0-7 of both half-waves, rows 16-31 registers 8-15; half-wave 0 stores the first centroid's row,
-                // half-wave 1 the second's (an unpaired item: one maximum, the same row twice as below)
-                float ma = a[0], mb = a[8];
-#pragma unroll
-                for (int r = 1; r < 8; ++r) { ma = fmaxf(ma, a[r]); mb = fmaxf(mb, a[8 + r]); }
-                const float mab = fmaxf(ma, mb);
-                m = max_halves2(paired ? ma : mab, paired ? mb : mab);
+                // half-wave 0 stores A's row, half-wave 1 B's (an unpaired item: one maximum, the same row twice as below)
+                m = max_split(a, own, paired);
             } else {
                 m = a[0];
 #pragma unroll
@@ -642,15 +653,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (long long rd = rbeg; rd < rend; rd += rstep) {
         const long long cent = item_of(rd);
         const int4 mt = mt_n;                            // (this round's item; mt_n moves on to the next round's below)
-        const bool paired = PAIR && mt.z != mt.w;
-        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z) : (size_t)cent;
+        const int ka = PAIR ? mt.z >> 24 : 8;            // A's row quartets (sa_p_kernel)
+        const bool paired = ka < 8;
+        const bool own[4] = {h < ka, 2 + h < ka, 4 + h < ka, 6 + h < ka};
+        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z & 0xffffff) : (size_t)cent;
         bf16x8 xh[KS], xl[KS], zh[KS], zl[KS];
         {
 #pragma unroll
             for (int k = 0; k < NV; ++k) *reinterpret_cast<f32x4*>(&vl[wave][k][4 * lane]) = vn[k];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            const float* vrow = &vl[wave][PAIR ? p >> 4 : 0][8 * h];
+            const float* vrow = &vl[wave][PAIR && p >= 4 * ka ? 1 : 0][8 * h];
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += 8) {
                 f32x4 v0[8], v1[8];
@@ -756,14 +769,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             SAW_MARK(3);
             if constexpr (PAIR) {
-                // rows 0-15 (registers 0-7) / rows 16-31 (registers 8-15): the two centroids of a paired item; half-wave 0 stores the first
-                // one's row, half-wave 1 the second's (unpaired: one maximum, both half-waves store the same row)
-                float m0a = a0[0], m0b = a0[8], m1a = a1[0], m1b = a1[8];
-#pragma unroll
-                for (int r = 1; r < 8; ++r) { m0a = fmaxf(m0a, a0[r]); m0b = fmaxf(m0b, a0[8 + r]); m1a = fmaxf(m1a, a1[r]); m1b = fmaxf(m1b, a1[8 + r]); }
-                const float m0ab = fmaxf(m0a, m0b), m1ab = fmaxf(m1a, m1b);
-                const float m0 = max_halves2(paired ? m0a : m0ab, paired ? m0b : m0ab);
-                const float m1 = max_halves2(paired ? m1a : m1ab, paired ? m1b : m1ab);
+                // half-wave 0 stores A's row, half-wave 1 B's (unpaired: one maximum, both half-waves store the same row)
+                const float m0 = max_split(a0, own, paired), m1 = max_split(a1, own, paired);
                 out[orow * C3 + (2 * q) * 32 + p] = reluf(m0 + bl[lz + C2 + (2 * q) * 32 + p]);
                 out[orow * C3 + (2 * q + 1) * 32 + p] = reluf(m1 + bl[lz + C2 + (2 * q + 1) * 32 + p]);
             } else {

@@ -1006,74 +1006,131 @@ __global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // Item lists of sa3 / sa4 (sa_p_kernel / sa_w_kernel with PAIR, encoder_u.hip).  query_ball_point (pointnet2_utils.py:107-130) pads a group
 // with fewer than 32 points in the ball with repeats of its FIRST entry; under the stage's max over the group the repeats change nothing.
-// A group's distinct entries come first, in increasing order, so  ball[16] == ball[0]  <=>  at most 16 distinct entries: two such groups
-// share one 32-row block of the stack (rows 0-15 / 16-31, each with its own V row, maximum and output row), every other group keeps a
-// block to itself.  On the bench clouds 18-22 % of the groups of both levels pair up: a tenth fewer blocks, per row the same arithmetic.
+// A group's d distinct entries come first (in increasing order), so its first 4 ceil(d / 4) rows already hold all of them: two groups whose
+// row needs add up to at most 32 share ONE 32-row block of the stack -- the larger one ("A", k = ceil(d / 4) four-row groups) in rows
+// 0 .. 4k-1, the other ("B") in rows 4k .. 31, each with its own V row, its own maximum and its own output row; every other group keeps a
+// block to itself.  The split is a multiple of four rows because an accumulator register quartet of a half-wave holds four consecutive
+// rows.  On the bench clouds (half the groups are full, the others spread over all sizes) 0.84-0.86 blocks per group, per row the same
+// arithmetic: bit-identical results.
 //
 // A SEGMENT is one step's launch (T1 = clouds x S centroids, rows and output numbered within it); a launch covers the segments of a group.
-// Work-group = chunk of 256 consecutive centroids of a segment; pairs are formed inside a chunk (the k-th group of at most 16 with the
-// (k ^ 1)-th: neighbours in index order, usually of the same cloud), an odd one out stays single.  Two passes, no atomics, so that the
-// list's ORDER is a function of the input too: sa_pair_count_kernel -> small groups per chunk; sa_pair_write_kernel -> every chunk adds up
-// the items of the chunks before it, then writes its items: [pairs][odd one out][groups of more than 16, in index order].
+// Work-group = chunk of 256 consecutive centroids of a segment, pairs are formed inside a chunk (neighbours in index order, usually of few
+// clouds): size class = ceil(d / 4) (1 .. 8), then the two-pointer matching that maximises the number of pairs -- the largest class that
+// still has a partner takes the smallest class left -- on the classes' COUNTS (plan_runs: at most 14 runs of (class, class, pairs)), every
+// group finding its run from its rank within its class.  Two passes, no atomics, so that the list's ORDER is a function of the input too:
+// pass 0 -> pairs per chunk; pass 1 -> every chunk adds up the items of the chunks before it and writes its items, [pairs][singles in
+// index order].
 //   rows  (T1 x 32)  U row of every block row, numbered over the segment (cloud x NSRC + ball entry)
-//   meta  (T1) int4  {V row of rows 0-15, V row of rows 16-31, output row of rows 0-15, of rows 16-31} (equal pairs: an unpaired item)
+//   meta  (T1) int4  {V row of A, V row of B, output row of A | k << 24, output row of B}; k = 8: an unpaired item (B = A)
 //   count (1)        items of the segment
-__global__ __launch_bounds__(256) void sa_pair_count_kernel(const int* __restrict__ ball, int T1, int CPS, int* __restrict__ chunk_ns) {
-    const int seg = blockIdx.x / CPS, chunk = blockIdx.x % CPS;
-    const int e = chunk * 256 + (int)threadIdx.x;
-    bool small = false;
-    if (e < T1) {
-        const int* b = ball + ((size_t)seg * T1 + e) * kNSample;
-        small = b[16] == b[0];
+namespace sap {
+struct Run { int big, small, m, off_big, off_small, slot0; };
+constexpr int MAXRUN = 16;
+// cnt[1 .. 7] -> runs; returns the number of pairs.  Ranks of a class are consumed from the front, whichever side of a pair they end up on.
+__device__ inline int plan_runs(const int* cnt, Run* runs, int* nruns) {
+    int rem[9], off[9];
+    for (int c = 0; c < 9; ++c) { rem[c] = c >= 1 && c <= 7 ? cnt[c] : 0; off[c] = 0; }
+    int np = 0, nr = 0;
+    for (int big = 7; big >= 1; --big) {
+        while (rem[big] > 0) {
+            int small = 1;
+            while (rem[small] == 0) ++small;                 // (the smallest class left: <= big)
+            if (small + big > 8) break;
+            const int m = small == big ? rem[big] / 2 : (rem[big] < rem[small] ? rem[big] : rem[small]);
+            if (m == 0) break;
+            if (runs) runs[nr] = Run{big, small, m, off[big], off[small], np};
+            ++nr;
+            if (small == big) { off[big] += 2 * m; rem[big] -= 2 * m; }
+            else { off[big] += m; rem[big] -= m; off[small] += m; rem[small] -= m; }
+            np += m;
+        }
     }
-    const int ns = __syncthreads_count(small);
-    if (threadIdx.x == 0) chunk_ns[blockIdx.x] = ns;
+    if (nruns) *nruns = nr;
+    return np;
 }
+}  // namespace sap
 
-__global__ __launch_bounds__(256) void sa_pair_write_kernel(const int* __restrict__ ball, const int* __restrict__ cent_idx, int T1, int S, int NSRC, int CPS,
-                                                            const int* __restrict__ chunk_ns, int* __restrict__ rows, int4* __restrict__ meta,
-                                                            int* __restrict__ count) {
-    __shared__ int wsum[4], wsmall[4];
+template <bool WRITE>
+__global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ball, const int* __restrict__ cent_idx, int T1, int S, int NSRC, int CPS,
+                                                      int* __restrict__ chunk_np, int* __restrict__ rows, int4* __restrict__ meta, int* __restrict__ count) {
+    __shared__ int wcnt[4][9], wsingle[4], wbefore[4], s_np, s_nruns;
+    __shared__ sap::Run runs[sap::MAXRUN];
     const int seg = blockIdx.x / CPS, chunk = blockIdx.x % CPS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // items of the chunks before this one
-    int before = 0;
-    for (int k = tid; k < chunk; k += 256) before += 256 - (chunk_ns[seg * CPS + k] >> 1);      // (only the last chunk of a segment can be partial)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int e = chunk * 256 + tid;
     const bool valid = e < T1;
     const size_t ge = (size_t)seg * T1 + (valid ? e : 0);
-    const int* b = ball + ge * kNSample;
-    const bool small = valid && b[16] == b[0];
-    const unsigned long long m = __ballot(small);
-    if (lane == 0) { wsum[wave] = before; wsmall[wave] = __popcll(m); }
+    const int4* src = reinterpret_cast<const int4*>(ball + ge * kNSample);
+    int4 b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = src[k];
+    int d = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d += (b[k].x != b[0].x) + (b[k].y != b[0].x) + (b[k].z != b[0].x) + (b[k].w != b[0].x);
+    const int cls = valid ? (d + 3) >> 2 : 0;                // 1 .. 8 (0: past the end of the segment)
+    int rank = 0;                                            // groups of the same class before this one in the chunk
+    for (int c = 1; c <= 7; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (lane == 0) wcnt[wave][c] = __popcll(m);
+        if (cls == c) rank = __popcll(m & lt);
+    }
+    if (WRITE) {
+        // items of the chunks before this one (only the last chunk of a segment can be partial)
+        int before = 0;
+        for (int k = tid; k < chunk; k += 256) before += 256 - chunk_np[seg * CPS + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+        if (lane == 0) wbefore[wave] = before;
+    }
     __syncthreads();
-    const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    int rank = __popcll(m & ((1ull << lane) - 1ull));                 // groups of at most 16 before this one in the chunk
-    for (int w = 0; w < wave; ++w) rank += wsmall[w];
-    const int ns = wsmall[0] + wsmall[1] + wsmall[2] + wsmall[3], npairs = ns >> 1;
+    if (tid == 0) {
+        int cnt[9] = {};
+        for (int c = 1; c <= 7; ++c) cnt[c] = wcnt[0][c] + wcnt[1][c] + wcnt[2][c] + wcnt[3][c];
+        int nr = 0;
+        s_np = sap::plan_runs(cnt, WRITE ? runs : nullptr, &nr);
+        s_nruns = nr;
+        if (!WRITE) chunk_np[blockIdx.x] = s_np;
+    }
+    if (!WRITE) return;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) rank += cls >= 1 && cls <= 7 ? wcnt[w][cls] : 0;
+    const int npairs = s_np, nruns = s_nruns;
+    const int base = wbefore[0] + wbefore[1] + wbefore[2] + wbefore[3];
+    // this group's run: side 0 = A (rows 0 .. 4k-1), side 1 = B
+    int slot = -1, side = 0, kA = 8;
+    for (int r = 0; r < nruns; ++r) {
+        const sap::Run q = runs[r];
+        if (q.big == q.small) {
+            if (cls == q.big && rank >= q.off_big && rank < q.off_big + 2 * q.m) { slot = q.slot0 + ((rank - q.off_big) >> 1); side = (rank - q.off_big) & 1; kA = q.big; }
+        } else if (cls == q.big && rank >= q.off_big && rank < q.off_big + q.m) { slot = q.slot0 + rank - q.off_big; side = 0; kA = q.big; }
+        else if (cls == q.small && rank >= q.off_small && rank < q.off_small + q.m) { slot = q.slot0 + rank - q.off_small; side = 1; kA = q.big; }
+    }
+    const bool single = valid && slot < 0;
+    const unsigned long long ms = __ballot(single);
+    if (lane == 0) wsingle[wave] = __popcll(ms);
+    __syncthreads();
     const int nvalid = T1 - chunk * 256 < 256 ? T1 - chunk * 256 : 256;
     if (chunk == CPS - 1 && tid == 0) count[seg] = base + nvalid - npairs;
     if (!valid) return;
-    const bool member = small && rank < 2 * npairs;
-    const int slot = member ? rank >> 1 : (small ? npairs : npairs + (ns & 1) + (tid - rank));
-    const int half = member ? rank & 1 : 0;
+    if (single) {
+        slot = npairs + __popcll(ms & lt);
+        for (int w = 0; w < wave; ++w) slot += wsingle[w];
+        kA = 8;
+    }
     const size_t gi = (size_t)seg * T1 + base + slot;
-    const int r0 = (e / S) * NSRC;                                     // first U / V row of the centroid's cloud
+    const int r0 = (e / S) * NSRC;                           // first U / V row of the centroid's cloud
     const int vrow = r0 + cent_idx[ge];
-    const int4* src = reinterpret_cast<const int4*>(b);
-    int4* dst = reinterpret_cast<int4*>(rows + gi * kNSample + half * 16);
+    const int n4 = single ? 8 : (side ? 8 - kA : kA);        // quartets of rows this group fills
+    int4* dst = reinterpret_cast<int4*>(rows + gi * kNSample + (side ? 4 * kA : 0));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (member && k >= 4) break;
-        int4 v = src[k];
-        v.x += r0; v.y += r0; v.z += r0; v.w += r0;
-        dst[k] = v;
+        if (k < n4) dst[k] = make_int4(b[k].x + r0, b[k].y + r0, b[k].z + r0, b[k].w + r0);
     }
     int* mi = reinterpret_cast<int*>(meta + gi);
-    if (member) { mi[half] = vrow; mi[2 + half] = e; }
-    else meta[gi] = make_int4(vrow, vrow, e, e);
+    if (single) meta[gi] = make_int4(vrow, vrow, e | (8 << 24), e);
+    else if (side == 0) { mi[0] = vrow; mi[2] = e | (kA << 24); }
+    else { mi[1] = vrow; mi[3] = e; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1110,11 +1167,11 @@ void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsign
 }
 
 int sa_pair_chunks(int T1) { return (T1 + 255) / 256; }
-void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_ns, int* rows, int4* meta, int* count,
+void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_np, int* rows, int4* meta, int* count,
                          hipStream_t st) {
     const int cps = sa_pair_chunks(T1);
-    hipLaunchKernelGGL(sa_pair_count_kernel, dim3(segs * cps), dim3(256), 0, st, ball, T1, cps, chunk_ns);
-    hipLaunchKernelGGL(sa_pair_write_kernel, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_ns, rows, meta, count);
+    hipLaunchKernelGGL(sa_pair_kernel<false>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count);
+    hipLaunchKernelGGL(sa_pair_kernel<true>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count);
 }
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,

@@ -124,12 +124,12 @@ void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx
                       const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count);
 void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod = 0);
-// sa3 / sa4 over ITEM lists (groups of at most 16 distinct neighbours two to a 32-row block; geometry.hip: sa_pair_*_kernel):
+// sa3 / sa4 over ITEM lists (two ball-query groups whose distinct neighbours fit into 32 rows together share a block; geometry.hip: sa_pair_kernel):
 //   launch_sa_pair_plan: `segs` segments of T1 = clouds x S centroids each (ball (segs*T1, 32), cent_idx (segs*T1)) -> rows (segs*T1, 32),
-//                        meta (segs*T1) int4, count (segs); chunk_ns: segs * sa_pair_chunks(T1) ints of scratch
+//                        meta (segs*T1) int4, count (segs); chunk_np: segs * sa_pair_chunks(T1) ints of scratch
 //   launch_sa_u_items  : one segment's stage (level 2 = sa3, 3 = sa4) over its list
 int sa_pair_chunks(int T1);
-void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_ns, int* rows, int4* meta, int* count,
+void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_np, int* rows, int4* meta, int* count,
                          hipStream_t st);
 void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
                        const float* blob_b, float* out, hipStream_t st);

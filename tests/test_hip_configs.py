@@ -548,7 +548,7 @@ def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
 
 
 def test_sa3_sa4_item_lists_agree_with_one_block_per_group():
-    """sa3 / sa4 over item lists (two ball-query groups of at most 16 distinct neighbours in one 32-row block, geometry.hip: sa_pair_*_kernel)
+    """sa3 / sa4 over item lists (two ball-query groups whose distinct neighbours fit into 32 rows together in one block, geometry.hip: sa_pair_kernel)
     against every group in a block of its own (LSDM_SA_PAIR=0), bit for bit over a 4-step chain, on scenes whose objects cover the
     extremes: a cloud scattered over 100 m (every group is its centroid alone: all of them pair up), a single point and an all-zero slot
     (every group has 32 distinct entries: nothing pairs), a line, a 2 cm blob, two points, ordinary objects; and the item counts the
@@ -594,7 +594,7 @@ def test_sa3_sa4_item_lists_agree_with_one_block_per_group():
 
 
 def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
-    """fp2's planned kernel (fp_d_kernel: Morton-ordered tiles, rows deduplicated through LDS) and fp1's stage pipeline (fp_c_kernel) against the
+    """(Also sa3 / sa4 over item lists against one block per group, on the same clouds.)  fp2's planned kernel (fp_d_kernel: Morton-ordered tiles, rows deduplicated through LDS) and fp1's stage pipeline (fp_c_kernel) against the
     tile-per-work-group / register-chained forms they replaced, bit for bit, on the clouds that leave their fast paths: all-zero and single-point
     clouds (the level-1 order is not a permutation: the plan walks them in index order), a two-point cloud, a cloud scattered over 100 m (no two
     points of a tile share a coarse neighbour: up to 96 distinct rows per tile, beyond the 36 LDS slots -- the rows without a slot are read from
@@ -616,9 +616,9 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
     starts = torch.stack([torch.randint(0, n, (nc,)) for n in (1024, 1024, 256, 64)]).to(DEV)
     sd = make_synthetic_state_dict(seed=0)
     outs = {}
-    keep = {k: os.environ.get(k) for k in ("LSDM_FP2_WS", "LSDM_FP1_PIPE")}
+    keep = {k: os.environ.get(k) for k in ("LSDM_FP2_WS", "LSDM_FP1_PIPE", "LSDM_SA_PAIR")}
     try:
-        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_FP1_PIPE": "1"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_FP1_PIPE": "0"})):
+        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_FP1_PIPE": "1", "LSDM_SA_PAIR": "1"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_FP1_PIPE": "0", "LSDM_SA_PAIR": "0"})):
             os.environ.update(env)
             m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
             m.load_state_dict(sd)
@@ -627,7 +627,9 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
             out = torch.empty(nc, 1024, 3, device=DEV)
             ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), nc, out.data_ptr(), None)
             torch.cuda.synchronize()
-            outs[name] = (out.clone(), ws(m, "fp2", (nc, 1024, 128)).clone())
+            outs[name] = (out.clone(), ws(m, "fp2", (nc, 1024, 128)).clone(), ws(m, "feat3", (nc, 64, 256)).clone(), ws(m, "feat4", (nc, 16, 512)).clone())
+            if name == "new":
+                items = ws(m, "sa_step_items", (2,), torch.int32).clone()
             del m, ctx
     finally:
         for k, v in keep.items():
@@ -636,6 +638,10 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
             else:
                 os.environ[k] = v
     assert bool(torch.isfinite(outs["new"][0]).all())
+    # sa3 / sa4 over the step's item lists (sa_pair_kernel) against one block per ball-query group; the scattered cloud and the line pair up
+    # completely, the single-point, zero and two-point clouds (every group = the first 32 points) not at all
+    assert torch.equal(outs["new"][2], outs["old"][2]) and torch.equal(outs["new"][3], outs["old"][3]), "sa3 / sa4 differ between item lists and groups"
+    assert nc * 64 // 2 <= int(items[0]) <= nc * 64 - 32 and nc * 16 // 2 <= int(items[1]) <= nc * 16 - 8, items
     assert torch.equal(outs["new"][1], outs["old"][1]), "fp2 output differs between fp_d_kernel and fp_pre_kernel"
     assert torch.equal(outs["new"][0], outs["old"][0]), "encoder output differs between the new and the old kernel forms"
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How many 32-row blocks sa3 / sa4 run per step with the item lists (geometry.hip: sa_pair_*_kernel) on the bench workload, and the wall time of
+"""How many 32-row blocks sa3 / sa4 run per step with the item lists (geometry.hip: sa_pair_kernel) on the bench workload, and the wall time of
 a K-step call with and without them (LSDM_SA_PAIR, read when the context is created).  GPU box only:  python tools/sa_pair_probe.py [--surface]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
