@@ -245,14 +245,16 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
     __syncthreads();
 
     const int total = PAIR ? __builtin_amdgcn_readfirstlane(*pcount) : (int)total_centroids;
-    const int rounds = (total + NW - 1) / NW;
-    // (one contiguous chunk of rounds per work-group; the XCD-cooperative schedule of sa2 / fp1 was measured without effect here and
-    // in sa_w: their HBM fetch already equals the unique input)
-    const int rchunk = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int rbeg = xcd_remap((int)blockIdx.x, (int)gridDim.x) * rchunk;
-    const int rend = rbeg + rchunk < rounds ? rbeg + rchunk : rounds;
+    // An even, contiguous share of the blocks for every work-group (consecutive shares on one XCD; the XCD-cooperative schedule of sa2 / fp1
+    // was measured without effect here and in sa_w: their HBM fetch already equals the unique input).  The LAST round of a share is partial:
+    // its idle waves skip everything but the panel copies and the barriers, so the waves that do have a block run it with a SIMD (nearly) to
+    // themselves -- with whole rounds per work-group a launch of 10.3 rounds' worth of blocks took 11.
+    const int G = (int)gridDim.x, bx = xcd_remap((int)blockIdx.x, G);
+    const int per = total / G, extra = total - per * G;
+    const int ibeg = bx * per + (bx < extra ? bx : extra), nit = per + (bx < extra ? 1 : 0);
+    const int rbeg = 0, rend = (nit + NW - 1) / NW;
     constexpr int rstep = 1;
-    auto cent_of = [&](int rd) { const int ce = rd * NW + wave; return ce < total ? ce : total - 1; };
+    auto cent_of = [&](int rd) { const int k = rd * NW + wave; return ibeg + (k < nit ? k : nit - 1); };
     int idx_n = 0, ci_n = 0;
     int4 mt_n = {0, 0, 0, 0};
     auto request_idx = [&](int ce) {
@@ -262,7 +264,16 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
     };
     if (rbeg < rend) request_idx(cent_of(rbeg));
     for (int rd = rbeg; rd < rend; rd += rstep) {
-        const int cent = cent_of(rd);        // (a wave past the end repeats the last centroid: same values, same addresses)
+        if (rd * NW + wave >= nit) {           // no block for this wave in the share's last round: its part of the panel stream only
+#pragma unroll 1
+            for (int q = 0; q < NPANEL; ++q) {
+                fetch((q + 1) % NPANEL);
+                lds_dma_wait();
+                __syncthreads();
+            }
+            continue;
+        }
+        const int cent = cent_of(rd);
         const int c = cent / S;
         const int4 mt = mt_n;
         const int ka = PAIR ? mt.z >> 24 : 8;              // A's row quartets
