@@ -48,8 +48,8 @@ STAGE_KERNELS_BF16X3 = {
                                "scan) + memo_src_kernel + sa_ur_kernel on the list of uncrowded points (the memo F2), then per GROUP of steps (up to "
                                "LSDM_GROUP, default 28 / 32) memo_cent_kernel (copies F2 rows, lists the crowded centroids) + ONE sa_ur_kernel launch "
                                "over that list; avg_launch_ms is per step covered",
-    "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_p_kernel<128,128,256,12> (epilogues software-pipelined against the next block's MFMAs)",
-    "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_w_kernel",
+    "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_p_kernel<128,128,256,12> (epilogues software-pipelined against the next block's MFMAs) over the item list of sa_pair_kernel (two ball-query groups per 32-row block where their distinct neighbours fit)",
+    "sa_kernel<256,256,256,512>": "lin_u_kernel<256,256> (U, V per level-3 point) + sa_w_kernel over the item list of sa_pair_kernel",
     "fp_kernel<fp4>": "lin_u_kernel<512,256,false> (Y per level-4 point) + fp_pre_kernel<256,256,256,FUSE> (also writes fp3's Y); one launch per "
                       "group of steps (up to LSDM_GROUP, default 28 / 32) in the loop-invariant schedule",
     "fp_kernel<fp3>": "fp_pre_kernel<128,256,256,FUSE> (also writes fp2's Y)",
@@ -269,6 +269,20 @@ def config_legs(a, dev, local_rank, inv):
                                      "note": "fraction of the steps' sa2 centroids served by the per-call memo (fewer than 32 points within r = 0.2)"}
             except Exception as ex:     # (the memo is off: LSDM_SA2_MEMO=0 or a non-default schedule)
                 e["sa2_memo"] = {"error": str(ex)}
+            # sa3 / sa4's item lists: the 32-row blocks each step of the call's last group ran, per ball-query group
+            try:
+                hip = ctypes.CDLL("libamdhip64.so")
+                it = {}
+                for nm, S in (("sa3_items", 64), ("sa4_items", 16)):
+                    ptr, n = r.ctx.workspace_tensor(nm)
+                    k = min(K, int(n))
+                    cnt = (ctypes.c_int * k)()
+                    if hip.hipMemcpy(cnt, ctypes.c_void_p(ptr), ctypes.c_size_t(4 * k), 2) == 0:
+                        it[nm.replace("_items", "_blocks_per_group")] = sum(cnt) / float(k * B * 9 * S)
+                it["note"] = "two ball-query groups whose distinct neighbours fit into 32 rows share one MFMA block (1.0 = one block per group)"
+                e["sa_item_lists"] = it
+            except Exception as ex:     # (LSDM_SA_PAIR=0 or a non-default schedule)
+                e["sa_item_lists"] = {"error": str(ex)}
         out[name] = e
         del r
         torch.cuda.empty_cache()

@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Item lists of sa3 / sa4 (sa_p_kernel / sa_w_kernel with PAIR, encoder_u.hip).  query_ball_point (pointnet2_utils.py:107-130) pads a group
+// Item lists of sa3 / sa4 (sa_p_kernel / sa_w_kernel with PAIR, encoder_u.hip).  query_ball_point (pointnet2_utils.py:84-104; the padding :101-104) pads a group
 // with fewer than 32 points in the ball with repeats of its FIRST entry; under the stage's max over the group the repeats change nothing.
 // A group's d distinct entries come first (in increasing order), so its first 4 ceil(d / 4) rows already hold all of them: two groups whose
 // row needs add up to at most 32 share ONE 32-row block of the stack -- the larger one ("A", k = ceil(d / 4) four-row groups) in rows

@@ -56,3 +56,6 @@ def test_bench_json_line_carries_the_contract_fields():
     assert cf["configs[1]_f32"]["batch"] == 16 and cf["configs[1]_f32"]["max_cats"] == 43 and cf["configs[1]_f32"]["dtype"] == "f32"
     assert cf["configs[4]_one_gpu"]["sampler"] == "ddim" and cf["configs[4]_one_gpu"]["schedule_T"] == 250 and cf["configs[4]_one_gpu"]["max_cats"] == 11
     assert 0.0 < cf["headline_surface_sampled"]["sa2_memo"]["centroid_hit_rate"] <= 1.0
+    for leg in ("headline_surface_sampled", "headline_volume_reference"):       # sa3 / sa4 over item lists: between one block per two groups and one per group
+        il = cf[leg]["sa_item_lists"]
+        assert 0.5 <= il["sa3_blocks_per_group"] < 1.0 and 0.5 <= il["sa4_blocks_per_group"] < 1.0, il

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGES = {
     "sa_kernel<3,32,32,64>": ["sa_r_kernel<3, 32, 32, 64", "sa_h_kernel<3, 32, 32, 64", "sa_kernel<3, 32, 32, 64"],
     "sa_kernel<64,64,64,128>": ["sa_ur_kernel<64, 64, 128", "sa_r_kernel<64, 64, 64, 128", "sa_h_kernel<64, 64, 64, 128"],
-    "sa_kernel<128,128,128,256>": ["lin_u_kernel<128, 128, true>", "sa_p_kernel<128, 128, 256", "sa_u2_kernel<128, 128, 256", "sa_u_kernel<128, 128, 256", "sa_s_kernel<128",
+    "sa_kernel<128,128,128,256>": ["lin_u_kernel<128, 128, true>", "sa_p_kernel<128, 128, 256", "sa_pair_kernel", "sa_u2_kernel<128, 128, 256", "sa_u_kernel<128, 128, 256", "sa_s_kernel<128",
                                    "sa_h_kernel<128, 128, 128, 256"],
     "sa_kernel<256,256,256,512>": ["lin_u_kernel<256, 256, true>", "sa_w_kernel", "sa_x_kernel", "sa_h_kernel<256, 256, 256, 512"],
     "fp_kernel<fp4>": ["lin_u_kernel<512, 256, false>", "fp_pre_kernel<256, 256, 256", "fp_h_kernel<256, 512"],
