@@ -67,6 +67,7 @@ struct lsdm_ctx {
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
     // item lists of sa3 [0] / sa4 [1] of a single step (geometry.hip: sa_pair_kernel; the groups of the loop-invariant schedule have their own in gws)
     int *pair_rows[2] = {}, *pair_cnt = nullptr, *pair_chunk[2] = {}; int4* pair_meta[2] = {};
+    std::vector<int> pair_host[2];       // (profiled passes: the lists' block counts on the host, prof_read_counts)
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
     int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
     int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = sa3 / sa4 give every ball-query group a 32-row block of its own
@@ -269,6 +270,15 @@ void prof_exec_dev(lsdm_ctx* c, int id, const int* counter, double macs_per_coun
     int v = 0;
     if (hipMemcpyAsync(&v, counter, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
     prof_exec(c, id, macs_per_count * v);
+}
+// ... for the item lists of sa3 / sa4, whose counts are written by the planner BEFORE the stages run: read them once, inside an interval that
+// belongs to no stage (the host round trip must not sit in a stage's event interval), and account per step from the host copy
+void prof_read_counts(lsdm_ctx* c, const int* dev, int n, std::vector<int>& host, hipStream_t st) {
+    host.assign((size_t)n, 0);
+    if (!c->prof_on) return;
+    prof_mark(c, -1, st);
+    if (hipMemcpyAsync(host.data(), dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        host.assign((size_t)n, 0);
 }
 namespace xm {     // per cloud (encoder) / per chain or row (others), split-bf16 kernels in their default configuration
 constexpr double SA1 = 32768.0 * (16 * 32 + 32 * 32 + 32 * 64);
@@ -616,6 +626,20 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
     fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
+    // the step's item lists of sa3 / sa4 (geometry only): two groups whose distinct neighbours fit into 32 rows together share a block
+    const bool items3 = np == 2 && c->sa_pair && c->sa_split >= 1, items4 = np == 2 && c->sa_pair && c->sa_split >= 2;
+    if (items3) {
+        prof_mark(c, K_SA1 + 2, st, 0);
+        launch_sa_pair_plan(1, nc * 64, 64, 256, f.ball[2], f.idx[2], c->pair_chunk[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, st);
+    }
+    if (items4) {
+        prof_mark(c, K_SA1 + 3, st, 0);
+        launch_sa_pair_plan(1, nc * 16, 16, 64, f.ball[3], f.idx[3], c->pair_chunk[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, st);
+    }
+    if (items3 || items4) {
+        prof_read_counts(c, c->pair_cnt, 2, c->pair_host[0], st);
+        c->pair_host[1].assign(1, c->pair_host[0][1]);
+    }
     for (int l = skip_sa1 ? 1 : 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
         if (np == 2 && l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
@@ -627,23 +651,18 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         } else if (np == 2 && l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
             launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
-            if (c->sa_pair) {
-                // the step's item list: two groups whose distinct neighbours fit into 32 rows together share a block
-                launch_sa_pair_plan(1, nc * 64, 64, 256, f.ball[2], f.idx[2], c->pair_chunk[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, st);
+            if (items3) {
                 launch_sa_u_items(2, c->sa_U[0], c->sa_V[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
-                prof_exec(c, K_SA1 + 2, nc * xm::SA3_UV);
-                prof_exec_dev(c, K_SA1 + 2, c->pair_cnt, xm::SA3_ITEM, st);
+                prof_exec(c, K_SA1 + 2, nc * xm::SA3_UV + c->pair_host[0][0] * xm::SA3_ITEM);
             } else {
                 launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
                 prof_exec(c, K_SA1 + 2, nc * xm::SA3);
             }
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-            if (c->sa_pair) {
-                launch_sa_pair_plan(1, nc * 16, 16, 64, f.ball[3], f.idx[3], c->pair_chunk[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, st);
+            if (items4) {
                 launch_sa_u_items(3, c->sa_U[1], c->sa_V[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
-                prof_exec(c, K_SA1 + 3, nc * xm::SA4_UV);
-                prof_exec_dev(c, K_SA1 + 3, c->pair_cnt + 1, xm::SA4_ITEM, st);
+                prof_exec(c, K_SA1 + 3, nc * xm::SA4_UV + c->pair_host[1][0] * xm::SA4_ITEM);
             } else {
                 launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
                 prof_exec(c, K_SA1 + 3, nc * xm::SA4);
@@ -833,6 +852,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
         launch_sa_pair_plan(steps, nc1 * 64, 64, 256, f.ball[2], f.idx[2], g.pair_chunk[0], g.pair_rows[0], g.pair_meta[0], g.pair_cnt[0], st);
         prof_mark(c, K_SA1 + 3, st, 0);
         launch_sa_pair_plan(steps, nc1 * 16, 16, 64, f.ball[3], f.idx[3], g.pair_chunk[1], g.pair_rows[1], g.pair_meta[1], g.pair_cnt[1], st);
+        for (int l = 0; l < 2; ++l) prof_read_counts(c, g.pair_cnt[l], steps, c->pair_host[l], st);
     }
     // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were
     // measured: fp2 337 -> 323 us, but fp1 275 -> 295, fp3 165 -> 190, sa3 / sa4 slower as well -- the extra launch ramps and tails cost
@@ -859,8 +879,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
             if (c->sa_pair) {
                 const size_t t1 = (size_t)j * nc1 * 64;
                 launch_sa_u_items(2, U0, V0, g.pair_rows[0] + t1 * 32, g.pair_meta[0] + t1, g.pair_cnt[0] + j, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
-                prof_exec(c, K_SA1 + 2, ncp * xm::SA3_UV);
-                prof_exec_dev(c, K_SA1 + 2, g.pair_cnt[0] + j, xm::SA3_ITEM, st);     // the blocks that ran
+                prof_exec(c, K_SA1 + 2, ncp * xm::SA3_UV + c->pair_host[0][j] * xm::SA3_ITEM);     // the blocks that ran
             } else {
                 launch_sa_u(2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
                 prof_exec(c, K_SA1 + 2, ncp * xm::SA3);
@@ -870,8 +889,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
             if (c->sa_pair) {
                 const size_t t1 = (size_t)j * nc1 * 16;
                 launch_sa_u_items(3, U1, V1, g.pair_rows[1] + t1 * 32, g.pair_meta[1] + t1, g.pair_cnt[1] + j, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
-                prof_exec(c, K_SA1 + 3, ncp * xm::SA4_UV);
-                prof_exec_dev(c, K_SA1 + 3, g.pair_cnt[1] + j, xm::SA4_ITEM, st);
+                prof_exec(c, K_SA1 + 3, ncp * xm::SA4_UV + c->pair_host[1][j] * xm::SA4_ITEM);
             } else {
                 launch_sa_u(3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
                 prof_exec(c, K_SA1 + 3, ncp * xm::SA4);
