@@ -593,6 +593,72 @@ def test_sa3_sa4_item_lists_agree_with_one_block_per_group():
         assert bool((n >= groups // 2).all()) and bool((n <= groups - S // 2).all()), (lvl, n, groups)
 
 
+def _most_pairs(classes):
+    """Two-pointer matching on size classes (1..8 quartets of rows; a block holds 8): the largest class that still has a partner takes the smallest
+    class left -- the number of pairs it forms is the maximum."""
+    s = sorted(int(c) for c in classes)
+    i, j, pairs = 0, len(s) - 1, 0
+    while i < j:
+        if s[i] + s[j] <= 8:
+            pairs += 1; i += 1; j -= 1
+        else:
+            j -= 1
+    return pairs
+
+
+def test_sa_item_lists_are_an_exact_cover_with_the_most_pairs():
+    """The planner's output itself (geometry.hip: sa_pair_kernel), read back after one scene-encoder call over 18 clouds (degenerate ones among
+    them; 1152 / 288 centroids: whole chunks of 256 and a partial one at both levels): every centroid is in exactly one block; a block's rows are
+    its groups' first rows (A: 4k, B: 32 - 4k) shifted to the cloud's U rows and hold ALL their distinct entries; V rows and output rows are the
+    groups' own; and the number of blocks is what the pair-maximising matching gives chunk by chunk."""
+    nc = 18
+    g = torch.Generator().manual_seed(79)
+    objs = make_synthetic_batch(2, seed=63)["given_objs"].reshape(nc, 1024, 3).clone()
+    objs[1] = 0.0
+    objs[2] = torch.tensor([0.3, -1.2, 0.7]).expand(1024, 3)
+    objs[4] = (torch.rand(1024, 3, generator=g) - 0.5) * 100.0
+    objs[5, :, 0] = torch.linspace(-1.0, 1.0, 1024); objs[5, :, 1:] = 0.0
+    objs[7] = torch.randn(1024, 3, generator=g) * 0.02
+    objs[11] = (torch.rand(1024, 3, generator=g) - 0.5) * 6.0
+    clouds = objs.to(DEV).contiguous()
+    torch.manual_seed(6)
+    starts = torch.stack([torch.randint(0, n, (nc,)) for n in (1024, 1024, 256, 64)]).to(DEV)
+    m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
+    m.load_state_dict(make_synthetic_state_dict(seed=0))
+    ctx = m._context()
+    m._reserve(2)
+    out = torch.empty(nc, 1024, 3, device=DEV)
+    ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), nc, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    items = ws(m, "sa_step_items", (2,), torch.int32)
+    for lvl, (S, NSRC, name) in enumerate(((64, 256, "sa3"), (16, 64, "sa4"))):
+        T1 = nc * S
+        ball = ws(m, "ball%d" % (lvl + 3), (T1, 32), torch.int32).long()
+        cidx = ws(m, "fps_idx%d" % (lvl + 3), (T1,), torch.int32).long()
+        rows = ws(m, name + "_rows", (T1, 32), torch.int32).long()
+        meta = ws(m, name + "_meta", (T1, 4), torch.int32).long()
+        n = int(items[lvl])
+        d = 1 + (ball[:, 1:] != ball[:, :1]).sum(1)                       # distinct entries of every group (the padding repeats the first)
+        assert bool((ball[:, 1:] != ball[:, :1]).long().diff(dim=1).le(0).all())      # ... which come first
+        cls = (d + 3) // 4
+        want = sum(len(c) - _most_pairs(c) for c in cls.split(256))
+        assert n == want, (name, n, want)
+        r0 = (torch.arange(T1) // S) * NSRC
+        k = meta[:n, 2] >> 24
+        oa, ob, va, vb = meta[:n, 2] & 0xFFFFFF, meta[:n, 3], meta[:n, 0], meta[:n, 1]
+        single = k == 8
+        assert bool((k >= 1).all()) and bool((k <= 8).all()) and bool((oa[single] == ob[single]).all())
+        seen = torch.cat([oa, ob[~single]])
+        assert seen.numel() == T1 and bool((seen.sort().values == torch.arange(T1)).all()), name
+        assert bool((va == r0[oa] + cidx[oa]).all()) and bool((vb == r0[ob] + cidx[ob]).all())
+        assert bool((d[oa] <= 4 * k).all()) and bool((d[ob[~single]] <= 32 - 4 * k[~single]).all())
+        col = torch.arange(32).expand(n, 32)
+        from_a = col < (4 * k)[:, None]
+        src = torch.where(from_a, ball[oa].gather(1, col), ball[ob].gather(1, (col - 4 * k[:, None]).clamp(min=0)))
+        base = torch.where(from_a, r0[oa][:, None], r0[ob][:, None])
+        assert torch.equal(rows[:n], src + base), name
+
+
 def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
     """(Also sa3 / sa4 over item lists against one block per group, on the same clouds.)  fp2's planned kernel (fp_d_kernel: Morton-ordered tiles, rows deduplicated through LDS) and fp1's stage pipeline (fp_c_kernel) against the
     tile-per-work-group / register-chained forms they replaced, bit for bit, on the clouds that leave their fast paths: all-zero and single-point
