@@ -65,9 +65,11 @@ struct lsdm_ctx {
     float* fp_ybuf[3] = {};
     int* fp2_plan = nullptr;     // fp2's tile plan (encoder_d.hip::fp_plan_kernel) of a single step, rewritten by every such step
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
-    // item lists of sa3 [0] / sa4 [1] of a single step (geometry.hip: sa_pair_kernel; the groups of the loop-invariant schedule have their own in gws)
-    int *pair_rows[2] = {}, *pair_cnt = nullptr, *pair_chunk[2] = {}; int4* pair_meta[2] = {};
-    std::vector<int> pair_host[2];       // (profiled passes: the lists' block counts on the host, prof_read_counts)
+    // item lists of the SA stages of a single step (geometry.hip: sa_pair_kernel; the groups of the loop-invariant schedule have their own in gws)
+    // (step_*: by SA level 0 .. 3, one step's lists; the groups' sa3 / sa4 lists are in gws)
+    int *step_rows[4] = {}, *step_cnt = nullptr, *step_chunk[4] = {}; int4* step_meta[4] = {};
+    std::vector<int> step_host;          // (profiled passes: the step lists' block counts on the host, prof_read_counts)
+    std::vector<int> pair_host[2];       // (... and the group's sa3 / sa4 lists')
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
     int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
     int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = sa3 / sa4 give every ball-query group a 32-row block of its own
@@ -177,6 +179,7 @@ struct lsdm_ctx {
                      // memo of sa2 (geometry.hip: memo_src_kernel): r = 0.2 balls of the source points, flags, F2 rows, work lists, counters
                      int *memo_ball2 = nullptr, *memo_src_list = nullptr, *memo_list = nullptr, *memo_cnt = nullptr, *memo_ident = nullptr;
                      unsigned char *memo_unc = nullptr, *memo_crowd = nullptr; float* memo_F2 = nullptr;
+                     int *memo_rows = nullptr, *memo_chunks = nullptr; int4* memo_meta = nullptr;   // item list of the memo's pass (sa_pair_kernel over the uncrowded source points)
                      std::vector<void*> allocs; } gws;
     // side stream of a loop-invariant group: the dense chains of its steps are independent of each other, odd steps run next to even ones
     int streams = getenv("LSDM_STREAMS") ? atoi(getenv("LSDM_STREAMS")) : 2;         // A/B switch: 1 = everything on the caller's stream
@@ -283,6 +286,7 @@ void prof_read_counts(lsdm_ctx* c, const int* dev, int n, std::vector<int>& host
 namespace xm {     // per cloud (encoder) / per chain or row (others), split-bf16 kernels in their default configuration
 constexpr double SA1 = 32768.0 * (16 * 32 + 32 * 32 + 32 * 64);
 constexpr double SA2_UV = 1024.0 * 64 * 64, SA2_CENT = 32.0 * (64 * 64 + 64 * 128), SA2_FULL = 8192.0 * (80 * 64 + 64 * 64 + 64 * 128);
+constexpr double SA1_ITEM = 32.0 * (16 * 32 + 32 * 32 + 32 * 64);
 constexpr double SA3_UV = 256.0 * 128 * 128, SA3_ITEM = 32.0 * (128 * 128 + 128 * 256), SA4_UV = 64.0 * 256 * 256, SA4_ITEM = 32.0 * (256 * 256 + 256 * 512);
 constexpr double SA3 = 256.0 * 128 * 128 + 2048.0 * (128 * 128 + 128 * 256), SA3_FULL = 2048.0 * (144 * 128 + 128 * 128 + 128 * 256);
 constexpr double SA4 = 64.0 * 256 * 256 + 512.0 * (256 * 256 + 256 * 512), SA4_FULL = 512.0 * (272 * 256 + 256 * 256 + 256 * 512);
@@ -626,43 +630,51 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
     fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
-    // the step's item lists of sa3 / sa4 (geometry only): two groups whose distinct neighbours fit into 32 rows together share a block
-    const bool items3 = np == 2 && c->sa_pair && c->sa_split >= 1, items4 = np == 2 && c->sa_pair && c->sa_split >= 2;
-    if (items3) {
-        prof_mark(c, K_SA1 + 2, st, 0);
-        launch_sa_pair_plan(1, nc * 64, 64, 256, f.ball[2], f.idx[2], c->pair_chunk[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, st);
-    }
-    if (items4) {
-        prof_mark(c, K_SA1 + 3, st, 0);
-        launch_sa_pair_plan(1, nc * 16, 16, 64, f.ball[3], f.idx[3], c->pair_chunk[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, st);
-    }
-    if (items3 || items4) {
-        prof_read_counts(c, c->pair_cnt, 2, c->pair_host[0], st);
-        c->pair_host[1].assign(1, c->pair_host[0][1]);
+    // the step's item lists (geometry only): two ball-query groups whose distinct neighbours fit into 32 rows together share a block
+    const bool src1 = skip_sa1 && inv_in_source_order(c);      // sa2 reads the per-call U / V through the step's level-1 order
+    const bool items[4] = {np == 2 && c->sa_pair && !skip_sa1 && c->sa_reg > 0, np == 2 && c->sa_pair && c->sa_split >= 3 && c->sa_reg > 1 && !src1,
+                           np == 2 && c->sa_pair && c->sa_split >= 1, np == 2 && c->sa_pair && c->sa_split >= 2};
+    {
+        const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};
+        for (int l = 0; l < 4; ++l) {
+            if (!items[l]) continue;
+            prof_mark(c, K_SA1 + l, st, 0);
+            launch_sa_pair_plan(1, nc * S_[l], S_[l], N_[l], f.ball[l], f.idx[l], c->step_chunk[l], c->step_rows[l], c->step_meta[l], c->step_cnt + l, st);
+        }
+        if (items[0] || items[1] || items[2] || items[3]) prof_read_counts(c, c->step_cnt, 4, c->step_host, st);
+        else c->step_host.assign(4, 0);
     }
     for (int l = skip_sa1 ? 1 : 0; l < 4; ++l) {
         prof_mark(c, K_SA1 + l, st);
-        if (np == 2 && l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
+        if (l == 0 && items[0]) {
+            launch_sa_r_items(clouds, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, c->feat[0], st);
+            prof_exec(c, K_SA1, c->step_host[0] * xm::SA1_ITEM);
+        } else if (np == 2 && l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
             // sa2: U, V per level-1 point -- per step in FPS order, or (loop-invariant schedule) once per call in source order
-            const bool src = skip_sa1 && inv_in_source_order(c);
+            const bool src = src1;
             if (!src) launch_lin_u(1, nc * 1024, c->feat[0], lvl_xyz[1], c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
-            launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
-            prof_exec(c, K_SA1 + 1, nc * ((src ? 0.0 : xm::SA2_UV) + 256 * xm::SA2_CENT));
+            if (items[1]) {
+                launch_sa_u_items(1, c->sa_U[2], c->sa_V[2], c->step_rows[1], c->step_meta[1], c->step_cnt + 1, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
+                prof_exec(c, K_SA1 + 1, nc * xm::SA2_UV + c->step_host[1] * xm::SA2_CENT);
+            } else {
+                launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
+                prof_exec(c, K_SA1 + 1, nc * ((src ? 0.0 : xm::SA2_UV) + 256 * xm::SA2_CENT));
+            }
         } else if (np == 2 && l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
             launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
-            if (items3) {
-                launch_sa_u_items(2, c->sa_U[0], c->sa_V[0], c->pair_rows[0], c->pair_meta[0], c->pair_cnt, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
-                prof_exec(c, K_SA1 + 2, nc * xm::SA3_UV + c->pair_host[0][0] * xm::SA3_ITEM);
+            if (items[2]) {
+                launch_sa_u_items(2, c->sa_U[0], c->sa_V[0], c->step_rows[2], c->step_meta[2], c->step_cnt + 2, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+                prof_exec(c, K_SA1 + 2, nc * xm::SA3_UV + c->step_host[2] * xm::SA3_ITEM);
             } else {
                 launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
                 prof_exec(c, K_SA1 + 2, nc * xm::SA3);
             }
         } else if (np == 2 && l == 3 && c->sa_split >= 2) {
             launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
-            if (items4) {
-                launch_sa_u_items(3, c->sa_U[1], c->sa_V[1], c->pair_rows[1], c->pair_meta[1], c->pair_cnt + 1, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
-                prof_exec(c, K_SA1 + 3, nc * xm::SA4_UV + c->pair_host[1][0] * xm::SA4_ITEM);
+            if (items[3]) {
+                launch_sa_u_items(3, c->sa_U[1], c->sa_V[1], c->step_rows[3], c->step_meta[3], c->step_cnt + 3, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
+                prof_exec(c, K_SA1 + 3, nc * xm::SA4_UV + c->step_host[3] * xm::SA4_ITEM);
             } else {
                 launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
                 prof_exec(c, K_SA1 + 3, nc * xm::SA4);
@@ -736,7 +748,7 @@ bool group_batched(const lsdm_ctx* c) {
 bool ensure_group_ws(lsdm_ctx* c, int B) {
     lsdm_ctx::GroupWs& g = c->gws;
     if (g.cap_B >= B) {
-        if (g.memo_cnt) c->ws_named["memo_cnt"] = {g.memo_cnt, 2};     // (lsdm_reserve clears the names; the group workspace outlives it)
+        if (g.memo_cnt) c->ws_named["memo_cnt"] = {g.memo_cnt, 3};     // (lsdm_reserve clears the names; the group workspace outlives it)
         if (g.pair_cnt[0]) { c->ws_named["sa3_items"] = {g.pair_cnt[0], lsdm_ctx::kGroup}; c->ws_named["sa4_items"] = {g.pair_cnt[1], lsdm_ctx::kGroup}; }
         return true;
     }
@@ -786,7 +798,10 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
         g.memo_F2 = al(n1 * kN * 128);
         g.memo_crowd = reinterpret_cast<unsigned char*>(al((nc * 256 + 3) / 4));
         ok = g.memo_crowd && g.memo_ball2 && g.memo_src_list && g.memo_list && g.memo_cnt && g.memo_ident && g.memo_unc && g.memo_F2;
-        if (ok) c->ws_named["memo_cnt"] = {g.memo_cnt, 2};      // (lsdm_workspace_tensor: {uncrowded source points of the call, crowded centroids of its last group})
+        if (ok && c->sa_pair)
+            ok = (g.memo_rows = reinterpret_cast<int*>(al(n1 * kN * 32))) && (g.memo_meta = reinterpret_cast<int4*>(al(n1 * kN * 4))) &&
+                 (g.memo_chunks = reinterpret_cast<int*>(al((size_t)sa_pair_chunks((int)(n1 * kN)))));
+        if (ok) c->ws_named["memo_cnt"] = {g.memo_cnt, 3};      // (lsdm_workspace_tensor: {uncrowded source points of the call, crowded centroids of its last group, blocks of the memo's pass})
         if (ok) {
             std::vector<int> ident(n1 * kN);
             for (size_t i = 0; i < ident.size(); ++i) ident[i] = (int)(i % kN);
@@ -1506,11 +1521,12 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->fp2_plan = ws_alloc<int>(c, "fp2_plan", nc * fp_plan_ints(1024))) && (c->fp2_order = ws_alloc<int>(c, "fp2_order", nc * kN)) &&
          (c->inv_order = ws_alloc<int>(c, "inv_order", nc * kN));
     if (ok && c->sa_pair) {
-        ok = (c->pair_rows[0] = ws_alloc<int>(c, "sa3_rows", nc * 64 * 32)) && (c->pair_rows[1] = ws_alloc<int>(c, "sa4_rows", nc * 16 * 32)) &&
-             (c->pair_meta[0] = reinterpret_cast<int4*>(ws_alloc<int>(c, "sa3_meta", nc * 64 * 4))) &&
-             (c->pair_meta[1] = reinterpret_cast<int4*>(ws_alloc<int>(c, "sa4_meta", nc * 16 * 4))) && (c->pair_cnt = ws_alloc<int>(c, "sa_step_items", 2)) &&
-             (c->pair_chunk[0] = ws_alloc<int>(c, "sa3_chunks", (size_t)sa_pair_chunks((int)nc * 64))) &&
-             (c->pair_chunk[1] = ws_alloc<int>(c, "sa4_chunks", (size_t)sa_pair_chunks((int)nc * 16)));
+        const char* nm[4] = {"sa1", "sa2", "sa3", "sa4"};
+        for (int l = 0; l < 4 && ok; ++l)
+            ok = (c->step_rows[l] = ws_alloc<int>(c, (std::string(nm[l]) + "_rows").c_str(), nc * kS[l] * 32)) &&
+                 (c->step_meta[l] = reinterpret_cast<int4*>(ws_alloc<int>(c, (std::string(nm[l]) + "_meta").c_str(), nc * kS[l] * 4))) &&
+                 (c->step_chunk[l] = ws_alloc<int>(c, (std::string(nm[l]) + "_chunks").c_str(), (size_t)sa_pair_chunks((int)(nc * kS[l]))));
+        ok = ok && (c->step_cnt = ws_alloc<int>(c, "sa_step_items", 4));      // blocks of the last single step's lists, by SA level
     }
     if (ok && c->prec == LSDM_PREC_BF16) {
         // 2-byte elements: ws_alloc<uint16_t>
@@ -1584,9 +1600,15 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             launch_sa(0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), si);
             prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
-            prof_exec(c, K_SA1, nc * xm::SA1);
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
-            if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
+            const bool items1 = c->sa_reg > 0 && np == 2 && c->sa_pair;
+            if (!items1) prof_exec(c, K_SA1, nc * xm::SA1);
+            if (items1) {
+                // (r = 0.1: seven distinct neighbours per group on the bench clouds -- half the blocks)
+                launch_sa_pair_plan(1, nc * kN, kN, kN, c->inv_ball, nullptr, c->step_chunk[0], c->step_rows[0], c->step_meta[0], c->step_cnt, si);
+                launch_sa_r_items(given_objs, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, static_cast<float*>(c->inv_F1), si);
+                prof_exec_dev(c, K_SA1, c->step_cnt, xm::SA1_ITEM, si);
+            } else if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
             else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, si);
         }
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
@@ -1604,9 +1626,16 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si, nullptr, /*scan=*/true);
             launch_memo_src(gw.memo_ball2, (long long)nc * kN, gw.memo_unc, gw.memo_src_list, gw.memo_cnt, si);
             prof_mark(c, K_SA1 + 1, si);
-            launch_sa_u_list(1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
-                             gw.memo_src_list, gw.memo_cnt);
-            prof_exec_dev(c, K_SA1 + 1, gw.memo_cnt, xm::SA2_CENT, si);     // sa2 once per call on the uncrowded source points
+            if (c->sa_pair && gw.memo_rows) {
+                // every uncrowded point's group has fewer than 32 distinct entries: two to a block where they fit (geometry.hip: sa_pair_kernel)
+                launch_sa_pair_plan(1, (int)nc * kN, kN, kN, gw.memo_ball2, nullptr, gw.memo_chunks, gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, si, gw.memo_unc);
+                launch_sa_u_items(1, c->sa_U[2], c->sa_V[2], gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si);
+                prof_exec_dev(c, K_SA1 + 1, gw.memo_cnt + 2, xm::SA2_CENT, si);     // the blocks that ran
+            } else {
+                launch_sa_u_list(1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
+                                 gw.memo_src_list, gw.memo_cnt);
+                prof_exec_dev(c, K_SA1 + 1, gw.memo_cnt, xm::SA2_CENT, si);     // sa2 once per call on the uncrowded source points
+            }
             c->memo_ready = true;
         }
         prof_mark(c, K_NN1, si);

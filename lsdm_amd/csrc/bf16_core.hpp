@@ -337,4 +337,26 @@ __device__ __forceinline__ void layer_lds_pre_h(const __bf16* X, int ldx, int xp
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pooling of a 32-row block that two ball-query groups share (the SA kernels' item lists; geometry.hip: sa_pair_kernel).
+// two maxima at once: lanes 0-31 get max(a[l], a[l + 32]), lanes 32-63 get max(b[l - 32], b[l]) (one swap: afterwards a = [a.lo, b.lo], b = [a.hi, b.hi])
+__device__ __forceinline__ float max_halves2(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+// the pooled row(s) of a split block (PAIR): lanes 0-31 get the maximum over A's rows, lanes 32-63 over B's (an unpaired item: the maximum
+// over all 32 rows in both).  own[g]: register quartet g of this lane's half-wave belongs to A.
+__device__ __forceinline__ float max_split(const f32x16& a, const bool (&own)[4], bool paired) {
+    float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float m4 = fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), fmaxf(a[4 * g + 2], a[4 * g + 3]));
+        ma = fmaxf(ma, own[g] ? m4 : -INFINITY);
+        mb = fmaxf(mb, own[g] ? -INFINITY : m4);
+    }
+    return max_halves2(ma, paired ? mb : ma);
+}
+
+
 }  // namespace lsdm

@@ -114,12 +114,18 @@ __device__ __forceinline__ void relu_split_pair(const f32x16& acc, const float* 
 
 // blob layout (built by api.hip::build_sa_reg_blob), all offsets in bf16 elements / floats:
 //   [W1 frags: C1/32 x KS1 x NP x 512][W2: C2/32 x C1/16 x NP x 512][W3: C3/32 x C2/16 x NP x 512] then fp32 [b1|b2|b3]
-template <int D, int C1, int C2, int C3, int NW, int NP>
+// PAIR (level 1 only, D == 3): the launch walks an item list of launch_sa_pair_plan (geometry.hip) -- two ball-query groups whose distinct
+// neighbours fit into 32 rows together in one block (encoder_u.hip::sa_p_kernel): `ball` = the list's row table (32 source rows per item,
+// numbered over the launch), `pmeta` {source row of centroid A, of centroid B, output row of A | k << 24, of B}, *pcount its length.  A
+// centroid IS one of the source points, so its coordinates are read from src_xyz (new_xyz holds the same floats in centroid order).
+template <int D, int C1, int C2, int C3, int NW, int NP, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void sa_r_kernel(const float* __restrict__ src_xyz,
                                                         const typename FeatT<NP>::type* __restrict__ src_feat,
                                                         const float* __restrict__ new_xyz, const int* __restrict__ ball, int NSRC,
                                                         int S, long long total_centroids, const __bf16* __restrict__ blob_w,
-                                                        const float* __restrict__ blob_b, typename FeatT<NP>::type* __restrict__ out) {
+                                                        const float* __restrict__ blob_b, typename FeatT<NP>::type* __restrict__ out,
+                                                        const int4* __restrict__ pmeta, const int* __restrict__ pcount) {
+    static_assert(!PAIR || D == 3, "item lists: level 1");
     constexpr int KS1 = (D == 3) ? 1 : (D + 16) / 16;          // features (D) + one step holding [dx dy dz 0...]
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
     constexpr int W1E = (C1 / 32) * KS1 * NP * 512, W2E = (C2 / 32) * KS2 * NP * 512, W3E = (C3 / 32) * KS3 * NP * 512;
@@ -142,14 +148,21 @@ __global__ __launch_bounds__(NW * 64) void sa_r_kernel(const float* __restrict__
 
     // each work-group owns one contiguous chunk of centroids, and the chunks of the work-groups of one XCD are adjacent
     // (common.hpp::xcd_remap): the rows a chunk gathers stay in that XCD's L2
-    const long long chunk = ((total_centroids + gridDim.x - 1) / gridDim.x + NW - 1) / NW * NW;
+    const long long total = PAIR ? (long long)*pcount : total_centroids;
+    const long long chunk = ((total + gridDim.x - 1) / gridDim.x + NW - 1) / NW * NW;
     const long long cbeg = (long long)xcd_remap((int)blockIdx.x, (int)gridDim.x) * chunk;
-    const long long cend = cbeg + chunk < total_centroids ? cbeg + chunk : total_centroids;
+    const long long cend = cbeg + chunk < total ? cbeg + chunk : total;
     for (long long cent = cbeg + wave; cent < cend; cent += NW) {
         const long long c = cent / S;                                  // cloud
         const int idx = ball[cent * kNSample + p];
-        const float* xyz = src_xyz + ((size_t)c * NSRC + idx) * 3;
-        const float* cen = new_xyz + (size_t)cent * 3;
+        int4 mt = {0, 0, 0, 0};
+        if constexpr (PAIR) mt = pmeta[cent];
+        const int ka = PAIR ? mt.z >> 24 : 8;                          // A's row quartets
+        const bool paired = ka < 8;
+        const bool own[4] = {h < ka, 2 + h < ka, 4 + h < ka, 6 + h < ka};
+        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z & 0xffffff) : (size_t)cent;
+        const float* xyz = src_xyz + (PAIR ? (size_t)idx : (size_t)c * NSRC + idx) * 3;
+        const float* cen = PAIR ? src_xyz + (size_t)(p < 4 * ka ? mt.x : mt.y) * 3 : new_xyz + (size_t)cent * 3;
         const float dx = xyz[0] - cen[0], dy = xyz[1] - cen[1], dz = xyz[2] - cen[2];
         // ---- layer-1 operand fragments straight from global memory (k-step s, this lane's slots = k 16s + 8h .. +7) -------
         bf16x8 xh[KS1], xl[KS1];
@@ -197,12 +210,17 @@ __global__ __launch_bounds__(NW * 64) void sa_r_kernel(const float* __restrict__
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wh, acc, 0, 0, 0);
             }
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            m = fmaxf(m, __shfl_xor(m, 32));
             // relu(x + b) is monotone in x, so pooling before bias/ReLU is exact
-            if (lane < 32) store1(out + (size_t)cent * C3 + nb * 32 + lane, reluf(m + b3[nb * 32 + lane]));
+            if constexpr (PAIR) {
+                const float m = max_split(acc, own, paired);            // half-wave 0 stores A's row, half-wave 1 B's (unpaired: the same row twice)
+                store1(out + orow * C3 + nb * 32 + p, reluf(m + b3[nb * 32 + p]));
+            } else {
+                float m = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (lane < 32) store1(out + (size_t)cent * C3 + nb * 32 + lane, reluf(m + b3[nb * 32 + lane]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -682,9 +700,9 @@ void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* sr
     if (level == 0) {
         const long long tot = (long long)nc * 1024;
         if (np == 2) hipLaunchKernelGGL((sa_r_kernel<3, 32, 32, 64, 8, 2>), dim3(1024), dim3(512), 0, st, src_xyz, static_cast<const float*>(src_feat),
-                                        new_xyz, ball, 1024, 1024, tot, blob_w, blob_b, static_cast<float*>(out));
+                                        new_xyz, ball, 1024, 1024, tot, blob_w, blob_b, static_cast<float*>(out), nullptr, nullptr);
         else hipLaunchKernelGGL((sa_r_kernel<3, 32, 32, 64, 8, 1>), dim3(1024), dim3(512), 0, st, src_xyz, static_cast<const __bf16*>(src_feat),
-                                new_xyz, ball, 1024, 1024, tot, blob_w, blob_b, static_cast<__bf16*>(out));
+                                new_xyz, ball, 1024, 1024, tot, blob_w, blob_b, static_cast<__bf16*>(out), nullptr, nullptr);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
         if (np == 2) hipLaunchKernelGGL((sa_s_kernel<128, 128, 128, 256, 4, 2>), dim3(512), dim3(256), 0, st, src_xyz, static_cast<const float*>(src_feat),
@@ -694,10 +712,18 @@ void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* sr
     } else {
         const long long tot = (long long)nc * 256;
         if (np == 2) hipLaunchKernelGGL((sa_r_kernel<64, 64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, src_xyz, static_cast<const float*>(src_feat),
-                                        new_xyz, ball, 1024, 256, tot, blob_w, blob_b, static_cast<float*>(out));
+                                        new_xyz, ball, 1024, 256, tot, blob_w, blob_b, static_cast<float*>(out), nullptr, nullptr);
         else hipLaunchKernelGGL((sa_r_kernel<64, 64, 64, 128, 8, 1>), dim3(512), dim3(512), 0, st, src_xyz, static_cast<const __bf16*>(src_feat),
-                                new_xyz, ball, 1024, 256, tot, blob_w, blob_b, static_cast<__bf16*>(out));
+                                new_xyz, ball, 1024, 256, tot, blob_w, blob_b, static_cast<__bf16*>(out), nullptr, nullptr);
     }
+}
+
+// sa1 (bf16x3) over the item list of launch_sa_pair_plan: rows = 32 source rows per item, meta = {centroid rows, output rows}, *count items
+void launch_sa_r_items(const float* src_xyz, const int* rows, const int4* meta, const int* count, const __bf16* blob_w, const float* blob_b, float* out,
+                       hipStream_t st) {
+    // (70 VGPRs against the plain form's 64: three work-groups of 8 waves per CU instead of four)
+    hipLaunchKernelGGL((sa_r_kernel<3, 32, 32, 64, 8, 2, true>), dim3(768), dim3(512), 0, st, src_xyz, static_cast<const float*>(nullptr), src_xyz, rows, 1024, 1024, 0LL,
+                       blob_w, blob_b, out, meta, count);
 }
 
 }  // namespace lsdm

@@ -160,25 +160,6 @@ __device__ __forceinline__ float max_halves(float m) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return fmaxf(a, b);
 }
-// two maxima at once: lanes 0-31 get max(a[l], a[l + 32]), lanes 32-63 get max(b[l - 32], b[l]) (one swap: afterwards a = [a.lo, b.lo], b = [a.hi, b.hi])
-__device__ __forceinline__ float max_halves2(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
-}
-
-// the pooled row(s) of a split block (PAIR): lanes 0-31 get the maximum over A's rows, lanes 32-63 over B's (an unpaired item: the maximum
-// over all 32 rows in both).  own[g]: register quartet g of this lane's half-wave belongs to A.
-__device__ __forceinline__ float max_split(const f32x16& a, const bool (&own)[4], bool paired) {
-    float ma = -INFINITY, mb = -INFINITY;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float m4 = fmaxf(fmaxf(a[4 * g], a[4 * g + 1]), fmaxf(a[4 * g + 2], a[4 * g + 3]));
-        ma = fmaxf(ma, own[g] ? m4 : -INFINITY);
-        mb = fmaxf(mb, own[g] ? -INFINITY : m4);
-    }
-    return max_halves2(ma, paired ? mb : ma);
-}
-
 template <class F, int... Is>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F>
@@ -407,13 +388,15 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
 // through the stack in registers (encoder_reg.hip::sa_r_kernel without its first layer: 72 instead of 102 MFMAs per centroid).
 // `remap` (optional, per cloud NSRC entries): U / V are indexed by remap[position] instead of the position -- the loop-invariant
 // schedule evaluates U, V once per call in SOURCE order and reads them through the step's level-1 FPS order.
-template <int C1, int C2, int C3, int NW, int NP>
+// PAIR: the launch walks an item list of launch_sa_pair_plan (see sa_p_kernel: two groups in one 32-row block) -- `ball` = the list's row table,
+// `pmeta` its V / output rows, *list_count its length; cent_idx, remap, list and src_mod are not read.
+template <int C1, int C2, int C3, int NW, int NP, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                          const int* __restrict__ cent_idx, const int* __restrict__ ball,
                                                          const int* __restrict__ remap, int NSRC, int S, long long total_centroids,
                                                          const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
                                                          float* __restrict__ out, int src_mod, const int* __restrict__ list,
-                                                         const int* __restrict__ list_count) {
+                                                         const int* __restrict__ list_count, const int4* __restrict__ pmeta) {
     // list (optional): the launch covers the centroids list[0 .. *list_count) (global centroid numbers, any order) instead of
     // 0 .. total_centroids -- the loop-invariant schedule's memo of sa2 (api.hip: memo_ready)
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
@@ -433,12 +416,18 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     const int p = lane & 31, h = lane >> 5;
     // 32-bit index arithmetic (a 64-bit division per centroid costs ~60 instructions); the neighbour / centroid indices of a
     // centroid -- two dependent loads when they go through `remap` -- are requested one iteration ahead
-    const int total = list ? *list_count : (int)total_centroids;
+    const int total = (PAIR || list) ? *list_count : (int)total_centroids;
     const XcdRounds sched = xcd_rounds((total + NW - 1) / NW);       // a round = NW centroids, one per wave (common.hpp)
     const int cbeg = sched.first * NW, cstep = sched.stride * NW;
     const int cend = sched.end * NW < total ? sched.end * NW : total;
     int idx_n = 0, ci_n = 0, cent_n = 0;
+    int4 mt_n = {0, 0, 0, 0};
     auto request = [&](int k) {
+        if constexpr (PAIR) {
+            idx_n = ball[(size_t)k * kNSample + p];
+            mt_n = pmeta[k];
+            return;
+        }
         const int ce = list ? list[k] : k;
         const int cc = ce / S;
         cent_n = ce;
@@ -457,7 +446,7 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
     [[maybe_unused]] f32x4 un0[KS2], un1[KS2];
     auto cloud_of = [&](int cent) { return src_mod > 0 ? (cent / S) % src_mod : cent / S; };
     auto request_u = [&]() {        // the rows of the centroid whose indices `request` fetched last
-        const float* urow = U + ((size_t)cloud_of(cent_n) * NSRC + idx_n) * C1 + 8 * h;
+        const float* urow = U + (PAIR ? (size_t)idx_n : (size_t)cloud_of(cent_n) * NSRC + idx_n) * C1 + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS2; ++s) { un0[s] = load4f(urow + 16 * s); un1[s] = load4f(urow + 16 * s + 4); }
     };
@@ -470,8 +459,13 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
         // (src_mod > 0: a launch over the clouds of several steps whose U / V are per-CALL tensors in source order)
         const int c = cloud_of(cent);
         const int idx = idx_n, ci = ci_n;
-        const float* urow = U + ((size_t)c * NSRC + idx) * C1 + 8 * h;
-        const float* vrow = V + ((size_t)c * NSRC + ci) * C1 + 8 * h;
+        const int4 mt = mt_n;
+        const int ka = PAIR ? mt.z >> 24 : 8;              // A's row quartets (sa_p_kernel)
+        const bool paired = ka < 8;
+        const bool own[4] = {h < ka, 2 + h < ka, 4 + h < ka, 6 + h < ka};
+        const size_t orow = PAIR ? (size_t)(h ? mt.w : mt.z & 0xffffff) : (size_t)cent;
+        const float* urow = U + (PAIR ? (size_t)idx : (size_t)c * NSRC + idx) * C1 + 8 * h;
+        const float* vrow = V + (PAIR ? (size_t)(p < 4 * ka ? mt.x : mt.y) : (size_t)c * NSRC + ci) * C1 + 8 * h;
         bf16x8 yh[KS2], yl[KS2];
         {
             f32x4 u0[KS2], u1[KS2], v0[KS2], v1[KS2];
@@ -538,11 +532,15 @@ __global__ __launch_bounds__(NW * 64) void sa_ur_kernel(const float* __restrict_
                 }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], wh, acc, 0, 0, 0);
             }
-            float m = acc[0];
+            float m;
+            if constexpr (PAIR) m = max_split(acc, own, paired);      // half-wave 0 stores A's row, half-wave 1 B's
+            else {
+                m = acc[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            m = max_halves(m);      // both half-waves store the same values: no branch, no LDS round trip
-            out[(size_t)cent * C3 + nb * 32 + p] = reluf(m + b3[nb * 32 + p]);
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                m = max_halves(m);      // both half-waves store the same values: no branch, no LDS round trip
+            }
+            out[orow * C3 + nb * 32 + p] = reluf(m + b3[nb * 32 + p]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1693,7 +1691,7 @@ void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, 
 void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
                       const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count) {
     hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, S, 0LL, blob_w, blob_b, out, src_mod,
-                       list, list_count);
+                       list, list_count, nullptr);
 }
 
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
@@ -1710,7 +1708,7 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
         // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
         // issue-bound -- MFMA and VALU time add -- not latency-bound)
         hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out, src_mod,
-                           nullptr, nullptr);
+                           nullptr, nullptr, nullptr);
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
         hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out, nullptr,
@@ -1718,10 +1716,14 @@ void launch_sa_u(int level, int nc, const float* U, const float* V, const int* c
     }
 }
 
-// sa3 / sa4 over the item list of launch_sa_pair_plan (geometry.hip): rows = 32 U rows per item, meta = {V rows, output rows}, *count items
+// sa2 (level 1: the memo's pass over the source points) / sa3 / sa4 over the item list of launch_sa_pair_plan (geometry.hip): rows = 32 U rows per
+// item, meta = {V rows, output rows}, *count items
 void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
                        const float* blob_b, float* out, hipStream_t st) {
-    if (level == 3)
+    if (level == 1)
+        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2, true>), dim3(512), dim3(512), 0, st, U, V, nullptr, rows, nullptr, 1024, 1024, 0LL, blob_w, blob_b, out, 0,
+                           nullptr, count, meta);
+    else if (level == 3)
         hipLaunchKernelGGL((sa_w_kernel<2, true>), dim3(256), dim3(256), 0, st, U, V, nullptr, rows, 0LL, blob_w, blob_b, out, 0, meta, count);
     else
         hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2, true>), dim3(256), dim3(12 * 64), 0, st, U, V, nullptr, rows, 256, 64, 0LL, blob_w, blob_b, out, meta,

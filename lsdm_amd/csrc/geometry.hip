@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256) void memo_cent_kernel(const int* __restrict__ 
 // clouds): size class = ceil(d / 4) (1 .. 8), then the two-pointer matching that maximises the number of pairs -- the largest class that
 // still has a partner takes the smallest class left -- on the classes' COUNTS (plan_runs: at most 14 runs of (class, class, pairs)), every
 // group finding its run from its rank within its class.  Two passes, no atomics, so that the list's ORDER is a function of the input too:
-// pass 0 -> pairs per chunk; pass 1 -> every chunk adds up the items of the chunks before it and writes its items, [pairs][singles in
+// pass 0 -> blocks per chunk; pass 1 -> every chunk adds up the items of the chunks before it and writes its items, [pairs][singles in
 // index order].
 //   rows  (T1 x 32)  U row of every block row, numbered over the segment (cloud x NSRC + ball entry)
 //   meta  (T1) int4  {V row of A, V row of B, output row of A | k << 24, output row of B}; k = 8: an unpaired item (B = A)
@@ -1050,17 +1050,20 @@ __device__ inline int plan_runs(const int* cnt, Run* runs, int* nruns) {
 }
 }  // namespace sap
 
+// only (optional, one byte per centroid): the groups with a zero get no block (sa2's memo pass: the crowded source points are not evaluated);
+// cent_idx == nullptr: a centroid is source point number (its index within the cloud), as in that pass.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ball, const int* __restrict__ cent_idx, int T1, int S, int NSRC, int CPS,
-                                                      int* __restrict__ chunk_np, int* __restrict__ rows, int4* __restrict__ meta, int* __restrict__ count) {
+                                                      int* __restrict__ chunk_np, int* __restrict__ rows, int4* __restrict__ meta, int* __restrict__ count,
+                                                      const unsigned char* __restrict__ only) {
     __shared__ int wcnt[4][9], wsingle[4], wbefore[4], s_np, s_nruns;
     __shared__ sap::Run runs[sap::MAXRUN];
     const int seg = blockIdx.x / CPS, chunk = blockIdx.x % CPS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int e = chunk * 256 + tid;
-    const bool valid = e < T1;
-    const size_t ge = (size_t)seg * T1 + (valid ? e : 0);
+    const bool valid = e < T1 && (!only || only[(size_t)seg * T1 + e]);
+    const size_t ge = (size_t)seg * T1 + (e < T1 ? e : 0);
     const int4* src = reinterpret_cast<const int4*>(ball + ge * kNSample);
     int4 b[8];
 #pragma unroll
@@ -1076,9 +1079,9 @@ __global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ba
         if (cls == c) rank = __popcll(m & lt);
     }
     if (WRITE) {
-        // items of the chunks before this one (only the last chunk of a segment can be partial)
+        // blocks of the chunks before this one
         int before = 0;
-        for (int k = tid; k < chunk; k += 256) before += 256 - chunk_np[seg * CPS + k];
+        for (int k = tid; k < chunk; k += 256) before += chunk_np[seg * CPS + k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
         if (lane == 0) wbefore[wave] = before;
@@ -1090,10 +1093,12 @@ __global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ba
         int nr = 0;
         s_np = sap::plan_runs(cnt, WRITE ? runs : nullptr, &nr);
         s_nruns = nr;
-        if (!WRITE) chunk_np[blockIdx.x] = s_np;
     }
-    if (!WRITE) return;
-    __syncthreads();
+    const int nvalid = __syncthreads_count(valid);           // (also publishes s_np and the runs)
+    if (!WRITE) {
+        if (tid == 0) chunk_np[blockIdx.x] = nvalid - s_np;  // the chunk's blocks
+        return;
+    }
     for (int w = 0; w < wave; ++w) rank += cls >= 1 && cls <= 7 ? wcnt[w][cls] : 0;
     const int npairs = s_np, nruns = s_nruns;
     const int base = wbefore[0] + wbefore[1] + wbefore[2] + wbefore[3];
@@ -1110,7 +1115,6 @@ __global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ba
     const unsigned long long ms = __ballot(single);
     if (lane == 0) wsingle[wave] = __popcll(ms);
     __syncthreads();
-    const int nvalid = T1 - chunk * 256 < 256 ? T1 - chunk * 256 : 256;
     if (chunk == CPS - 1 && tid == 0) count[seg] = base + nvalid - npairs;
     if (!valid) return;
     if (single) {
@@ -1120,7 +1124,7 @@ __global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ba
     }
     const size_t gi = (size_t)seg * T1 + base + slot;
     const int r0 = (e / S) * NSRC;                           // first U / V row of the centroid's cloud
-    const int vrow = r0 + cent_idx[ge];
+    const int vrow = r0 + (cent_idx ? cent_idx[ge] : e % S);
     const int n4 = single ? 8 : (side ? 8 - kA : kA);        // quartets of rows this group fills
     int4* dst = reinterpret_cast<int4*>(rows + gi * kNSample + (side ? 4 * kA : 0));
 #pragma unroll
@@ -1168,10 +1172,10 @@ void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsign
 
 int sa_pair_chunks(int T1) { return (T1 + 255) / 256; }
 void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_np, int* rows, int4* meta, int* count,
-                         hipStream_t st) {
+                         hipStream_t st, const unsigned char* only) {
     const int cps = sa_pair_chunks(T1);
-    hipLaunchKernelGGL(sa_pair_kernel<false>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count);
-    hipLaunchKernelGGL(sa_pair_kernel<true>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count);
+    hipLaunchKernelGGL(sa_pair_kernel<false>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count, only);
+    hipLaunchKernelGGL(sa_pair_kernel<true>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count, only);
 }
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,

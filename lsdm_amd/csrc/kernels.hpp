@@ -127,10 +127,13 @@ void launch_sa_u(int level, int num_clouds, const float* U, const float* V, cons
 // sa3 / sa4 over ITEM lists (two ball-query groups whose distinct neighbours fit into 32 rows together share a block; geometry.hip: sa_pair_kernel):
 //   launch_sa_pair_plan: `segs` segments of T1 = clouds x S centroids each (ball (segs*T1, 32), cent_idx (segs*T1)) -> rows (segs*T1, 32),
 //                        meta (segs*T1) int4, count (segs); chunk_np: segs * sa_pair_chunks(T1) ints of scratch
-//   launch_sa_u_items  : one segment's stage (level 2 = sa3, 3 = sa4) over its list
+//   launch_sa_u_items  : one segment's stage (level 1 = sa2's memo pass over the source points, 2 = sa3, 3 = sa4) over its list
+//   (only: one byte per centroid, zero = the group gets no block; cent_idx == nullptr: centroid e is point e % S of its cloud)
 int sa_pair_chunks(int T1);
 void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_np, int* rows, int4* meta, int* count,
-                         hipStream_t st);
+                         hipStream_t st, const unsigned char* only = nullptr);
+void launch_sa_r_items(const float* src_xyz, const int* rows, const int4* meta, const int* count, const __bf16* blob_w, const float* blob_b, float* out,
+                       hipStream_t st);      // sa1 (register-chained kernel, first layer included)
 void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
                        const float* blob_b, float* out, hipStream_t st);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)

@@ -608,7 +608,7 @@ def _most_pairs(classes):
 
 def test_sa_item_lists_are_an_exact_cover_with_the_most_pairs():
     """The planner's output itself (geometry.hip: sa_pair_kernel), read back after one scene-encoder call over 18 clouds (degenerate ones among
-    them; 1152 / 288 centroids: whole chunks of 256 and a partial one at both levels): every centroid is in exactly one block; a block's rows are
+    them; 18432 / 4608 / 1152 / 288 centroids at the four SA levels: whole chunks of 256 and, at the last two, a partial one): every centroid is in exactly one block; a block's rows are
     its groups' first rows (A: 4k, B: 32 - 4k) shifted to the cloud's U rows and hold ALL their distinct entries; V rows and output rows are the
     groups' own; and the number of blocks is what the pair-maximising matching gives chunk by chunk."""
     nc = 18
@@ -630,11 +630,11 @@ def test_sa_item_lists_are_an_exact_cover_with_the_most_pairs():
     out = torch.empty(nc, 1024, 3, device=DEV)
     ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), nc, out.data_ptr(), None)
     torch.cuda.synchronize()
-    items = ws(m, "sa_step_items", (2,), torch.int32)
-    for lvl, (S, NSRC, name) in enumerate(((64, 256, "sa3"), (16, 64, "sa4"))):
+    items = ws(m, "sa_step_items", (4,), torch.int32)
+    for lvl, (S, NSRC, name) in enumerate(((1024, 1024, "sa1"), (256, 1024, "sa2"), (64, 256, "sa3"), (16, 64, "sa4"))):
         T1 = nc * S
-        ball = ws(m, "ball%d" % (lvl + 3), (T1, 32), torch.int32).long()
-        cidx = ws(m, "fps_idx%d" % (lvl + 3), (T1,), torch.int32).long()
+        ball = ws(m, "ball%d" % (lvl + 1), (T1, 32), torch.int32).long()
+        cidx = ws(m, "fps_idx%d" % (lvl + 1), (T1,), torch.int32).long()
         rows = ws(m, name + "_rows", (T1, 32), torch.int32).long()
         meta = ws(m, name + "_meta", (T1, 4), torch.int32).long()
         n = int(items[lvl])
@@ -693,9 +693,10 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
             out = torch.empty(nc, 1024, 3, device=DEV)
             ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), nc, out.data_ptr(), None)
             torch.cuda.synchronize()
-            outs[name] = (out.clone(), ws(m, "fp2", (nc, 1024, 128)).clone(), ws(m, "feat3", (nc, 64, 256)).clone(), ws(m, "feat4", (nc, 16, 512)).clone())
+            outs[name] = (out.clone(), ws(m, "fp2", (nc, 1024, 128)).clone(), ws(m, "feat3", (nc, 64, 256)).clone(), ws(m, "feat4", (nc, 16, 512)).clone(),
+                          ws(m, "feat1", (nc, 1024, 64)).clone(), ws(m, "feat2", (nc, 256, 128)).clone())
             if name == "new":
-                items = ws(m, "sa_step_items", (2,), torch.int32).clone()
+                items = ws(m, "sa_step_items", (4,), torch.int32).clone()[2:]       # (by SA level: sa3, sa4)
             del m, ctx
     finally:
         for k, v in keep.items():
@@ -707,6 +708,7 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
     # sa3 / sa4 over the step's item lists (sa_pair_kernel) against one block per ball-query group; the scattered cloud and the line pair up
     # completely, the single-point, zero and two-point clouds (every group = the first 32 points) not at all
     assert torch.equal(outs["new"][2], outs["old"][2]) and torch.equal(outs["new"][3], outs["old"][3]), "sa3 / sa4 differ between item lists and groups"
+    assert torch.equal(outs["new"][4], outs["old"][4]) and torch.equal(outs["new"][5], outs["old"][5]), "sa1 / sa2 differ between item lists and groups"
     assert nc * 64 // 2 <= int(items[0]) <= nc * 64 - 32 and nc * 16 // 2 <= int(items[1]) <= nc * 16 - 8, items
     assert torch.equal(outs["new"][1], outs["old"][1]), "fp2 output differs between fp_d_kernel and fp_pre_kernel"
     assert torch.equal(outs["new"][0], outs["old"][0]), "encoder output differs between the new and the old kernel forms"
