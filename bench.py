@@ -42,10 +42,10 @@ GFLOP_PER_SAMPLE_STEP = 14.58      # strict per-step recompute
 # A profiled STAGE (the reference function it replaces) can be two launches in the bf16x3 mode; the rocprofv3 summary lists
 # them separately (profiles/r01_*_kernel_stats.md), the HIP-event interval of the stage covers both.
 STAGE_KERNELS_BF16X3 = {
-    "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64> (once per call in the loop-invariant schedule)",
+    "sa_kernel<3,32,32,64>": "sa_r_kernel<3,32,32,64> over the item list of sa_pair_kernel (once per call in the loop-invariant schedule)",
     "sa_kernel<64,64,64,128>": "lin_u_kernel<64,64> (U, V per level-1 point; once per call in the loop-invariant schedule) + sa_ur_kernel<64,64,128>; "
                                "in the loop-invariant schedule: once per call the r = 0.2 ball of every source point (ball_query_kernel<1024>, ordered "
-                               "scan) + memo_src_kernel + sa_ur_kernel on the list of uncrowded points (the memo F2), then per GROUP of steps (up to "
+                               "scan) + memo_src_kernel + sa_ur_kernel on the item list of the uncrowded points (the memo F2), then per GROUP of steps (up to "
                                "LSDM_GROUP, default 28 / 32) memo_cent_kernel (copies F2 rows, lists the crowded centroids) + ONE sa_ur_kernel launch "
                                "over that list; avg_launch_ms is per step covered",
     "sa_kernel<128,128,128,256>": "lin_u_kernel<128,128> (U, V per level-2 point) + sa_p_kernel<128,128,256,12> (epilogues software-pipelined against the next block's MFMAs) over the item list of sa_pair_kernel (two ball-query groups per 32-row block where their distinct neighbours fit)",
