@@ -57,6 +57,9 @@ struct Gemm {
                                                   //    kStatCopies private copies [copy][N] (copy = row tile % kStatCopies: the atomics of a column
                                                   //    of a million-row layer would otherwise queue on one address)
     float* asum;                                  // += sum_k A(m, k) per row m of A (the bias gradient next to dW = dZ^T X)
+    // weighted rows (compacted PointNet++ groups, see cg_* below; NULL = every row counts once):
+    const float* rw;                              // csum / csq add rw[m] v and rw[m] v^2 for the values of row m of C
+    const float* kw;                              // A(m, k) is multiplied by kw[k] when loaded (dW = sum_rows w dZ^T X; asum follows)
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
@@ -92,6 +95,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = i < na ? pa[i * aes] : 0.0f;
+        }
+        if (g.kw) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = a_kfast ? k0 + ak0 + i : k0 + ak0;
+                if (i < na) ra[i] *= g.kw[k];
+            }
         }
         const int kb = b_nfast ? (k0 + bk0 < k_hi ? 4 : 0) : max(0, min(4, k_hi - (k0 + bk0)));
         const int nb = b_nfast ? (kb ? bn_n : 0) : (bn_n ? kb : 0);
@@ -149,7 +159,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(Gemm g) {
         if (g.mode == 0) *dst = v;
         else if (g.mode == 1) *dst += v;
         else atomicAdd(dst, v);
-        cs += (double)v; cq += (double)v * (double)v;
+        const double wv = g.rw ? (double)g.rw[gm] : 1.0;
+        cs += wv * (double)v; cq += wv * (double)v * (double)v;
     }
     if (g.csum) {      // (wave-uniform; both half-waves hold 16 rows of the same 32 columns)
         cs += __shfl_xor(cs, 32); cq += __shfl_xor(cq, 32);
@@ -263,7 +274,8 @@ __global__ void bn_relu_fwd_kernel(const float* __restrict__ Z, const float* __r
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, const float* __restrict__ Z,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, long long rows, int C,
-                                                            const unsigned char* __restrict__ keep, double* __restrict__ dbeta, double* __restrict__ dgamma) {
+                                                            const unsigned char* __restrict__ keep, double* __restrict__ dbeta, double* __restrict__ dgamma,
+                                                            const float* __restrict__ roww) {
     __shared__ double part[256][8];
     const int tpr = C >> 2, rpi = 256 / tpr, t = threadIdx.x;
     const int slot = t / tpr, c4 = (t - slot * tpr) * 4;
@@ -290,7 +302,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 for (int j = 0; j < 4; ++j) {
                     bool on = bn_act(z[u][j], mu[j], is[j], ga[j], be[j]) > 0.0f;
                     if (keep && r < hi) on = on && keep[((r >> 10) * C + c4 + j) * 1024 + (r & 1023)];
-                    const float d = on ? g[u][j] * ks : 0.0f;
+                    float d = on ? g[u][j] * ks : 0.0f;
+                    if (roww && r < hi) d *= roww[r];          // (the row stands for roww[r] identical rows)
                     s[j] += d;
                     q[j] += (double)d * (double)((z[u][j] - mu[j]) * is[j]);
                 }
@@ -313,7 +326,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, long long ldg, const float* __restrict__ Z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const double* __restrict__ dbeta, const double* __restrict__ dgamma, long long rows, int C,
-                                    int training, const unsigned char* __restrict__ keep, float* __restrict__ dZ) {
+                                    int training, const unsigned char* __restrict__ keep, float* __restrict__ dZ, long long norm_rows,
+                                    float* __restrict__ gbeta, float* __restrict__ ggamma) {
+    // (the two sums of the reduce pass are also the parameters' gradients: the first work-group adds them, one launch instead of three)
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (gbeta) gbeta[c] += (float)dbeta[c];
+            if (ggamma) ggamma[c] += (float)dgamma[c];
+        }
+    }
     const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = C >> 2;
     if (i4 >= rows * q) return;
@@ -330,15 +351,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dY, long long ldg,
         if (keep) d *= 2.0f;
         if (training) {
             const float xh = (z[j] - mu[j]) * is[j];
-            d -= (float)((dbeta[c + j] + (double)xh * dgamma[c + j]) / (double)rows);
+            d -= (float)((dbeta[c + j] + (double)xh * dgamma[c + j]) / (double)norm_rows);      // (norm_rows: the rows of the batch statistics)
         }
         o[j] = d * ga[j] * is[j];
     }
     *reinterpret_cast<f32x4*>(dZ + r * C + c) = o;
-}
-__global__ void add_f64_to_f32_kernel(const double* src, float* dst, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += (float)src[i];
 }
 
 // ---- GroupNorm(8, 64) of the POSA decoder: per (sample, group) over 8 channels x P points, fused with ReLU ----------------------------
@@ -455,6 +472,102 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const unsigne
     const long long gq = r >> 5;
     dY[i] = arg[gq * C + c] == (unsigned char)(r & 31) ? dout[gq * C + c] : 0.0f;
 }
+// ---- compacted groups ---------------------------------------------------------------------------------------------------------------
+// query_ball_point pads a group with fewer than 32 points in the ball with repeats of its FIRST entry (pointnet2_utils.py:101-104): rows
+// d .. 31 of the group are copies of row 0 through the whole MLP stack -- same input, same pre-activations, and, since the max-pool's
+// gradient goes to the FIRST maximum, none of them ever receives one.  The stack is therefore evaluated on d (+ 1) rows per group: the d
+// distinct ones with weight 1 (row 0 included: it may carry the pool's gradient) and, when d < 32, ONE more copy of row 0 that stands for
+// the 32 - d repeats.  Whatever sums over rows -- BatchNorm's batch statistics, its two backward sums, the weight / bias gradients, the
+// scatter-add into the source features -- takes the weights; everything per row is unchanged.  At the finest level (r = 0.1: 7 distinct
+// neighbours on the bench clouds) the 1.77 M x {32, 32, 64} tensors of a B = 6 step shrink to a quarter.
+//   n[g] = d + (d < 32)
+__global__ void cg_count_kernel(const int* __restrict__ ball, long long groups, int* __restrict__ n) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const int4* b = reinterpret_cast<const int4*>(ball + g * 32);
+    const int first = ball[g * 32];
+    int d = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int4 v = b[k]; d += (v.x != first) + (v.y != first) + (v.z != first) + (v.w != first); }
+    n[g] = d + (d < 32 ? 1 : 0);
+}
+//   off[g] = exclusive prefix sum of n, off[groups] = *total = the compacted rows (one work-group walks the array: 10^3 .. 10^5 groups)
+__global__ __launch_bounds__(1024) void cg_scan_kernel(const int* __restrict__ n, long long groups, int* __restrict__ off, int* __restrict__ total) {
+    __shared__ int wsum[16], carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (long long base = 0; base < groups; base += 1024) {
+        const long long g = base + t;
+        const int v = g < groups ? n[g] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (g < groups) off[g] = before + x - v;
+        __syncthreads();
+        if (t == 1023) carry_s = before + x;
+        __syncthreads();
+    }
+    if (t == 0) { off[groups] = carry_s; *total = carry_s; }
+}
+//   rows of group g: off[g] + k  <-  neighbour k (k < d), then the stand-in of the repeats
+__global__ void cg_fill_kernel(const int* __restrict__ ball, const int* __restrict__ off, long long groups, int* __restrict__ rowsrc, int* __restrict__ rowgrp,
+                               float* __restrict__ roww) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const int o = off[g], nrow = off[g + 1] - o;
+    const int first = ball[g * 32];
+    const int d = nrow == 32 && ball[g * 32 + 31] != first ? 32 : nrow - 1;      // (32 rows: either 32 distinct, or 31 + the stand-in)
+    for (int k = 0; k < nrow; ++k) {
+        rowsrc[o + k] = k < d ? ball[g * 32 + k] : first;
+        rowgrp[o + k] = (int)g;
+        roww[o + k] = k < d ? 1.0f : (float)(32 - d);
+    }
+}
+// G[r, :] = [xyz[c, j] - new_xyz[g]  ||  feat[c, j, :]],  j = rowsrc[r], g = rowgrp[r], c = g / S
+__global__ void group_fwd_c_kernel(const float* __restrict__ xyz, const float* __restrict__ feat, const float* __restrict__ new_xyz, const int* __restrict__ rowsrc,
+                                   const int* __restrict__ rowgrp, int NS, int S, int D, float* __restrict__ G, long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = 3 + D;
+    if (i >= rows * W) return;
+    const long long r = i / W; const int col = (int)(i - r * W);
+    const long long cs = rowgrp[r], c = cs / S;
+    const int j = rowsrc[r];
+    G[i] = col < 3 ? xyz[(c * NS + j) * 3 + col] - new_xyz[cs * 3 + col] : feat[(c * NS + j) * D + (col - 3)];
+}
+// d feat[c, j, :] += roww[r] dG[r, 3:]
+__global__ void group_bwd_c_kernel(const float* __restrict__ dG, const int* __restrict__ rowsrc, const int* __restrict__ rowgrp, const float* __restrict__ roww, int NS,
+                                   int S, int D, float* __restrict__ dfeat, long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const long long r = i / D; const int col = (int)(i - r * D);
+    const long long c = rowgrp[r] / S;
+    atomicAdd(dfeat + (c * NS + rowsrc[r]) * D + col, roww[r] * dG[r * (3 + D) + 3 + col]);
+}
+// max over the group's rows (the stand-in equals row 0 and never wins the strict comparison); arg = position within the group = the k of the
+// uncompacted group
+__global__ void maxpool_fwd_c_kernel(const float* __restrict__ Y, int C, const int* __restrict__ off, float* __restrict__ out, unsigned char* __restrict__ arg,
+                                     long long groups) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    const long long gq = i / C; const int c = (int)(i - gq * C);
+    const long long o = off[gq]; const int n = off[gq + 1] - (int)o;
+    float m = Y[o * C + c]; int a = 0;
+    for (int k = 1; k < n; ++k) { const float v = Y[(o + k) * C + c]; if (v > m) { m = v; a = k; } }
+    out[i] = m; arg[i] = (unsigned char)a;
+}
+__global__ void maxpool_bwd_c_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ arg, int C, const int* __restrict__ off,
+                                     const int* __restrict__ rowgrp, float* __restrict__ dY, long long rows) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long long r = i / C; const int c = (int)(i - r * C);
+    const long long gq = rowgrp[r];
+    dY[i] = arg[gq * C + c] == (unsigned char)(r - off[gq]) ? dout[gq * C + c] : 0.0f;
+}
 // H[(c, n), off + ch] = sum_j w[(c, n), j] p2[c, idx[(c, n), j], ch]      (pointnet2_utils.py:299-303)
 __global__ void interp_fwd_kernel(const float* __restrict__ p2, int S, int D2, const int* __restrict__ idx, const float* __restrict__ w, int N, float* __restrict__ H,
                                   int ldh, int off, long long rows) {
@@ -552,14 +665,24 @@ __global__ void pweight_fwd_kernel(const float* __restrict__ pcd, const float* _
 }
 __global__ void pweight_bwd_kernel(const float* __restrict__ dP, const float* __restrict__ pcd, const float* __restrict__ w, float* __restrict__ dpcd,
                                    float* __restrict__ dw, long long total) {
+    // (a block of 256 never straddles two samples: kO kN 3 = 108 x 256 -- its nine partial sums of dw go through LDS, nine global atomics per
+    // block instead of one per element onto 54 addresses: 347 -> 12 us at B = 6)
+    static_assert((kO * kN * 3) % 256 == 0, "a block of 256 elements belongs to one sample");
+    __shared__ float part[kO];
+    if (threadIdx.x < kO) part[threadIdx.x] = 0.0f;
+    __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
     const int per = kO * kN * 3;
-    const int b = (int)(i / per), f = (int)(i - (long long)b * per);
-    const int j = f / kO, o = f - j * kO;
-    const size_t src = ((size_t)b * kO + o) * (kN * 3) + j;
-    dpcd[src] += dP[i] * w[b * kO + o];
-    atomicAdd(dw + b * kO + o, dP[i] * pcd[src]);
+    const int b = (int)(((long long)blockIdx.x * blockDim.x) / per);
+    if (i < total) {
+        const int f = (int)(i - (long long)b * per);
+        const int j = f / kO, o = f - j * kO;
+        const size_t src = ((size_t)b * kO + o) * (kN * 3) + j;
+        dpcd[src] += dP[i] * w[b * kO + o];
+        atomicAdd(&part[o], dP[i] * pcd[src]);
+    }
+    __syncthreads();
+    if (threadIdx.x < kO) atomicAdd(dw + b * kO + threadIdx.x, part[threadIdx.x]);
 }
 // pcd_attention collapsed to ONE query row per (b, o) (Q7): 12 heads of dim 1 over the 1024 points of the slot, scale 1.
 // q2 (BO,12), k2 / v2 (BO*1024,12) hold their biases.  One work-group per (b, o); a (BO*1024,12) is kept for the backward.
@@ -769,6 +892,14 @@ struct lsdm_train {
     std::vector<std::function<void()>> tape;
     std::map<std::string, std::pair<void*, int64_t>> named;     // intermediates of the last step kept for the tests (lsdm_train_tensor)
     bool failed = false;
+    // compacted rows of the four PointNet++ levels of the step: counted on the device at the top of the step, read here just before the encoder
+    int* h_rows = nullptr;          // pinned
+    hipEvent_t ev_rows = nullptr;
+    // the geometry of a step (FPS: 54 dependent chains of 1360 steps at B = 6, half a millisecond on an otherwise idle chip; ball queries; the
+    // row layout) runs on a stream of its own next to the conditioning branches, which do not read it
+    hipStream_t geo = nullptr;
+    hipEvent_t ev_in = nullptr, ev_geo = nullptr;
+    int compact = getenv("LSDM_TRAIN_COMPACT") ? atoi(getenv("LSDM_TRAIN_COMPACT")) : 1;    // A/B switch: 0 = every group on its 32 rows
 };
 
 namespace {
@@ -847,9 +978,9 @@ Par par(lsdm_train* s, const std::string& name, int64_t numel) {
 
 void gemm(lsdm_train* s, const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C, long long scm, long long scn,
           int M, int N, int K, const float* bias, int mode, int batch = 1, long long bA = 0, long long bB = 0, long long bC = 0, int ksplit = 1,
-          double* csum = nullptr, double* csq = nullptr, float* asum = nullptr) {
+          double* csum = nullptr, double* csq = nullptr, float* asum = nullptr, const float* rw = nullptr, const float* kw = nullptr) {
     if (s->failed || M <= 0 || N <= 0) return;
-    Gemm g{A, B, C, bias, M, N, K, sam, sak, sbk, sbn, scm, scn, bA, bB, bC, ksplit, 0, mode, csum, csq, asum};
+    Gemm g{A, B, C, bias, M, N, K, sam, sak, sbk, sbn, scm, scn, bA, bB, bC, ksplit, 0, mode, csum, csq, asum, rw, kw};
     g.kchunk = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
     g.ksplit = (K + g.kchunk - 1) / g.kchunk;
     if (g.ksplit < 1) g.ksplit = 1;
@@ -858,11 +989,13 @@ void gemm(lsdm_train* s, const float* A, long long sam, long long sak, const flo
 
 // Y = X W^T + b on (rows, K) -> (rows, N) views
 // (csum / csq: the per-channel sum and sum of squares of Z in double, accumulated by the same launch -- batch statistics)
-void linear_fwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const Ten& Z, double* csum = nullptr, double* csq = nullptr) {
-    gemm(s, X.d, X.ld, 1, W.w, 1, X.C, Z.d, Z.ld, 1, (int)X.rows, Z.C, X.C, b.w, 0, 1, 0, 0, 0, 1, csum, csq);
+// (roww: weights of the rows in the statistics -- compacted groups)
+void linear_fwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const Ten& Z, double* csum = nullptr, double* csq = nullptr, const float* roww = nullptr) {
+    gemm(s, X.d, X.ld, 1, W.w, 1, X.C, Z.d, Z.ld, 1, (int)X.rows, Z.C, X.C, b.w, 0, 1, 0, 0, 0, 1, csum, csq, nullptr, roww);
 }
 // dX += dZ W ; dW += dZ^T X ; db += colsum(dZ)      (dZ dense (rows, N))
-void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const float* dZ, int N, bool need_dx = true) {
+// (roww: a row stands for roww[r] identical rows -- the weight and bias gradients sum over all of them, the data gradient is per row)
+void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const float* dZ, int N, bool need_dx = true, const float* roww = nullptr) {
     if (s->failed) return;
     const int rows = (int)X.rows, K = X.C;
     if (need_dx && X.g) {
@@ -883,9 +1016,10 @@ void linear_bwd(lsdm_train* s, const Ten& X, const Par& W, const Par& b, const f
         const int most = (rows + 127) / 128;
         if (ksplit > most) ksplit = most;
         if (ksplit < 1) ksplit = 1;
-        gemm(s, dZ, 1, N, X.d, X.ld, 1, W.g, K, 1, N, K, rows, nullptr, 2, 1, 0, 0, 0, ksplit, nullptr, nullptr, b.g);
+        gemm(s, dZ, 1, N, X.d, X.ld, 1, W.g, K, 1, N, K, rows, nullptr, 2, 1, 0, 0, 0, ksplit, nullptr, nullptr, b.g, nullptr, roww);
     }
     if (b.g && !W.g) {
+        if (roww) { tfail(s, LSDM_ERR_STATE, "training: bias-only gradient of a layer on weighted rows"); return; }
         const int ry = rows > 2048 ? (rows + 2047) / 2048 : 1;
         hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ry), dim3(256), 0, s->st, dZ, (long long)N, (long long)rows, N, b.g);
     }
@@ -911,8 +1045,10 @@ Ten dense(lsdm_train* s, const Ten& X, const std::string& name, int N, int act, 
 }
 
 // 1x1 conv + BatchNorm + ReLU (+ dropout keep-mask) on (rows, K) -> (rows, N)
+// roww / norm_rows: the rows are COMPACTED groups (cg_* kernels): row r stands for roww[r] identical rows of the norm_rows the layer has in the
+// reference -- batch statistics and every gradient that sums over rows weigh it so, everything per row is unchanged
 Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std::string& bn, int N, int training, const unsigned char* keep = nullptr,
-                 bool need_dx = true, bool lazy_out = false) {
+                 bool need_dx = true, bool lazy_out = false, const float* roww = nullptr, long long norm_rows = 0) {
     const Par W = par(s, conv + ".weight", (int64_t)N * X.C), b = par(s, conv + ".bias", N);
     const Par gam = par(s, bn + ".weight", N), bet = par(s, bn + ".bias", N);
     const Par rm = par(s, bn + ".running_mean", N), rv = par(s, bn + ".running_var", N);
@@ -920,29 +1056,32 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
     if (s->failed) return Y;
     if (N % 4 != 0 || N > 1024 || 256 % (N / 4) != 0) { tfail(s, LSDM_ERR_ARG, "training: BatchNorm width %d (a power of two in 32 .. 1024 expected)", N); return Y; }
     const long long rows = X.rows;
+    const long long nrows = roww ? norm_rows : rows;
     float* Z = talloc<float>(s, (size_t)rows * N);
     float* mean = talloc<float>(s, N);
     float* invstd = talloc<float>(s, N);
     Ten Zt; Zt.d = Z; Zt.rows = rows; Zt.C = N; Zt.ld = N;
-    // (work-groups of the backward reduction: 512 rows each, at most ~8 per CU)
-    const int ry4 = (int)std::min<long long>(2048, std::max<long long>(1, (rows + 511) / 512));
+    // (work-groups of the backward reduction: 512 rows each for the large tensors -- bandwidth-bound, at most ~8 per CU.  Smaller tensors are
+    // bound by the work-group's serial passes (256 / (N / 4) x 4 rows each: 46 work-groups of 64 passes left the coarsest level at 126 us per
+    // launch) on one side and by the 2 N double atomics every work-group ends with on the other (864 work-groups on 55 k rows: 87 us against 52
+    // with 108): 256 rows per work-group from 40 k rows, 64 below)
+    const int per_wg = rows >= 200000 ? 512 : (rows >= 40000 ? 256 : 64);
+    const int ry4 = (int)std::min<long long>(2048, std::max<long long>(1, (rows + per_wg - 1) / per_wg));
     double* st2 = talloc<double>(s, 2 * (size_t)N * kStatCopies, true);
     if (!st2) return Y;
     double* const stq = st2 + (size_t)N * kStatCopies;
-    linear_fwd(s, X, W, b, Zt, training ? st2 : nullptr, training ? stq : nullptr);      // batch statistics: by-product of the GEMM
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, st2, stq, rows, N, training, const_cast<float*>(rm.w), const_cast<float*>(rv.w),
+    linear_fwd(s, X, W, b, Zt, training ? st2 : nullptr, training ? stq : nullptr, roww);      // batch statistics: by-product of the GEMM
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, st2, stq, nrows, N, training, const_cast<float*>(rm.w), const_cast<float*>(rv.w),
                        mean, invstd);
     hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Z, mean, invstd, gam.w, bet.w, Y.d, Y.ld, rows, N, keep);
     s->tape.push_back([=]() {
         float* dZ = talloc<float>(s, (size_t)rows * N);
         double* red = talloc<double>(s, 2 * (size_t)N, true);
         if (!dZ || !red) return;
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ry4), dim3(256), 0, s->st, Y.g, Z, mean, invstd, gam.w, bet.w, rows, N, keep, red, red + N);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ry4), dim3(256), 0, s->st, Y.g, Z, mean, invstd, gam.w, bet.w, rows, N, keep, red, red + N, roww);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Y.g, Y.ld, Z, mean, invstd, gam.w, bet.w, red, red + N, rows, N,
-                           training, keep, dZ);
-        if (bet.g) hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, red, bet.g, N);
-        if (gam.g) hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, red + N, gam.g, N);
-        linear_bwd(s, X, W, b, dZ, N, need_dx);
+                           training, keep, dZ, nrows, bet.g, gam.g);
+        linear_bwd(s, X, W, b, dZ, N, need_dx, roww);
     });
     return Y;
 }
@@ -974,6 +1113,11 @@ int lsdm_train_destroy(lsdm_train* s) {
     for (auto& c : s->zchunks) (void)hipFree(c.base);
     if (s->zl_ptrs) (void)hipFree(s->zl_ptrs);
     if (s->zl_ns) (void)hipFree(s->zl_ns);
+    if (s->h_rows) (void)hipHostFree(s->h_rows);
+    if (s->ev_rows) (void)hipEventDestroy(s->ev_rows);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    if (s->ev_geo) (void)hipEventDestroy(s->ev_geo);
+    if (s->geo) (void)hipStreamDestroy(s->geo);
     if (prev >= 0) (void)hipSetDevice(prev);
     delete s;
     return LSDM_OK;
@@ -1057,6 +1201,50 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
     (void)hipMemsetAsync(losses, 0, 3 * sizeof(float), st);
 
     auto body = [&]() {
+    // ---- geometry of the scene encoder first (it depends on the inputs only): FPS, ball queries and -- with compacted groups -- the row
+    // layout of the four levels, whose row counts travel to the host while the conditioning branches below are being enqueued
+    static const int S[4] = {1024, 256, 64, 16}, NS[4] = {1024, 1024, 256, 64};
+    static const double RAD[4] = {0.1, 0.2, 0.4, 0.8};
+    int* idx[4]; float* xyz[4]; int* ball[4];
+    int* cg_off[4] = {}; int* cg_src[4] = {}; int* cg_grp[4] = {}; float* cg_w[4] = {};
+    const bool compact = s->compact != 0;
+    {
+        for (int l = 0; l < 4; ++l) {
+            idx[l] = talloc<int>(s, (size_t)nc * S[l]);
+            xyz[l] = talloc<float>(s, (size_t)nc * S[l] * 3);
+            ball[l] = talloc<int>(s, (size_t)nc * S[l] * 32);
+        }
+        if (s->failed) return;
+        if (!s->geo && (hipStreamCreateWithFlags(&s->geo, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&s->ev_geo, hipEventDisableTiming) != hipSuccess)) { tfail(s, LSDM_ERR_HIP, "training: geometry stream"); return; }
+        // (the inputs and the arena's previous contents belong to the caller's stream: the side stream starts behind it)
+        (void)hipEventRecord(s->ev_in, st);
+        (void)hipStreamWaitEvent(s->geo, s->ev_in, 0);
+        hipStream_t const sg = s->geo;
+        launch_fps_chain(given_objs, fps_starts, nc, nc, idx, xyz, sg);
+        const float* lx[5] = {given_objs, xyz[0], xyz[1], xyz[2], xyz[3]};
+        for (int l = 0; l < 4; ++l) launch_ball_query(lx[l], lx[l + 1], nc, NS[l], S[l], (float)(RAD[l] * RAD[l]), ball[l], 0, sg);
+        if (compact) {
+            if (!s->h_rows && hipHostMalloc(reinterpret_cast<void**>(&s->h_rows), 4 * sizeof(int)) != hipSuccess) { tfail(s, LSDM_ERR_HIP, "training: pinned row counts"); return; }
+            if (!s->ev_rows && hipEventCreateWithFlags(&s->ev_rows, hipEventDisableTiming) != hipSuccess) { tfail(s, LSDM_ERR_HIP, "training: event"); return; }
+            int* totals = talloc<int>(s, 4);
+            for (int l = 0; l < 4; ++l) {
+                const long long groups = (long long)nc * S[l];
+                int* n = talloc<int>(s, (size_t)groups);
+                cg_off[l] = talloc<int>(s, (size_t)groups + 1);
+                cg_src[l] = talloc<int>(s, (size_t)groups * 32);          // (upper bound: the counts are not on the host yet)
+                cg_grp[l] = talloc<int>(s, (size_t)groups * 32);
+                cg_w[l] = talloc<float>(s, (size_t)groups * 32);
+                if (s->failed) return;
+                hipLaunchKernelGGL(cg_count_kernel, dim3(nblk(groups)), dim3(256), 0, sg, ball[l], groups, n);
+                hipLaunchKernelGGL(cg_scan_kernel, dim3(1), dim3(1024), 0, sg, n, groups, cg_off[l], totals + l);
+                hipLaunchKernelGGL(cg_fill_kernel, dim3(nblk(groups)), dim3(256), 0, sg, ball[l], cg_off[l], groups, cg_src[l], cg_grp[l], cg_w[l]);
+            }
+            (void)hipMemcpyAsync(s->h_rows, totals, 4 * sizeof(int), hipMemcpyDeviceToHost, sg);
+            (void)hipEventRecord(s->ev_rows, sg);
+        }
+        (void)hipEventRecord(s->ev_geo, sg);
+    }
     // ---- forward --------------------------------------------------------------------------------------------------------------------
     // x_t = q_sample(x_start, t, noise)
     Ten xt = make(s, (long long)B * kN, 3, false);
@@ -1116,8 +1304,8 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
             // d u3[(b, c), n] += sum_j dZ[(b, n), j] W[j, c]   ->  C(m = n, n = c) with strides (1, 1024)
             gemm(s, dZ, 128, 1, W.w, 256, 1, u3.g, 1, 1024, kN, 256, 128, nullptr, 1, B, (long long)kN * 128, 0, 256LL * 1024);
             // dW[j, c] += sum_{b, n} dZ[(b, n), j] u3[(b, c), n]
-            for (int b = 0; b < B; ++b)
-                gemm(s, dZ + (size_t)b * kN * 128, 1, 128, u3.d + (size_t)b * 256 * 1024, 1, 1024, W.g, 256, 1, 128, 256, kN, nullptr, 2);
+            // (one batched launch, the samples' partial sums added atomically: B launches of 8 work-groups took 49 us each)
+            gemm(s, dZ, 1, 128, u3.d, 1, 1024, W.g, 256, 1, 128, 256, kN, nullptr, 2, B, (long long)kN * 128, 256LL * 1024, 0);
             hipLaunchKernelGGL(colsum_kernel, dim3(2, 8), dim3(256), 0, st, dZ, 128LL, (long long)B * kN, 128, bb.g);
         });
     }
@@ -1164,45 +1352,58 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
     // 7. PointNet++ scene encoder on the B*9 clouds
     Ten pcd;                                         // (nc*1024, 3)
     {
-        static const int S[4] = {1024, 256, 64, 16}, NS[4] = {1024, 1024, 256, 64}, CH[4][3] = {{32, 32, 64}, {64, 64, 128}, {128, 128, 256}, {256, 256, 512}};
-        static const double RAD[4] = {0.1, 0.2, 0.4, 0.8};
-        int* idx[4]; float* xyz[4]; int* ball[4];
-        for (int l = 0; l < 4; ++l) {
-            idx[l] = talloc<int>(s, (size_t)nc * S[l]);
-            xyz[l] = talloc<float>(s, (size_t)nc * S[l] * 3);
-            ball[l] = talloc<int>(s, (size_t)nc * S[l] * 32);
+        static const int CH[4][3] = {{32, 32, 64}, {64, 64, 128}, {128, 128, 256}, {256, 256, 512}};
+        (void)hipStreamWaitEvent(st, s->ev_geo, 0);      // the geometry (side stream) from here on
+        long long crows[4] = {0, 0, 0, 0};
+        if (compact) {
+            if (hipEventSynchronize(s->ev_rows) != hipSuccess) { tfail(s, LSDM_ERR_HIP, "training: row counts"); return; }
+            for (int l = 0; l < 4; ++l) {
+                crows[l] = s->h_rows[l];
+                if (crows[l] < (long long)nc * S[l] || crows[l] > (long long)nc * S[l] * 32) { tfail(s, LSDM_ERR_STATE, "training: %lld compacted rows at level %d", crows[l], l + 1); return; }
+            }
         }
-        if (s->failed) return;
-        launch_fps_chain(given_objs, fps_starts, nc, nc, idx, xyz, st);
         const float* lxyz[5] = {given_objs, xyz[0], xyz[1], xyz[2], xyz[3]};
-        for (int l = 0; l < 4; ++l) launch_ball_query(lxyz[l], lxyz[l + 1], nc, NS[l], S[l], (float)(RAD[l] * RAD[l]), ball[l], 0, st);
         Ten feat[5];
         feat[0].d = const_cast<float*>(given_objs); feat[0].rows = (long long)nc * kN; feat[0].C = 3; feat[0].ld = 3;      // l0_points = xyz (pointnet2.py:63-64)
         for (int l = 0; l < 4; ++l) {
             const std::string pre = "pcd_backbone.sa" + std::to_string(l + 1);
             const int D = feat[l].C;
-            const long long rows = (long long)nc * S[l] * 32;
+            const long long full_rows = (long long)nc * S[l] * 32;
+            const long long rows = compact ? crows[l] : full_rows;
+            const float* roww = compact ? cg_w[l] : nullptr;
+            const int* rsrc = cg_src[l]; const int* rgrp = cg_grp[l]; const int* goff = cg_off[l];
             Ten G = make(s, rows, 3 + D, l > 0, /*lazy: written by the first conv's data gradient*/ true);
             const Ten src = feat[l];
             const int* bl = ball[l];
-            if (!s->failed) hipLaunchKernelGGL(group_fwd_kernel, dim3(nblk(rows * (3 + D))), dim3(256), 0, st, lxyz[l], src.d, lxyz[l + 1], bl, NS[l], S[l], D, G.d, rows);
+            const int NSl = NS[l], Sl = S[l];
+            if (!s->failed) {
+                if (compact) hipLaunchKernelGGL(group_fwd_c_kernel, dim3(nblk(rows * (3 + D))), dim3(256), 0, st, lxyz[l], src.d, lxyz[l + 1], rsrc, rgrp, NSl, Sl, D, G.d, rows);
+                else hipLaunchKernelGGL(group_fwd_kernel, dim3(nblk(rows * (3 + D))), dim3(256), 0, st, lxyz[l], src.d, lxyz[l + 1], bl, NSl, Sl, D, G.d, rows);
+            }
             if (l > 0) {
-                const int NSl = NS[l], Sl = S[l];
-                s->tape.push_back([=]() { hipLaunchKernelGGL(group_bwd_kernel, dim3(nblk(rows * D)), dim3(256), 0, st, G.g, bl, NSl, Sl, D, src.g, rows); });
+                s->tape.push_back([=]() {
+                    if (compact) hipLaunchKernelGGL(group_bwd_c_kernel, dim3(nblk(rows * D)), dim3(256), 0, st, G.g, rsrc, rgrp, roww, NSl, Sl, D, src.g, rows);
+                    else hipLaunchKernelGGL(group_bwd_kernel, dim3(nblk(rows * D)), dim3(256), 0, st, G.g, bl, NSl, Sl, D, src.g, rows);
+                });
             }
             Ten h = G;
             for (int i = 0; i < 3; ++i)
                 h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), CH[l][i], training, nullptr, !(l == 0 && i == 0),
-                                 /*lazy: consumed by the next conv / the max-pool, whose backward passes write every element*/ true);
+                                 /*lazy: consumed by the next conv / the max-pool, whose backward passes write every element*/ true, roww, full_rows);
             Ten out = make(s, (long long)nc * S[l], CH[l][2]);
             unsigned char* arg = talloc<unsigned char>(s, (size_t)nc * S[l] * CH[l][2]);
             const int Cc = CH[l][2];
             const long long groups = (long long)nc * S[l];
-            if (!s->failed) hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(groups * Cc)), dim3(256), 0, st, h.d, Cc, out.d, arg, groups);
+            if (!s->failed) {
+                if (compact) hipLaunchKernelGGL(maxpool_fwd_c_kernel, dim3(nblk(groups * Cc)), dim3(256), 0, st, h.d, Cc, goff, out.d, arg, groups);
+                else hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(groups * Cc)), dim3(256), 0, st, h.d, Cc, out.d, arg, groups);
+            }
             s->named["sa" + std::to_string(l + 1) + ".arg"] = {arg, (int64_t)(groups * Cc)};
             const Ten hl = h;
             s->tape.push_back([=]() {
-                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, hl.g, rows);      // (stores every element)
+                // (stores every element)
+                if (compact) hipLaunchKernelGGL(maxpool_bwd_c_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, goff, rgrp, hl.g, rows);
+                else hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, hl.g, rows);
                 if (hl.gs) *hl.gs = 1;
             });
             feat[l + 1] = out;

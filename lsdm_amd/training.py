@@ -186,10 +186,10 @@ def training_losses(diffusion, model, x_start, mask, t, given_objs, given_cats, 
         all_terms, out, out_cat = run()
         loss = all_terms[0]
     if training:
-        with torch.no_grad():
-            for name, buf in model.named_buffers():
-                if name.endswith("num_batches_tracked"):
-                    buf += 1
+        with torch.no_grad():      # (one multi-tensor launch for the 23 counters)
+            counters = [buf for name, buf in model.named_buffers() if name.endswith("num_batches_tracked")]
+            if counters:
+                torch._foreach_add_(counters, 1)
     if training or want_grads:   # the sampling context re-reads the parameters after an optimizer step / running-statistics update
         model._dirty = True      # (a pure evaluation changes neither)
     model.saved_cat = out_cat

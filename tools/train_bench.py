@@ -28,7 +28,7 @@ if not a.host_rng:
 model.load_state_dict(make_synthetic_state_dict(seed=0))
 model.requires_grad_(True)
 model.train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)        # (as lsdm_amd/run/train_sdm.py builds it)
 B = a.batch
 bt = {k: v.to(dev) for k, v in make_synthetic_batch(B, seed=3, num_objects=8).items()}
 x_start = bt["given_objs"][:, 1].clone()
