@@ -560,13 +560,69 @@ __global__ void maxpool_fwd_c_kernel(const float* __restrict__ Y, int C, const i
     for (int k = 1; k < n; ++k) { const float v = Y[(o + k) * C + c]; if (v > m) { m = v; a = k; } }
     out[i] = m; arg[i] = (unsigned char)a;
 }
-__global__ void maxpool_bwd_c_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ arg, int C, const int* __restrict__ off,
-                                     const int* __restrict__ rowgrp, float* __restrict__ dY, long long rows) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C) return;
-    const long long r = i / C; const int c = (int)(i - r * C);
-    const long long gq = rowgrp[r];
-    dY[i] = arg[gq * C + c] == (unsigned char)(r - off[gq]) ? dout[gq * C + c] : 0.0f;
+// The LAST layer of a level's stack feeds the max-pool only: its output gradient is dout[g, c] at the row the pool picked and zero elsewhere.
+// Instead of materialising that (rows, C) tensor (maxpool_bwd_c_kernel) and reading it twice, BatchNorm's backward takes it from (dout, arg):
+// the two sums run over the groups x C picked entries, the apply pass forms each row's gradient on the fly.
+struct PoolGrad { const float* dout; const unsigned char* arg; const int* off; const int* rowgrp; long long groups; };
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(PoolGrad pg, const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int C, double* __restrict__ dbeta,
+                                                                 double* __restrict__ dgamma) {
+    // thread = (group slot, channel): 256 / C' group slots per pass with C' = min(C, 256) channels side by side, grid.y = channel blocks of 256
+    __shared__ double ps[256], pq[256];
+    const int cw = C < 256 ? C : 256, slots = 256 / cw;
+    const int c = blockIdx.y * 256 + (int)threadIdx.x % cw, slot = (int)threadIdx.x / cw;
+    const long long per = (pg.groups + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(pg.groups, lo + per);
+    double s1 = 0.0, s2 = 0.0;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    for (long long g = lo + slot; g < hi; g += slots) {
+        const long long r = (long long)pg.off[g] + pg.arg[g * C + c];
+        const float z = Z[r * C + c];
+        if (bn_act(z, mu, is, ga, be) > 0.0f) {                  // (the picked row is one of the group's distinct rows: weight 1)
+            const float d = pg.dout[g * C + c];
+            s1 += d; s2 += (double)d * (double)((z - mu) * is);
+        }
+    }
+    ps[threadIdx.x] = s1; pq[threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < cw) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < slots; ++k) { a += ps[k * cw + threadIdx.x]; b += pq[k * cw + threadIdx.x]; }
+        atomicAdd(dbeta + c, a); atomicAdd(dgamma + c, b);
+    }
+}
+__global__ void bn_bwd_apply_pool_kernel(PoolGrad pg, const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, const double* __restrict__ dbeta,
+                                         const double* __restrict__ dgamma, long long rows, int C, int training, float* __restrict__ dZ, long long norm_rows,
+                                         float* __restrict__ gbeta, float* __restrict__ ggamma) {
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (gbeta) gbeta[c] += (float)dbeta[c];
+            if (ggamma) ggamma[c] += (float)dgamma[c];
+        }
+    }
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = C >> 2;
+    if (i4 >= rows * q) return;
+    const long long r = i4 / q; const int c = (int)(i4 - r * q) * 4;
+    const long long g = pg.rowgrp[r];
+    const unsigned char k = (unsigned char)(r - pg.off[g]);
+    const uchar4 a4 = *reinterpret_cast<const uchar4*>(pg.arg + g * C + c);
+    const unsigned char a[4] = {a4.x, a4.y, a4.z, a4.w};
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * C + c);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c), ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool on = a[j] == k && bn_act(z[j], mu[j], is[j], ga[j], be[j]) > 0.0f;
+        float d = on ? pg.dout[g * C + c + j] : 0.0f;
+        if (training) {
+            const float xh = (z[j] - mu[j]) * is[j];
+            d -= (float)((dbeta[c + j] + (double)xh * dgamma[c + j]) / (double)norm_rows);
+        }
+        o[j] = d * ga[j] * is[j];
+    }
+    *reinterpret_cast<f32x4*>(dZ + r * C + c) = o;
 }
 // H[(c, n), off + ch] = sum_j w[(c, n), j] p2[c, idx[(c, n), j], ch]      (pointnet2_utils.py:299-303)
 __global__ void interp_fwd_kernel(const float* __restrict__ p2, int S, int D2, const int* __restrict__ idx, const float* __restrict__ w, int N, float* __restrict__ H,
@@ -1048,7 +1104,7 @@ Ten dense(lsdm_train* s, const Ten& X, const std::string& name, int N, int act, 
 // roww / norm_rows: the rows are COMPACTED groups (cg_* kernels): row r stands for roww[r] identical rows of the norm_rows the layer has in the
 // reference -- batch statistics and every gradient that sums over rows weigh it so, everything per row is unchanged
 Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std::string& bn, int N, int training, const unsigned char* keep = nullptr,
-                 bool need_dx = true, bool lazy_out = false, const float* roww = nullptr, long long norm_rows = 0) {
+                 bool need_dx = true, bool lazy_out = false, const float* roww = nullptr, long long norm_rows = 0, const PoolGrad* pool = nullptr) {
     const Par W = par(s, conv + ".weight", (int64_t)N * X.C), b = par(s, conv + ".bias", N);
     const Par gam = par(s, bn + ".weight", N), bet = par(s, bn + ".bias", N);
     const Par rm = par(s, bn + ".running_mean", N), rv = par(s, bn + ".running_var", N);
@@ -1074,10 +1130,21 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
     hipLaunchKernelGGL(bn_finish_kernel, dim3(nblk(N, 64)), dim3(64), 0, s->st, st2, stq, nrows, N, training, const_cast<float*>(rm.w), const_cast<float*>(rv.w),
                        mean, invstd);
     hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Z, mean, invstd, gam.w, bet.w, Y.d, Y.ld, rows, N, keep);
+    const bool pooled = pool != nullptr;
+    const PoolGrad pg = pool ? *pool : PoolGrad{};
     s->tape.push_back([=]() {
         float* dZ = talloc<float>(s, (size_t)rows * N);
         double* red = talloc<double>(s, 2 * (size_t)N, true);
         if (!dZ || !red) return;
+        if (pooled) {
+            // (the output feeds the level's max-pool only: its gradient is (dout, arg), never materialised)
+            const int gx = (int)std::min<long long>(512, std::max<long long>(1, pg.groups / 64));
+            hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(gx, (N + 255) / 256), dim3(256), 0, s->st, pg, Z, mean, invstd, gam.w, bet.w, N, red, red + N);
+            hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, pg, Z, mean, invstd, gam.w, bet.w, red, red + N, rows, N, training,
+                               dZ, nrows, bet.g, gam.g);
+            linear_bwd(s, X, W, b, dZ, N, need_dx, roww);
+            return;
+        }
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ry4), dim3(256), 0, s->st, Y.g, Z, mean, invstd, gam.w, bet.w, rows, N, keep, red, red + N, roww);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, Y.g, Y.ld, Z, mean, invstd, gam.w, bet.w, red, red + N, rows, N,
                            training, keep, dZ, nrows, bet.g, gam.g);
@@ -1386,26 +1453,28 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
                     else hipLaunchKernelGGL(group_bwd_kernel, dim3(nblk(rows * D)), dim3(256), 0, st, G.g, bl, NSl, Sl, D, src.g, rows);
                 });
             }
-            Ten h = G;
-            for (int i = 0; i < 3; ++i)
-                h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), CH[l][i], training, nullptr, !(l == 0 && i == 0),
-                                 /*lazy: consumed by the next conv / the max-pool, whose backward passes write every element*/ true, roww, full_rows);
             Ten out = make(s, (long long)nc * S[l], CH[l][2]);
             unsigned char* arg = talloc<unsigned char>(s, (size_t)nc * S[l] * CH[l][2]);
             const int Cc = CH[l][2];
             const long long groups = (long long)nc * S[l];
+            const PoolGrad pg{out.g, arg, goff, rgrp, groups};
+            Ten h = G;
+            for (int i = 0; i < 3; ++i)
+                h = conv_bn_relu(s, h, pre + ".mlp_convs." + std::to_string(i), pre + ".mlp_bns." + std::to_string(i), CH[l][i], training, nullptr, !(l == 0 && i == 0),
+                                 /*lazy: consumed by the next conv / the max-pool, whose backward passes write every element*/ true, roww, full_rows,
+                                 compact && i == 2 ? &pg : nullptr);
             if (!s->failed) {
                 if (compact) hipLaunchKernelGGL(maxpool_fwd_c_kernel, dim3(nblk(groups * Cc)), dim3(256), 0, st, h.d, Cc, goff, out.d, arg, groups);
                 else hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nblk(groups * Cc)), dim3(256), 0, st, h.d, Cc, out.d, arg, groups);
             }
             s->named["sa" + std::to_string(l + 1) + ".arg"] = {arg, (int64_t)(groups * Cc)};
             const Ten hl = h;
-            s->tape.push_back([=]() {
-                // (stores every element)
-                if (compact) hipLaunchKernelGGL(maxpool_bwd_c_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, goff, rgrp, hl.g, rows);
-                else hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, hl.g, rows);
-                if (hl.gs) *hl.gs = 1;
-            });
+            if (!compact)
+                s->tape.push_back([=]() {
+                    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nblk(rows * Cc)), dim3(256), 0, st, out.g, arg, Cc, hl.g, rows);      // (stores every element)
+                    if (hl.gs) *hl.gs = 1;
+                });
+            // (compacted groups: the last layer's BatchNorm backward reads the pool's gradient as (out.g, arg) -- conv_bn_relu above)
             feat[l + 1] = out;
         }
         // feature propagation: fp4 (l3 <- l4), fp3 (l2 <- l3), fp2 (l1 <- l2), fp1 (l0 <- l1, points1 = None)
