@@ -1138,7 +1138,9 @@ Ten conv_bn_relu(lsdm_train* s, const Ten& X, const std::string& conv, const std
         if (!dZ || !red) return;
         if (pooled) {
             // (the output feeds the level's max-pool only: its gradient is (dout, arg), never materialised)
-            const int gx = (int)std::min<long long>(512, std::max<long long>(1, pg.groups / 64));
+            // (~8 passes of 256 / min(N, 256) groups per work-group: the gathers of a pass are independent, the passes a dependent chain)
+            const int slots = 256 / (N < 256 ? N : 256);
+            const int gx = (int)std::min<long long>(2048, std::max<long long>(1, pg.groups / (8 * slots)));
             hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(gx, (N + 255) / 256), dim3(256), 0, s->st, pg, Z, mean, invstd, gam.w, bet.w, N, red, red + N);
             hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(nblk(rows * (N / 4))), dim3(256), 0, s->st, pg, Z, mean, invstd, gam.w, bet.w, red, red + N, rows, N, training,
                                dZ, nrows, bet.g, gam.g);
