@@ -283,6 +283,7 @@ void prof_read_counts(lsdm_ctx* c, const int* dev, int n, std::vector<int>& host
     if (hipMemcpyAsync(host.data(), dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         host.assign((size_t)n, 0);
 }
+constexpr long long kItemRowLimit = 1ll << 24;      // output rows of an item list are 24-bit (sa_pair_kernel: out row A | k << 24)
 namespace xm {     // per cloud (encoder) / per chain or row (others), split-bf16 kernels in their default configuration
 constexpr double SA1 = 32768.0 * (16 * 32 + 32 * 32 + 32 * 64);
 constexpr double SA2_UV = 1024.0 * 64 * 64, SA2_CENT = 32.0 * (64 * 64 + 64 * 128), SA2_FULL = 8192.0 * (80 * 64 + 64 * 64 + 64 * 128);
@@ -632,7 +633,9 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     // the step's item lists (geometry only): two ball-query groups whose distinct neighbours fit into 32 rows together share a block
     const bool src1 = skip_sa1 && inv_in_source_order(c);      // sa2 reads the per-call U / V through the step's level-1 order
-    const bool items[4] = {np == 2 && c->sa_pair && !skip_sa1 && c->sa_reg > 0, np == 2 && c->sa_pair && c->sa_split >= 3 && c->sa_reg > 1 && !src1,
+    // (a list's output rows carry the split in their top byte: levels of 2^24 centroids and more -- sa1 from 16 384 clouds -- keep one block per group)
+    const bool fits1 = (long long)nc * 1024 < kItemRowLimit;
+    const bool items[4] = {np == 2 && c->sa_pair && !skip_sa1 && c->sa_reg > 0 && fits1, np == 2 && c->sa_pair && c->sa_split >= 3 && c->sa_reg > 1 && !src1,
                            np == 2 && c->sa_pair && c->sa_split >= 1, np == 2 && c->sa_pair && c->sa_split >= 2};
     {
         const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};
@@ -1601,7 +1604,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
-            const bool items1 = c->sa_reg > 0 && np == 2 && c->sa_pair;
+            const bool items1 = c->sa_reg > 0 && np == 2 && c->sa_pair && (long long)nc * kN < kItemRowLimit;
             if (!items1) prof_exec(c, K_SA1, nc * xm::SA1);
             if (items1) {
                 // (r = 0.1: seven distinct neighbours per group on the bench clouds -- half the blocks)
@@ -1626,7 +1629,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si, nullptr, /*scan=*/true);
             launch_memo_src(gw.memo_ball2, (long long)nc * kN, gw.memo_unc, gw.memo_src_list, gw.memo_cnt, si);
             prof_mark(c, K_SA1 + 1, si);
-            if (c->sa_pair && gw.memo_rows) {
+            if (c->sa_pair && gw.memo_rows && (long long)nc * kN < kItemRowLimit) {
                 // every uncrowded point's group has fewer than 32 distinct entries: two to a block where they fit (geometry.hip: sa_pair_kernel)
                 launch_sa_pair_plan(1, (int)nc * kN, kN, kN, gw.memo_ball2, nullptr, gw.memo_chunks, gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, si, gw.memo_unc);
                 launch_sa_u_items(1, c->sa_U[2], c->sa_V[2], gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si);
