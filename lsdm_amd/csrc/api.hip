@@ -72,7 +72,7 @@ struct lsdm_ctx {
     std::vector<int> pair_host[2];       // (... and the group's sa3 / sa4 lists')
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
     int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
-    int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = sa3 / sa4 give every ball-query group a 32-row block of its own
+    int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = every ball-query group gets a 32-row block of its own; 2 = item lists for single steps of any batch
     int fp1_order = getenv("LSDM_FP1_ORDER") ? atoi(getenv("LSDM_FP1_ORDER")) : 1;   // A/B switch: fp1 + head walks the source points along that order
     int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
     int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
@@ -635,8 +635,10 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const bool src1 = skip_sa1 && inv_in_source_order(c);      // sa2 reads the per-call U / V through the step's level-1 order
     // (a list's output rows carry the split in their top byte: levels of 2^24 centroids and more -- sa1 from 16 384 clouds -- keep one block per group)
     const bool fits1 = (long long)nc * 1024 < kItemRowLimit;
-    const bool items[4] = {np == 2 && c->sa_pair && !skip_sa1 && c->sa_reg > 0 && fits1, np == 2 && c->sa_pair && c->sa_split >= 3 && c->sa_reg > 1 && !src1,
-                           np == 2 && c->sa_pair && c->sa_split >= 1, np == 2 && c->sa_pair && c->sa_split >= 2};
+    // (a single step pays eight planner launches for its lists: measured break-even between 8 and 16 chains -- strict schedule 1656 vs 1673
+    // steps/s at B = 8, 1116 vs 1099 at B = 16, 687 vs 661 at B = 32; LSDM_SA_PAIR=2 forces them at any size)
+    const bool on = np == 2 && c->sa_pair && (nc >= 108 || c->sa_pair > 1);
+    const bool items[4] = {on && !skip_sa1 && c->sa_reg > 0 && fits1, on && c->sa_split >= 3 && c->sa_reg > 1 && !src1, on && c->sa_split >= 1, on && c->sa_split >= 2};
     {
         const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};
         for (int l = 0; l < 4; ++l) {

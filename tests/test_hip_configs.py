@@ -507,7 +507,7 @@ _SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "
              {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
              {"LSDM_GROUP": "3"}, {"LSDM_BATCH_ENC": "0"}, {"LSDM_BATCH_DEN": "0"}, {"LSDM_STREAMS": "1"}, {"LSDM_INV_SIDE": "0"}, {"LSDM_SA2_MEMO": "0"},
              {"LSDM_FP2_WS": "0"}, {"LSDM_FP2_WS": "1"}, {"LSDM_FP2_WS": "2"}, {"LSDM_FP2_WS": "3"}, {"LSDM_FP1_PIPE": "0"}, {"LSDM_FP1_ORDER": "0"},
-             {"LSDM_FP1_PIPE": "0", "LSDM_FP1_ORDER": "0"}, {"LSDM_SA_PAIR": "0"}]
+             {"LSDM_FP1_PIPE": "0", "LSDM_FP1_ORDER": "0"}, {"LSDM_SA_PAIR": "0"}, {"LSDM_SA_PAIR": "2"}]
 _SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN", "LSDM_STREAMS", "LSDM_INV_SIDE", "LSDM_SA2_MEMO", "LSDM_FP2_WS", "LSDM_FP1_PIPE",
                     "LSDM_FP1_ORDER", "LSDM_SA_PAIR")      # launch shapes / kernel forms with the same arithmetic in the same order: bit-identical results
 
@@ -623,9 +623,17 @@ def test_sa_item_lists_are_an_exact_cover_with_the_most_pairs():
     clouds = objs.to(DEV).contiguous()
     torch.manual_seed(6)
     starts = torch.stack([torch.randint(0, n, (nc,)) for n in (1024, 1024, 256, 64)]).to(DEV)
-    m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
-    m.load_state_dict(make_synthetic_state_dict(seed=0))
-    ctx = m._context()
+    keep = os.environ.get("LSDM_SA_PAIR")
+    os.environ["LSDM_SA_PAIR"] = "2"        # (single steps take the lists from 12 chains on by default; 2 = at any size)
+    try:
+        m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
+        m.load_state_dict(make_synthetic_state_dict(seed=0))
+        ctx = m._context()
+    finally:
+        if keep is None:
+            del os.environ["LSDM_SA_PAIR"]
+        else:
+            os.environ["LSDM_SA_PAIR"] = keep
     m._reserve(2)
     out = torch.empty(nc, 1024, 3, device=DEV)
     ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), nc, out.data_ptr(), None)
@@ -684,7 +692,7 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
     outs = {}
     keep = {k: os.environ.get(k) for k in ("LSDM_FP2_WS", "LSDM_FP1_PIPE", "LSDM_SA_PAIR")}
     try:
-        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_FP1_PIPE": "1", "LSDM_SA_PAIR": "1"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_FP1_PIPE": "0", "LSDM_SA_PAIR": "0"})):
+        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_FP1_PIPE": "1", "LSDM_SA_PAIR": "2"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_FP1_PIPE": "0", "LSDM_SA_PAIR": "0"})):
             os.environ.update(env)
             m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
             m.load_state_dict(sd)
