@@ -641,10 +641,16 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const bool items[4] = {on && !skip_sa1 && c->sa_reg > 0 && fits1, on && c->sa_split >= 3 && c->sa_reg > 1 && !src1, on && c->sa_split >= 1, on && c->sa_split >= 2};
     {
         const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};
+        PairLevel lv[4];
+        int nlv = 0, firstl = -1;
         for (int l = 0; l < 4; ++l) {
             if (!items[l]) continue;
-            prof_mark(c, K_SA1 + l, st, 0);
-            launch_sa_pair_plan(1, nc * S_[l], S_[l], N_[l], f.ball[l], f.idx[l], c->step_chunk[l], c->step_rows[l], c->step_meta[l], c->step_cnt + l, st);
+            if (firstl < 0) firstl = l;
+            lv[nlv++] = PairLevel{f.ball[l], f.idx[l], nc * S_[l], S_[l], N_[l], 0, 1, c->step_chunk[l], c->step_rows[l], c->step_meta[l], c->step_cnt + l, nullptr, 0};
+        }
+        if (nlv) {
+            prof_mark(c, K_SA1 + firstl, st, 0);      // (all levels in one pair of launches, timed with the first of them)
+            launch_sa_pair_plans(lv, nlv, st);
         }
         if (items[0] || items[1] || items[2] || items[3]) prof_read_counts(c, c->step_cnt, 4, c->step_host, st);
         else c->step_host.assign(4, 0);
@@ -868,10 +874,10 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     }
     // sa3 / sa4's item lists of every step of the group: two groups whose distinct neighbours fit into 32 rows together share a block
     if (c->sa_pair) {
-        prof_mark(c, K_SA1 + 2, st, 0);
-        launch_sa_pair_plan(steps, nc1 * 64, 64, 256, f.ball[2], f.idx[2], g.pair_chunk[0], g.pair_rows[0], g.pair_meta[0], g.pair_cnt[0], st);
-        prof_mark(c, K_SA1 + 3, st, 0);
-        launch_sa_pair_plan(steps, nc1 * 16, 16, 64, f.ball[3], f.idx[3], g.pair_chunk[1], g.pair_rows[1], g.pair_meta[1], g.pair_cnt[1], st);
+        prof_mark(c, K_SA1 + 2, st, 0);      // (both levels in one pair of launches, timed with sa3)
+        const PairLevel lv[2] = {{f.ball[2], f.idx[2], nc1 * 64, 64, 256, 0, steps, g.pair_chunk[0], g.pair_rows[0], g.pair_meta[0], g.pair_cnt[0], nullptr, 0},
+                                 {f.ball[3], f.idx[3], nc1 * 16, 16, 64, 0, steps, g.pair_chunk[1], g.pair_rows[1], g.pair_meta[1], g.pair_cnt[1], nullptr, 0}};
+        launch_sa_pair_plans(lv, 2, st);
         for (int l = 0; l < 2; ++l) prof_read_counts(c, g.pair_cnt[l], steps, c->pair_host[l], st);
     }
     // (the chains of a step in two or three cloud slices, so that each slice's U / V or Y fits the Infinity Cache with room to spare, were

@@ -8,6 +8,7 @@
 // discrete decisions (arg-max, d > r^2, nearest-3) are index-exact against the CPU oracle.
 // Built with -ffp-contract=off; explicit __f*_rn intrinsics are used where the order matters.
 #include "common.hpp"
+#include "kernels.hpp"
 #include <cmath>
 
 namespace lsdm {
@@ -1052,13 +1053,21 @@ __device__ inline int plan_runs(const int* cnt, Run* runs, int* nruns) {
 
 // only (optional, one byte per centroid): the groups with a zero get no block (sa2's memo pass: the crowded source points are not evaluated);
 // cent_idx == nullptr: a centroid is source point number (its index within the cloud), as in that pass.
+// One launch plans up to four levels (a single step's four SA stages: two launches instead of eight).
 template <bool WRITE>
-__global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ball, const int* __restrict__ cent_idx, int T1, int S, int NSRC, int CPS,
-                                                      int* __restrict__ chunk_np, int* __restrict__ rows, int4* __restrict__ meta, int* __restrict__ count,
-                                                      const unsigned char* __restrict__ only) {
+__global__ __launch_bounds__(256) void sa_pair_kernel(PairLevels P) {
     __shared__ int wcnt[4][9], wsingle[4], wbefore[4], s_np, s_nruns;
     __shared__ sap::Run runs[sap::MAXRUN];
-    const int seg = blockIdx.x / CPS, chunk = blockIdx.x % CPS;
+    int lv = 0;
+    for (int i = 1; i < P.n; ++i)
+        if ((int)blockIdx.x >= P.l[i].first_block) lv = i;
+    const PairLevel& a = P.l[lv];
+    const int* __restrict__ ball = a.ball; const int* __restrict__ cent_idx = a.cent_idx;
+    const int T1 = a.T1, S = a.S, NSRC = a.NSRC, CPS = a.CPS;
+    int* __restrict__ chunk_np = a.chunk_np; int* __restrict__ rows = a.rows; int4* __restrict__ meta = a.meta; int* __restrict__ count = a.count;
+    const unsigned char* __restrict__ only = a.only;
+    const int bid = (int)blockIdx.x - a.first_block;
+    const int seg = bid / CPS, chunk = bid % CPS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int e = chunk * 256 + tid;
@@ -1096,7 +1105,7 @@ __global__ __launch_bounds__(256) void sa_pair_kernel(const int* __restrict__ ba
     }
     const int nvalid = __syncthreads_count(valid);           // (also publishes s_np and the runs)
     if (!WRITE) {
-        if (tid == 0) chunk_np[blockIdx.x] = nvalid - s_np;  // the chunk's blocks
+        if (tid == 0) chunk_np[bid] = nvalid - s_np;         // the chunk's blocks
         return;
     }
     for (int w = 0; w < wave; ++w) rank += cls >= 1 && cls <= 7 ? wcnt[w][cls] : 0;
@@ -1171,11 +1180,25 @@ void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsign
 }
 
 int sa_pair_chunks(int T1) { return (T1 + 255) / 256; }
+void launch_sa_pair_plans(const PairLevel* levels, int n, hipStream_t st) {
+    PairLevels P;
+    P.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < n && P.n < 4; ++i) {
+        PairLevel a = levels[i];
+        a.CPS = sa_pair_chunks(a.T1);
+        a.first_block = blocks;
+        blocks += a.segs * a.CPS;
+        P.l[P.n++] = a;
+    }
+    if (!blocks) return;
+    hipLaunchKernelGGL(sa_pair_kernel<false>, dim3(blocks), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(sa_pair_kernel<true>, dim3(blocks), dim3(256), 0, st, P);
+}
 void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_np, int* rows, int4* meta, int* count,
                          hipStream_t st, const unsigned char* only) {
-    const int cps = sa_pair_chunks(T1);
-    hipLaunchKernelGGL(sa_pair_kernel<false>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count, only);
-    hipLaunchKernelGGL(sa_pair_kernel<true>, dim3(segs * cps), dim3(256), 0, st, ball, cent_idx, T1, S, NSRC, cps, chunk_np, rows, meta, count, only);
+    const PairLevel a{ball, cent_idx, T1, S, NSRC, 0, segs, chunk_np, rows, meta, count, only, 0};
+    launch_sa_pair_plans(&a, 1, st);
 }
 
 void launch_three_nn(const float* fine, const float* coarse, int num_clouds, int N, int S, int* out_idx, float* out_w, int fine_mod,

@@ -129,7 +129,11 @@ void launch_sa_u(int level, int num_clouds, const float* U, const float* V, cons
 //                        meta (segs*T1) int4, count (segs); chunk_np: segs * sa_pair_chunks(T1) ints of scratch
 //   launch_sa_u_items  : one segment's stage (level 1 = sa2's memo pass over the source points, 2 = sa3, 3 = sa4) over its list
 //   (only: one byte per centroid, zero = the group gets no block; cent_idx == nullptr: centroid e is point e % S of its cloud)
+struct PairLevel { const int* ball; const int* cent_idx; int T1, S, NSRC, CPS /* filled in */, segs; int* chunk_np; int* rows; int4* meta; int* count;
+                   const unsigned char* only; int first_block /* filled in */; };
+struct PairLevels { PairLevel l[4]; int n; };
 int sa_pair_chunks(int T1);
+void launch_sa_pair_plans(const PairLevel* levels, int n, hipStream_t st);      // up to four levels in one pair of launches
 void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, const int* cent_idx, int* chunk_np, int* rows, int4* meta, int* count,
                          hipStream_t st, const unsigned char* only = nullptr);
 void launch_sa_r_items(const float* src_xyz, const int* rows, const int4* meta, const int* count, const __bf16* blob_w, const float* blob_b, float* out,
