@@ -635,9 +635,9 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const bool src1 = skip_sa1 && inv_in_source_order(c);      // sa2 reads the per-call U / V through the step's level-1 order
     // (a list's output rows carry the split in their top byte: levels of 2^24 centroids and more -- sa1 from 16 384 clouds -- keep one block per group)
     const bool fits1 = (long long)nc * 1024 < kItemRowLimit;
-    // (a single step pays eight planner launches for its lists: measured break-even between 8 and 16 chains -- strict schedule 1656 vs 1673
-    // steps/s at B = 8, 1116 vs 1099 at B = 16, 687 vs 661 at B = 32; LSDM_SA_PAIR=2 forces them at any size)
-    const bool on = np == 2 && c->sa_pair && (nc >= 108 || c->sa_pair > 1);
+    // (a single step pays two planner launches for its lists: measured break-even around 4 chains -- strict schedule 2262 vs 2269 steps/s at
+    // B = 4, 1790 vs 1705 at B = 8, 1177 vs 1099 at B = 16, 400 vs 361 at B = 64; LSDM_SA_PAIR=2 forces them at any size)
+    const bool on = np == 2 && c->sa_pair && (nc >= 54 || c->sa_pair > 1);
     const bool items[4] = {on && !skip_sa1 && c->sa_reg > 0 && fits1, on && c->sa_split >= 3 && c->sa_reg > 1 && !src1, on && c->sa_split >= 1, on && c->sa_split >= 2};
     {
         const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};

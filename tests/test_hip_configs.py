@@ -624,7 +624,7 @@ def test_sa_item_lists_are_an_exact_cover_with_the_most_pairs():
     torch.manual_seed(6)
     starts = torch.stack([torch.randint(0, n, (nc,)) for n in (1024, 1024, 256, 64)]).to(DEV)
     keep = os.environ.get("LSDM_SA_PAIR")
-    os.environ["LSDM_SA_PAIR"] = "2"        # (single steps take the lists from 12 chains on by default; 2 = at any size)
+    os.environ["LSDM_SA_PAIR"] = "2"        # (single steps take the lists from 6 chains on by default; 2 = at any size)
     try:
         m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
         m.load_state_dict(make_synthetic_state_dict(seed=0))
