@@ -874,7 +874,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     }
     // sa3 / sa4's item lists of every step of the group: two groups whose distinct neighbours fit into 32 rows together share a block
     if (c->sa_pair) {
-        prof_mark(c, K_SA1 + 2, st, 0);      // (both levels in one pair of launches, timed with sa3)
+        prof_mark(c, K_SA1 + 3, st, 0);      // (both levels in one pair of launches, timed with sa4 -- the stage the roofline leg follows)
         const PairLevel lv[2] = {{f.ball[2], f.idx[2], nc1 * 64, 64, 256, 0, steps, g.pair_chunk[0], g.pair_rows[0], g.pair_meta[0], g.pair_cnt[0], nullptr, 0},
                                  {f.ball[3], f.idx[3], nc1 * 16, 16, 64, 0, steps, g.pair_chunk[1], g.pair_rows[1], g.pair_meta[1], g.pair_cnt[1], nullptr, 0}};
         launch_sa_pair_plans(lv, 2, st);
