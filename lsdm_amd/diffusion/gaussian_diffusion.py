@@ -234,6 +234,8 @@ class GaussianDiffusion:
         # Host-RNG (parity) mode: the draws of a chunk go straight into one of two page-locked staging buffers and are
         # uploaded with ONE asynchronous copy per chunk, so the host draws chunk k+1 while the GPU runs chunk k (a blocking
         # per-step upload would wait behind the whole previous chunk and leave the GPU idle while the host draws).
+        if chunk_steps is None:
+            chunk_steps = 56 if (self.host_rng or not x.is_cuda) else 256
         kmax = min(int(chunk_steps), total)
         stage = None
         if self.host_rng and x.is_cuda:
@@ -296,11 +298,12 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                       denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, skip_timesteps=0,
                       init_image=None, randomize_class=False, cond_fn_with_grad=False, dump_steps=None,
-                      const_noise=False, *, hoist_conditioning=False, chunk_steps=56, hoist_invariants=True):
+                      const_noise=False, *, hoist_conditioning=False, chunk_steps=None, hoist_invariants=True):
         """Reference signature (gaussian_diffusion.py:611-632) + keyword-only extensions: ``hoist_invariants`` (default on: evaluate the
         loop-invariant level-1 encoder work once per library call -- bit-identical results, lsdm_sample_steps_invariant; off = every
         stage recomputed every step, lsdm_sample_steps), ``chunk_steps`` (steps per
-        library call on the fused path; results do not depend on it) and ``hoist_conditioning`` (pin the FPS starts to
+        library call on the fused path; results do not depend on it; default 56 with host-side draws -- the host draws chunk k + 1 while the
+        GPU runs chunk k -- and 256 with device draws, where a call's once-per-call work is all a longer chunk saves) and ``hoist_conditioning`` (pin the FPS starts to
         the first step's draws and evaluate the scene conditioning once -- not the stock reference's behaviour)."""
         if (dump_steps is None and not progress and not randomize_class and not cond_fn_with_grad
                 and self._fusable(model, clip_denoised, denoised_fn, cond_fn)):
@@ -365,7 +368,7 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,
                          denoised_fn=None, cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
                          skip_timesteps=0, init_image=None, randomize_class=False, cond_fn_with_grad=False,
-                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=56, hoist_invariants=True):
+                         dump_steps=None, const_noise=False, *, hoist_conditioning=False, chunk_steps=None, hoist_invariants=True):
         """Argument list of the reference's ``ddim_sample_loop`` (gaussian_diffusion.py:957-1000) with the conditioning
         arguments threaded.  ``dump_steps`` behaves as in ``p_sample_loop`` (:661-680); ``const_noise`` is accepted for
         signature compatibility -- the reference's DDIM step has no such argument (``ddim_sample`` :761-775 draws
