@@ -1425,6 +1425,8 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
         (void)hipStreamWaitEvent(st, s->ev_geo, 0);      // the geometry (side stream) from here on
         long long crows[4] = {0, 0, 0, 0};
         if (compact) {
+            // (a HOST synchronisation per step -- the compacted row counts size the encoder's launches: lsdm_train_step with compacted groups
+            // cannot be captured into a hipGraph; LSDM_TRAIN_COMPACT=0 has no host round trip)
             if (hipEventSynchronize(s->ev_rows) != hipSuccess) { tfail(s, LSDM_ERR_HIP, "training: row counts"); return; }
             for (int l = 0; l < 4; ++l) {
                 crows[l] = s->h_rows[l];
@@ -1615,6 +1617,13 @@ int lsdm_train_step(lsdm_train* s, int B, int flags, const float* x_start, const
     }
     };
     body();
+    // Every exit of body() after the fork, the failing ones included, leaves the caller's stream BEHIND the geometry stream: FPS / ball-query work
+    // still in flight reads given_objs, fps_starts and arena memory that the next step (or the caller's allocator, on `st`) may reuse.  On the
+    // normal path the encoder block has already joined (the second wait is a no-op); on an early return the event is recorded here first.
+    if (s->geo && s->ev_geo) {
+        if (s->failed) (void)hipEventRecord(s->ev_geo, s->geo);
+        (void)hipStreamWaitEvent(st, s->ev_geo, 0);
+    }
     s->tape.clear();
     if (prev >= 0 && prev != s->device) (void)hipSetDevice(prev);
     if (s->failed) return LSDM_ERR_STATE;

@@ -302,7 +302,9 @@ class GaussianDiffusion:
         """Reference signature (gaussian_diffusion.py:611-632) + keyword-only extensions: ``hoist_invariants`` (default on: evaluate the
         loop-invariant level-1 encoder work once per library call -- bit-identical results, lsdm_sample_steps_invariant; off = every
         stage recomputed every step, lsdm_sample_steps), ``chunk_steps`` (steps per
-        library call on the fused path; results do not depend on it; default 56 with host-side draws -- the host draws chunk k + 1 while the
+        library call on the fused path; with host-side draws (``host_rng``, the parity mode) results do not depend on it -- with DEVICE draws a
+        chunk's noise and FPS starts are one ``th.randn(k, ...)`` / ``th.randint(..., (k, ...))`` each, whose Philox stream depends on k, so seeded
+        device-RNG samples change with ``chunk_steps`` (and changed when the default went from 56 to 256); default 56 with host-side draws -- the host draws chunk k + 1 while the
         GPU runs chunk k -- and 256 with device draws, where a call's once-per-call work is all a longer chunk saves) and ``hoist_conditioning`` (pin the FPS starts to
         the first step's draws and evaluate the scene conditioning once -- not the stock reference's behaviour)."""
         if (dump_steps is None and not progress and not randomize_class and not cond_fn_with_grad
@@ -345,6 +347,7 @@ class GaussianDiffusion:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
         inner = _unwrap(model)
+        failed = False
         try:
             for i in indices:
                 t = th.tensor([i] * shape[0], device=device)
@@ -359,10 +362,16 @@ class GaussianDiffusion:
                                             const_noise=const_noise)
                     yield out
                     img = out["sample"]
+        except GeneratorExit:
+            raise                # close() / a caller's break: the check below still runs, and its ValueError reaches the caller of close()
+        except BaseException:
+            failed = True        # the loop body is already raising: the deferred check must not replace that exception
+            raise
         finally:
             # the deferred range checks of the loop's device-resident timesteps (model/sdm.py::_run) are resolved when the generator ends --
-            # also when the caller abandons it early (break / close): an out-of-range index must not go unreported
-            if hasattr(inner, "check_timesteps"):
+            # also when the caller abandons it early.  A caller that breaks out of the loop should close() the generator (or call
+            # model.check_timesteps()) itself: a generator left to the garbage collector can only PRINT the error ("Exception ignored").
+            if not failed and hasattr(inner, "check_timesteps"):
                 inner.check_timesteps()
 
     def ddim_sample_loop(self, model, shape, mask, given_objs, given_cats, y, noise=None, clip_denoised=True,

@@ -5,7 +5,13 @@ partitioned over ranks with NO data-path collective: rank r runs its own referen
 ``B_local`` chains with seed ``base_seed + r``.  The only exchange is one all-gather of the final samples
 (``torch.distributed`` backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 """
+import math
+
 import torch
+
+# agree=False (exactly ONE collective): a rank whose local preconditions failed still takes part in that collective, with a block whose first
+# column carries this bit pattern (a quiet NaN with a payload no arithmetic produces) -- every rank finds it and raises
+_POISON = 0x7FC0DEAD
 
 
 def shard_seed(base_seed, rank):
@@ -65,7 +71,10 @@ def gather_results(sample, saved_cat=None, guiding=None, dist=None, total=None, 
     and, optionally, ``model.saved_guiding_points`` (B,1024,3)) in ONE collective: the per-chain rows of the three
     tensors are packed side by side into one (B_local, 3072 + C [+ 3072]) fp32 buffer, all-gathered once (``gather_samples``: same
     padding and shard-size agreement) and split again.  Returns ``(sample, saved_cat, guiding)`` over all ranks' chains in rank order;
-    entries passed as None come back as None.  8 x 64 chains: 6.3 MB with the guiding points -- latency-, not bandwidth-bound."""
+    entries passed as None come back as None.  8 x 64 chains: 6.3 MB with the guiding points -- latency-, not bandwidth-bound.
+    A rank whose parts are inconsistent (chain counts, dtype) makes EVERY rank raise ValueError in either mode: with ``agree`` the failure
+    travels in the 8-byte size exchange, with ``agree=False`` (the caller vouches for the shard SIZES; one collective, nothing else) inside
+    the data all-gather itself as a poisoned block of the agreed shape -- no rank is left waiting in a collective."""
     parts = [("sample", sample)] + [(n, t) for n, t in (("saved_cat", saved_cat), ("guiding", guiding)) if t is not None]
     B = sample.shape[0]
     # local preconditions (every part holds B chains of fp32 values): a failure is AGREED ON with the other ranks inside gather_samples' size
@@ -79,10 +88,21 @@ def gather_results(sample, saved_cat=None, guiding=None, dist=None, total=None, 
     single = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
     if single and not invalid:
         return sample, saved_cat, guiding
-    if invalid:
+    if invalid and agree:
         gather_samples(sample.new_zeros((B, 1), dtype=torch.float32), dist, total=total, _invalid=invalid)     # raises on every rank
-    flat = [t.reshape(B, -1) for _, t in parts]
-    packed = gather_samples(flat[0] if len(flat) == 1 else torch.cat(flat, dim=1), dist, total=total, agree=agree)
+    if invalid:
+        # agree=False: the same single collective as the valid ranks issue, B rows of the packed width, first column = the poison word
+        width = sum(math.prod(t.shape[1:]) for _, t in parts)
+        mine = torch.zeros((B, width), dtype=torch.float32, device=sample.device)
+        mine.view(torch.int32)[:, 0] = _POISON
+    else:
+        flat = [t.reshape(B, -1) for _, t in parts]
+        mine = flat[0] if len(flat) == 1 else torch.cat(flat, dim=1)
+    packed = gather_samples(mine, dist, total=total, agree=agree)
+    if invalid:
+        raise ValueError(invalid)
+    if not agree and packed.shape[0] and bool((packed[:, 0].contiguous().view(torch.int32) == _POISON).any()):
+        raise ValueError("a rank holds inconsistent tensors (its own error says which)")
     out, col = {}, 0
     for (n, t), f in zip(parts, flat):
         w = f.shape[1]

@@ -541,11 +541,13 @@ def test_config2_b16_c43_mid_schedule_25_steps_vs_reference_golden(golden, preci
     args = (m, [B, 1024, 3], bt["mask"], bt["given_objs"], bt["given_cats"], bt["text_features"])
     torch.manual_seed(seed)
     fifths, last = [], None
-    for i, o in enumerate(diff.p_sample_loop_progressive(*args, clip_denoised=False, **kw)):
+    gen = diff.p_sample_loop_progressive(*args, clip_denoised=False, **kw)
+    for i, o in enumerate(gen):
         if i % 5 == 4:
             fifths.append(o["sample"].clone())
         if i + 1 == K:
             break
+    gen.close()          # an abandoned generator: close() runs its deferred timestep check and raises HERE (gaussian_diffusion.py)
     worst = g15_check(g, fifths, m.saved_cat, m.saved_guiding_points, 1e-4)
     print("g15 %s: worst deviation over 25 steps, relative to the sample's magnitude (15 .. 95): %.2e" % (precision, worst))
     # the same 25 steps as ONE library call per schedule (what a chunk of the bulk loop is): draws in the reference's order

@@ -109,6 +109,17 @@ def _ragged_worker(rank, world, port, q):
             raise AssertionError("a rank with inconsistent tensors went through on rank %d" % rank)
         except ValueError:
             pass
+    # ... the same with agree=False (bench.py's timed gather: the sizes were agreed on in the warm-up, ONE collective): the bad rank takes part
+    # in that collective with a poisoned block, BOTH ranks raise, nobody waits in a collective the other never issues
+    e_lo, e_hi = 2 * rank, 2 * rank + 2           # equal shards of 2 chains
+    ok = gather_results(units[e_lo:e_hi], cats[e_lo:e_hi], gpts[e_lo:e_hi], dist, agree=False)
+    assert torch.equal(ok[0], units[:4]) and torch.equal(ok[1], cats[:4]) and torch.equal(ok[2], gpts[:4])
+    for bad_cats in (cats[:3] if rank == 1 else cats[e_lo:e_hi], cats[e_lo:e_hi].double() if rank == 0 else cats[e_lo:e_hi]):
+        try:
+            gather_results(units[e_lo:e_hi], bad_cats, gpts[e_lo:e_hi], dist, agree=False)
+            raise AssertionError("agree=False: a rank with inconsistent tensors went through on rank %d" % rank)
+        except ValueError:
+            pass
     dist.barrier()
     if rank == 0:
         q.put((got.numpy(), bad))

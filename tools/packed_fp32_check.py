@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""Static check of the generated gfx950 code: a translation unit whose kernels issue matrix instructions (v_mfma_*) must not contain
-packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32).  Round 4 found a v_pk_fma_f32 with cross operand selection losing
-its update in a gather wave that shares a SIMD with an MFMA wave; the library is therefore compiled with
--target-feature -packed-fp32-ops for those units (csrc/Makefile: NOPK) and this check keeps it that way.
+"""Static check of the generated gfx950 code, LIBRARY-WIDE (every kernel of the library can share a SIMD with a matrix wave of another
+kernel: the side streams run geometry next to dense stages):
+  1. a translation unit whose kernels issue matrix instructions (v_mfma_*) contains no packed fp32 arithmetic at all
+     (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32);
+  2. NO unit contains a packed fp32 instruction with an operand modifier (op_sel / op_sel_hi / neg_lo / neg_hi).
+Round 4 found a v_pk_fma_f32 with cross operand selection losing its update in a gather wave that shares a SIMD with an MFMA wave; round 5
+narrowed the trigger to the operand-selected forms.  Every unit is compiled with -target-feature -packed-fp32-ops
+(csrc/Makefile: NOPK); the geometry kernels keep packed arithmetic as explicit inline-asm instructions on plain register pairs
+(geometry.hip: pk_add / pk_mul / pk_fma), which is what rule 2 holds them to.
 
     python tools/packed_fp32_check.py /tmp/lsdm_asm_check/*-gfx950.s        (make -C lsdm_amd/csrc check-packed)
 
-Exit status 1 and a per-kernel listing when a unit mixes the two."""
+Exit status 1 and a per-kernel listing on a violation."""
 import re
 import sys
 
 PK = re.compile(r"^\s*v_pk_(mul|fma|add)_f32\b")
+MOD = re.compile(r"\b(op_sel|op_sel_hi|neg_lo|neg_hi)\s*:")
 MFMA = re.compile(r"^\s*v_mfma_")
 LABEL = re.compile(r"^([A-Za-z_][\w$.]*):")
 
 
 def scan(path):
-    """-> (number of mfma instructions, {kernel or function label: packed fp32 instructions})"""
-    mfma, pk, cur = 0, {}, "?"
+    """-> (number of mfma instructions, {kernel or function label: packed fp32 instructions}, {label: those with an operand modifier})"""
+    mfma, pk, mod, cur = 0, {}, {}, "?"
     with open(path) as fh:
         for line in fh:
             m = LABEL.match(line)
@@ -27,20 +33,29 @@ def scan(path):
                 mfma += 1
             elif PK.match(line):
                 pk[cur] = pk.get(cur, 0) + 1
-    return mfma, pk
+                if MOD.search(line):
+                    mod[cur] = mod.get(cur, 0) + 1
+    return mfma, pk, mod
 
 
 def main(paths):
     bad = 0
     for p in paths:
-        mfma, pk = scan(p)
-        n = sum(pk.values())
+        mfma, pk, mod = scan(p)
+        n, nm = sum(pk.values()), sum(mod.values())
         if mfma and n:
             bad += 1
             print("%s: %d v_mfma next to %d packed fp32 instructions" % (p, mfma, n))
             for k, v in sorted(pk.items(), key=lambda kv: -kv[1])[:12]:
                 print("    %6d  %s" % (v, k))
-    print("%d unit(s) mix matrix instructions with packed fp32 arithmetic" % bad)
+        if nm:
+            bad += 1
+            print("%s: %d packed fp32 instructions with op_sel / op_sel_hi / neg modifiers" % (p, nm))
+            for k, v in sorted(mod.items(), key=lambda kv: -kv[1])[:12]:
+                print("    %6d  %s" % (v, k))
+        elif n:
+            print("%s: %d packed fp32 instructions, all on plain register pairs (no matrix instruction in the unit)" % (p, n))
+    print("%d violation(s): matrix instructions next to packed fp32 arithmetic, or operand-selected packed fp32 anywhere" % bad)
     return 1 if bad else 0
 
 

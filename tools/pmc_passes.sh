@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 export LSDM_STREAMS=1    # counters per kernel: no overlapping kernels (see round_profile.sh)
-CMD="python $R/bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-others --no-parity --no-hoisted"
+CMD="python $R/bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-others --no-parity --no-hoisted --no-configs"
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" \

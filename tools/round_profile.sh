@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 export LSDM_STREAMS=1
 OUT=$R/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT -o bench -- python $R/bench.py --precision $P --steps 10 --warmup 2 \
-    --no-cpu-baseline --no-others --no-parity --no-hoisted > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
+    --no-cpu-baseline --no-others --no-parity --no-hoisted --no-configs > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
 F=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp "$F" $R/gpurun_out/${TAG}_kernel_stats.csv
 python $R/tools/summarize_rocprof.py stats $OUT $R/gpurun_out/${TAG}_kernel_stats.md > /dev/null
