@@ -130,7 +130,8 @@ def parity_check(precision, dev):
 class Runner:
     """Model + resident inputs + RNG streams of one precision; run(t_first, k0, k) = k steps in one C-ABI call."""
 
-    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev, datatype="proxd", respacing="", ddim=False, surface=False, prompts_per_scene=1):
+    def __init__(self, precision, B, C, n_steps, seed, local_rank, dev, datatype="proxd", respacing="", ddim=False, surface=False, prompts_per_scene=1,
+                 num_objects=8):
         from lsdm_amd import _lib
         from lsdm_amd.synthetic import make_synthetic_batch, make_synthetic_state_dict
         from lsdm_amd.util.model_util import create_gaussian_diffusion, create_model_and_diffusion, get_default_diffusion
@@ -144,7 +145,7 @@ class Runner:
         self.ctx = self.model._context()
         self.model._reserve(B)
         self.model._set_schedule(self.diffusion._schedule_key(), self.diffusion._device_tables())
-        bt = make_synthetic_batch(B // prompts_per_scene, seed=seed, max_cats=C, num_objects=8, surface=surface)
+        bt = make_synthetic_batch(B // prompts_per_scene, seed=seed, max_cats=C, num_objects=num_objects, surface=surface)
         if prompts_per_scene > 1:      # HUMANISE (BASELINE configs[4]): chains 2 s, 2 s + 1 share scene s and differ in the prompt
             text = make_synthetic_batch(B, seed=seed + 1000, max_cats=C, num_objects=1)["text_features"]
             bt = {k: v.repeat_interleave(prompts_per_scene, dim=0) for k, v in bt.items()}
@@ -233,7 +234,8 @@ def contract_fields(a, world, K, W, B, C, dt, per_rank_dt, allgather_us, T, inv,
 
 
 def config_legs(a, dev, local_rank, inv):
-    """Short legs (never `value`) for the BASELINE configs that are not the headline but fit one GPU, through the same entry point:
+    """Short legs (never `value`) for the BASELINE configs that are not the headline but fit one GPU, through the same entry point (plus `ragged_k`:
+    SURVEY.md 8d's k ~ U{1..8} variant of the headline workload):
     configs[1] (B = 16, C = 43: f32 -- its stated precision -- and bf16x3), configs[4]'s shapes on one GPU (HUMANISE defaults C = 11, 32 scenes x
     2 prompts, DDIM on the 'ddim250' schedule, reference util/model_util.py:56-85 + diffusion/gaussian_diffusion.py:790-811) and the headline
     workload on SURFACE-sampled objects (points on the box faces: PROX-like scans, posa/dataset.py:424-470) with sa2's memo hit rate."""
@@ -257,6 +259,12 @@ def config_legs(a, dev, local_rank, inv):
         e = {"value": K / d, "value_is": "median of 3 repeats", "value_min": K / max(ds), "value_max": K / min(ds), "unit": "denoising-steps/sec (batch of %d chains)" % B, "ms_per_step": d / K * 1e3, "steps": K, "batch": B, "max_cats": C,
              "dtype": precision, "sample_steps_per_s": B * K / d, "schedule_T": T, "sampler": "ddim" if kw.get("ddim") else "p_sample",
              "entry_point": "lsdm_sample_steps_invariant" if inv else "lsdm_sample_steps", "finite": bool(torch.isfinite(r.x).all()), "workload": note}
+        if name == "ragged_k":
+            zero = int((r.bt["given_objs"].abs().amax(dim=(2, 3)) == 0).sum())
+            e["clouds"] = {"per_step": B * 9, "all_zero_slots": zero, "live": B * 9 - zero,
+                           "note": "k ~ U{1..8} objects per scene, the absent slots ZERO clouds (SURVEY.md 8d, posa/dataset.py:456): a cloud of 1024 identical "
+                                   "points has an encoder output independent of the FPS draws -- one representative per call, the per-step encoder on the "
+                                   "live clouds only (DESIGN.md 10; LSDM_DEG_FAST=0 = every cloud every step); bit-identical to it"}
         if kw.get("surface") or name == "headline_volume_reference":
             # sa2's memo: memo_cnt = {uncrowded source points of the call, crowded centroids of the call's last group}; the K steps are one group
             try:
@@ -294,6 +302,9 @@ def config_legs(a, dev, local_rank, inv):
     leg("headline_surface_sampled", "bf16x3", 64, 13, 10, "the headline workload with the 8 objects' points ON their box faces (surface scans) instead of in the "
         "volume: sparser balls, higher sa2-memo hit rate", surface=True)
     leg("headline_volume_reference", "bf16x3", 64, 13, 10, "the headline workload (volume-filled boxes) through the same 10-step leg, for the memo hit rate beside it")
+    leg("ragged_k", "bf16x3", 64, 13, 10, "the headline workload with k ~ U{1..8} objects per scene instead of 8 (SURVEY.md 8d's default variant; mask = slots 1..k), "
+        "through the same 10-step leg as headline_volume_reference", num_objects=None)
+    out["ragged_k"]["vs_all_8_objects"] = out["ragged_k"]["value"] / out["headline_volume_reference"]["value"]
     return out
 
 

@@ -1,6 +1,7 @@
 // liblsdm_hip: context, parameter folding/packing, workspace and the extern "C" surface (include/lsdm_hip.h).
 #include "../../include/lsdm_hip.h"
 
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -63,6 +64,9 @@ struct lsdm_ctx {
     // index 0: fp3, 1: fp2
     DenseH fp_a[3], fp_y[3];     // first FP layer split at the concat boundary: [0] fp3, [1] fp2, [2] fp4
     float* fp_ybuf[3] = {};
+    // fp3 [0] / fp4 [1] as register-chained blobs of encoder_w.hip::fp_w_kernel: [Wa (256 x D1) | second layer | the next finer stage's Wb], biases [b1 | b2 | 0]
+    DenseH fp_w[2];
+    int fp_wk = getenv("LSDM_FP_W") ? atoi(getenv("LSDM_FP_W")) : 1;   // A/B switch: 0 = fp3 / fp4 on the tile-per-work-group form (fp_pre_kernel)
     int* fp2_plan = nullptr;     // fp2's tile plan (encoder_d.hip::fp_plan_kernel) of a single step, rewritten by every such step
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
     // item lists of the SA stages of a single step (geometry.hip: sa_pair_kernel; the groups of the loop-invariant schedule have their own in gws)
@@ -129,12 +133,13 @@ struct lsdm_ctx {
         if (j == 0) return f;
         static const int S[4] = {1024, 256, 64, 16}, NN[4] = {64, 256, 1024, 1024};
         const size_t nc = (size_t)B * 9, o = (size_t)j;
+        const size_t ne = enc_nc > 0 ? (size_t)enc_nc : nc;       // clouds per step of the encoder's batched launches (compacted: the live ones)
         for (int l = 0; l < 4; ++l) {
-            f.idx[l] += o * nc * S[l];
-            f.xyz[l] += o * nc * S[l] * 3;
-            f.ball[l] += o * nc * S[l] * 32;
-            f.nn_idx[l] += o * nc * NN[l] * 3;
-            f.nn_w[l] += o * nc * NN[l] * 3;
+            f.idx[l] += o * ne * S[l];
+            f.xyz[l] += o * ne * S[l] * 3;
+            f.ball[l] += o * ne * S[l] * 32;
+            f.nn_idx[l] += o * ne * NN[l] * 3;
+            f.nn_w[l] += o * ne * NN[l] * 3;
         }
         f.e0 += o * B * 256;
         f.tr += o * nc * 12;
@@ -171,6 +176,7 @@ struct lsdm_ctx {
     // (alt_*: a second set of the per-step scratch tensors of the dense chain -- sa3 / sa4's U and V, fp2's pre-multiplied operand, fp2's
     // output -- for the steps that run on the side stream)
     struct GroupWs { int cap_B = 0; float *feat[4] = {}, *ybuf[3] = {}, *pcd = nullptr, *o12 = nullptr;
+                     float* pcd_c = nullptr;   // the encoder's output of the LIVE clouds of every step of a group (degenerate-cloud compaction)
                      struct Alt { float *U[2] = {}, *V[2] = {}, *ybuf1 = nullptr, *fpo2 = nullptr; } alt[3];
                      int* plan = nullptr;     // fp2's tile plans of every step of a group (one fp_plan_kernel launch per group)
                      // item lists of sa3 [0] / sa4 [1] of every step of a group (geometry.hip: sa_pair_kernel): U rows, {V rows, output rows},
@@ -194,6 +200,21 @@ struct lsdm_ctx {
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
     double prof_exec[64] = {0};                      // executed MACs per stage id over the profiled window (prof_exec())
+    // Degenerate clouds: a cloud whose 1024 points are bit-identical -- the all-zero padding slots of a scene with fewer than 8
+    // objects (posa/dataset.py:456) -- has an encoder output that does not depend on the FPS draws (farthest_point_sample returns
+    // [start, 0, 0, ...] on it and every ball is the indices 0 .. 31, pointnet2_utils.py:60-104: every grouped row, hence every feature row of
+    // every level, is the same vector).  lsdm_sample_steps_invariant evaluates the encoder for ONE representative of each distinct such cloud
+    // once per call and runs the per-step encoder on the LIVE clouds only, compacted; a copy kernel spreads both over the (step, chain, slot)
+    // layout the scene attention and the denoiser read.  enc_nc: clouds per step of the compacted encoder (0 = all B x 9).
+    int deg_fast = getenv("LSDM_DEG_FAST") ? atoi(getenv("LSDM_DEG_FAST")) : 1;      // A/B switch: 0 = every cloud through the encoder every step
+    int enc_nc = 0;
+    unsigned char* cls_flag = nullptr;  float* cls_first = nullptr;      // per cloud: all points identical; its first point
+    void* cls_host = nullptr;                                           // pinned: the flags and first points on the host
+    int *enc_map = nullptr, *rep_map = nullptr, *exp_src = nullptr;      // live slot -> cloud; representative -> cloud; cloud -> live slot | -(representative + 1)
+    float *enc_clouds = nullptr, *rep_clouds = nullptr, *rep_pcd = nullptr;
+    int64_t *rep_starts = nullptr, *enc_starts = nullptr;
+    size_t enc_starts_cap = 0;
+    int deg_last[3] = {0, 0, 0};                                        // {live, degenerate, distinct degenerate} clouds of the last multi-step call
 };
 
 namespace {
@@ -403,19 +424,13 @@ bool fold_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname,
 //                 8*(s%2) .. 8*(s%2)+7 of block s/2 of the previous layer's transposed product
 // followed (separately) by the fp32 biases of the layers back to back, BatchNorm folded.
 struct ChainLayer { std::string w, b, bn; int N, K; int padN = 0; };   // padN: rows zero-padded to that many channels
-bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const std::vector<int>& first_map, int np, DenseH* out) {
+struct ChainMat { std::vector<float> W, Bv; int N, K; };               // a layer as a folded (N, K) matrix + bias (the split first FP layers)
+bool build_chain_blob_mats(lsdm_ctx* c, const std::vector<ChainMat>& mats, const std::vector<int>& first_map, int np, DenseH* out) {
     std::vector<uint16_t> blob;
     std::vector<float> biases;
-    for (size_t li = 0; li < layers.size(); ++li) {
-        int N = layers[li].N;
-        const int K = layers[li].K;
-        std::vector<float> W, Bv;
-        if (!fold_dense(c, layers[li].w, layers[li].b, layers[li].bn, N, K, W, Bv)) return false;
-        if (layers[li].padN > N) {
-            N = layers[li].padN;
-            W.resize((size_t)N * K, 0.0f);
-            Bv.resize(N, 0.0f);
-        }
+    for (size_t li = 0; li < mats.size(); ++li) {
+        const int N = mats[li].N, K = mats[li].K;
+        const std::vector<float>&W = mats[li].W, &Bv = mats[li].Bv;
         const int KS = li == 0 ? ((int)first_map.size() + 15) / 16 : K / 16;
         for (int nb = 0; nb < N / 32; ++nb)
             for (int s = 0; s < KS; ++s)
@@ -439,6 +454,20 @@ bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const 
     out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
     out->b = upload(c, biases.data(), biases.size());
     return out->w && out->b;
+}
+bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const std::vector<int>& first_map, int np, DenseH* out) {
+    std::vector<ChainMat> mats(layers.size());
+    for (size_t li = 0; li < layers.size(); ++li) {
+        ChainMat& m = mats[li];
+        m.N = layers[li].N; m.K = layers[li].K;
+        if (!fold_dense(c, layers[li].w, layers[li].b, layers[li].bn, m.N, m.K, m.W, m.Bv)) return false;
+        if (layers[li].padN > m.N) {
+            m.N = layers[li].padN;
+            m.W.resize((size_t)m.N * m.K, 0.0f);
+            m.Bv.resize(m.N, 0.0f);
+        }
+    }
+    return build_chain_blob_mats(c, mats, first_map, np, out);
 }
 
 // Fragment blob of denoise_reg.hip::denoise_r_kernel, fragments [nb][k-step s][plane][lane][8] per layer, layers back to back:
@@ -559,6 +588,40 @@ T* ws_alloc(lsdm_ctx* c, const char* name, size_t count) {
 __global__ void fill_steps_kernel(int64_t* p, int64_t t0, int B, int g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * g) p[i] = t0 - i / B;
+}
+
+// ---- degenerate clouds (lsdm_ctx::deg_fast) -------------------------------------------------------------------------------------------
+// one work-group per cloud: flag[c] = every point BIT-identical to point 0 (a +0 / -0 mix is not: sign bits reach the features); first[c] = point 0
+__global__ __launch_bounds__(256) void cloud_class_kernel(const float* __restrict__ clouds, unsigned char* __restrict__ flag, float* __restrict__ first) {
+    const unsigned* p = reinterpret_cast<const unsigned*>(clouds) + (size_t)blockIdx.x * kN * 3;
+    const unsigned x0 = p[0], y0 = p[1], z0 = p[2];
+    bool same = true;
+    for (int i = threadIdx.x; i < kN; i += 256) same = same && p[i * 3] == x0 && p[i * 3 + 1] == y0 && p[i * 3 + 2] == z0;
+    const int all = __syncthreads_and(same ? 1 : 0);
+    if (threadIdx.x == 0) {
+        flag[blockIdx.x] = (unsigned char)all;
+        first[blockIdx.x * 3 + 0] = __uint_as_float(x0); first[blockIdx.x * 3 + 1] = __uint_as_float(y0); first[blockIdx.x * 3 + 2] = __uint_as_float(z0);
+    }
+}
+// dst cloud i = src cloud map[i]
+__global__ __launch_bounds__(256) void gather_clouds_kernel(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src + (size_t)map[blockIdx.x] * kN * 3);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst + (size_t)blockIdx.x * kN * 3);
+    for (int i = threadIdx.x; i < kN * 3 / 4; i += 256) d4[i] = s4[i];
+}
+// the start draws (rows, nc) of the clouds map[0 .. n): dst (rows, n)
+__global__ void gather_starts_kernel(const int64_t* __restrict__ src, const int* __restrict__ map, int nc, int n, long long total, int64_t* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) dst[i] = src[(i / n) * nc + map[i % n]];
+}
+// out (steps, nc, 1024, 3): cloud c of step j = the compacted encoder's slot exp_src[c] of that step, or representative -(exp_src[c] + 1) of the call
+__global__ __launch_bounds__(256) void expand_pcd_kernel(const float* __restrict__ live, const float* __restrict__ rep, const int* __restrict__ exp_src, int nc,
+                                                         int nlive, float* __restrict__ out) {
+    const int c = blockIdx.x, j = blockIdx.y;
+    const int e = exp_src[c];
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(e >= 0 ? live + ((size_t)j * nlive + e) * kN * 3 : rep + (size_t)(-e - 1) * kN * 3);
+    f32x4* d4 = reinterpret_cast<f32x4*>(out + ((size_t)j * nc + c) * kN * 3);
+    for (int i = threadIdx.x; i < kN * 3 / 4; i += 256) d4[i] = s4[i];
 }
 
 // geometry + dense stages of get_backbone.forward on `num_clouds` clouds
@@ -704,7 +767,11 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     // fp4 / fp3 also write the next finer stage's pre-multiplied interpolation operand (one more layer on their rows) when that stage
     // takes the pre-multiplied form
     const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y;
-    if (fuse_y && c->fp4_pre)
+    const bool fpw = fuse_y && c->fp4_pre && c->fp_wk && c->fp_w[0].w;      // fp3 / fp4 on the register-chained panel kernel (encoder_w.hip)
+    if (fpw) {
+        launch_fp_y512(nc * 16, c->feat[3], c->fp_y[2], c->fp_ybuf[2], st);
+        launch_fp_w(4, nc, c->feat[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_w[1].w, c->fp_w[1].b, c->keep_taps ? c->fpo4 : nullptr, c->fp_ybuf[0], c->num_cus, st);
+    } else if (fuse_y && c->fp4_pre)
         // fp4 in the pre-multiplied form too: Y4 = feat4 x Wb^T on the 16 coarse points of a cloud, the matrix pipe then contracts over the
         // 256 columns of points1 only (K = 256 instead of 768: a third of the fragments every 64-row tile streams from L2)
         launch_fp_pre(4, nc, c->feat[2], nullptr, c->feat[3], c->fp_y[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], c->fpo4, false,
@@ -713,7 +780,9 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
     prof_exec(c, K_FP4, nc * (fuse_y && c->fp4_pre ? xm::FP4_PRE : (fuse_y ? xm::FP4_Y : xm::FP4_FULL)));
     prof_mark(c, K_FP3, st);
-    if (np == 2 && c->fp_pre >= 2)
+    if (fpw)
+        launch_fp_w(3, nc, c->feat[1], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_w[0].w, c->fp_w[0].b, c->keep_taps ? c->fpo3 : nullptr, c->fp_ybuf[1], c->num_cus, st);
+    else if (np == 2 && c->fp_pre >= 2)
         launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, fuse_y,
                       c->fp_y[1], fuse_y ? c->fp_ybuf[1] : nullptr, c->keep_taps, st);
     else
@@ -778,7 +847,7 @@ bool ensure_group_ws(lsdm_ctx* c, int B) {
     bool ok = true;
     for (int l = 1; l < 4 && ok; ++l) ok = (g.feat[l] = al(nc * kS[l] * kFeatC[l])) != nullptr;
     ok = ok && (g.ybuf[0] = al(nc * 64 * 256)) && (g.ybuf[2] = al(nc * 16 * 256));
-    ok = ok && (g.pcd = al(nc * kN * 3)) && (g.o12 = al(nc * 12)) && (g.plan = reinterpret_cast<int*>(al(nc * fp_plan_ints(1024))));
+    ok = ok && (g.pcd = al(nc * kN * 3)) && (!c->deg_fast || (g.pcd_c = al(nc * kN * 3))) && (g.o12 = al(nc * 12)) && (g.plan = reinterpret_cast<int*>(al(nc * fp_plan_ints(1024))));
     if (ok && c->sa_pair) {
         for (int l = 0; l < 2 && ok; ++l) {
             const size_t S = l ? 16 : 64, T1 = (size_t)B * kO * S;
@@ -845,7 +914,7 @@ static void stream_join(lsdm_ctx* c, hipStream_t st) {
 
 void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds, int B, int steps, hipStream_t st0) {
     const lsdm_ctx::GroupWs& g = c->gws;
-    const int nc1 = B * kO, nc = nc1 * steps;
+    const int nc1 = c->enc_nc > 0 ? c->enc_nc : B * kO, nc = nc1 * steps;
     const int nl = lanes(c);
     const bool two = nl > 1;
     hipStream_t st = st0;
@@ -926,6 +995,10 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     if (two) stream_join(c, st0);
     prof_mark(c, K_FP4, st, steps);
     // (fp4 / fp3 store only the next finer stage's pre-multiplied operand inside a multi-step call: keep_out = false, `out` unused)
+    if (c->fp_wk && c->fp_w[1].w) {
+        launch_fp_y512(nc * 16, g.feat[3], c->fp_y[2], g.ybuf[2], st);
+        launch_fp_w(4, nc, g.feat[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_w[1].w, c->fp_w[1].b, nullptr, g.ybuf[0], c->num_cus, st);
+    } else
     launch_fp_pre(4, nc, g.feat[2], nullptr, g.feat[3], c->fp_y[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], nullptr, false,
                   c->fp_y[0], g.ybuf[0], false, st);
     prof_exec(c, K_FP4, nc * xm::FP4_PRE);
@@ -936,7 +1009,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
 // (lane > 0: the step runs on side stream lane - 1 with that lane's scratch set)
 void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float* pcd_out, hipStream_t st, int lane) {
     const lsdm_ctx::GroupWs& g = c->gws;
-    const int nc1 = B * kO;
+    const int nc1 = c->enc_nc > 0 ? c->enc_nc : B * kO;
     float* const ybuf1 = lane ? g.alt[lane - 1].ybuf1 : c->fp_ybuf[1];
     float* const fpo2 = lane ? g.alt[lane - 1].fpo2 : c->fpo2;
     const int* const plan = fp2_ws() == 4 ? g.plan + (size_t)j * nc1 * fp_plan_ints(1024) : nullptr;
@@ -946,6 +1019,10 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         const size_t o = 0;
         const int ncp = nc1;
         prof_mark(c, K_FP3, st);
+        if (c->fp_wk && c->fp_w[0].w)
+            launch_fp_w(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256, fj.nn_idx[1] + o * 256 * 3,
+                        fj.nn_w[1] + o * 256 * 3, c->fp_w[0].w, c->fp_w[0].b, nullptr, ybuf1, c->num_cus, st);
+        else
         launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
                       fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], ybuf1, false, st);
         prof_exec(c, K_FP3, ncp * (xm::FP3_PRE + xm::FP3_NEXT_Y));
@@ -1108,6 +1185,8 @@ int lsdm_destroy(lsdm_ctx* c) {
         for (void* p : c->allocs) (void)hipFree(p);
         for (void* p : c->sched_allocs) (void)hipFree(p);
         for (void* p : c->ws_allocs) (void)hipFree(p);
+        if (c->enc_starts) (void)hipFree(c->enc_starts);
+        if (c->cls_host) (void)hipHostFree(c->cls_host);
         for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
         for (void* p : c->gws.allocs) (void)hipFree(p);
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1302,6 +1381,28 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                     c->fp_y[i].b = nullptr;
                     ok = c->fp_a[i].w && c->fp_a[i].b && c->fp_y[i].w;
                 }
+            }
+            // fp3 / fp4 as chains for fp_w_kernel: [Wa | mlp_convs.1 | Wb of the next finer stage (fp2 / fp3)]
+            for (int i = 0; i < 2 && ok; ++i) {
+                const char* own = i == 0 ? "pcd_backbone.fp3" : "pcd_backbone.fp4";
+                const char* nxt = i == 0 ? "pcd_backbone.fp2" : "pcd_backbone.fp3";
+                const int d1 = i == 0 ? 128 : 256, d2 = i == 0 ? 256 : 512, nd1 = i == 0 ? 64 : 128;
+                std::vector<float> W0, B0, Wn, Bn;
+                std::vector<ChainMat> mats(3);
+                ok = fold_dense(c, std::string(own) + ".mlp_convs.0.weight", std::string(own) + ".mlp_convs.0.bias", std::string(own) + ".mlp_bns.0", 256, d1 + d2, W0, B0) &&
+                     fold_dense(c, std::string(own) + ".mlp_convs.1.weight", std::string(own) + ".mlp_convs.1.bias", std::string(own) + ".mlp_bns.1", 256, 256, mats[1].W, mats[1].Bv) &&
+                     fold_dense(c, std::string(nxt) + ".mlp_convs.0.weight", std::string(nxt) + ".mlp_convs.0.bias", std::string(nxt) + ".mlp_bns.0", 256, nd1 + 256, Wn, Bn);
+                if (!ok) break;
+                mats[0].N = 256; mats[0].K = d1; mats[0].W.resize((size_t)256 * d1); mats[0].Bv = B0;
+                mats[1].N = 256; mats[1].K = 256;
+                mats[2].N = 256; mats[2].K = 256; mats[2].W.resize((size_t)256 * 256); mats[2].Bv.assign(256, 0.0f);
+                for (int n = 0; n < 256; ++n) {
+                    for (int k = 0; k < d1; ++k) mats[0].W[(size_t)n * d1 + k] = W0[(size_t)n * (d1 + d2) + k];
+                    for (int k = 0; k < 256; ++k) mats[2].W[(size_t)n * 256 + k] = Wn[(size_t)n * (nd1 + 256) + nd1 + k];
+                }
+                std::vector<int> ident(d1);
+                for (int k = 0; k < d1; ++k) ident[k] = k;
+                ok = build_chain_blob_mats(c, mats, ident, np, &c->fp_w[i]);
             }
             // sa4: first layer (256 x 259) split the same way; layers 2-3 are the LDS-tiled operands sa_h[3][1..2]
             std::vector<float> W4, B4;
@@ -1531,6 +1632,17 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
          (c->s_stash = ws_alloc<float>(c, "s_stash", (size_t)B * (kN / 32) * 6 * 16 * 64)) &&
          (c->fp2_plan = ws_alloc<int>(c, "fp2_plan", nc * fp_plan_ints(1024))) && (c->fp2_order = ws_alloc<int>(c, "fp2_order", nc * kN)) &&
          (c->inv_order = ws_alloc<int>(c, "inv_order", nc * kN));
+    if (ok && c->deg_fast) {
+        ok = (c->cls_flag = ws_alloc<unsigned char>(c, "cls_flag", nc)) && (c->cls_first = ws_alloc<float>(c, "cls_first", nc * 3)) &&
+             (c->enc_map = ws_alloc<int>(c, "enc_map", nc)) && (c->rep_map = ws_alloc<int>(c, "rep_map", nc)) && (c->exp_src = ws_alloc<int>(c, "exp_src", nc)) &&
+             (c->enc_clouds = ws_alloc<float>(c, "enc_clouds", nc * kN * 3)) && (c->rep_clouds = ws_alloc<float>(c, "rep_clouds", nc * kN * 3)) &&
+             (c->rep_pcd = ws_alloc<float>(c, "rep_pcd", nc * kN * 3)) && (c->rep_starts = ws_alloc<int64_t>(c, "rep_starts", nc * 4));
+        if (ok) {
+            if (c->cls_host) (void)hipHostFree(c->cls_host);
+            c->cls_host = nullptr;
+            ok = hipHostMalloc(&c->cls_host, nc * 16) == hipSuccess;
+        }
+    }
     if (ok && c->sa_pair) {
         const char* nm[4] = {"sa1", "sa2", "sa3", "sa4"};
         for (int l = 0; l < 4 && ok; ++l)
@@ -1583,7 +1695,65 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
     float* cur = x;
     float* nxt = c->xs;
     const size_t xn = (size_t)B * kN * 3;
-    const int nc = B * kO;
+    const int nc_all = B * kO;
+    // ---- degenerate clouds (lsdm_ctx::deg_fast): classified per call (one compare kernel + a 16-byte-per-cloud read-back: the only host round trip
+    // of the call, in front of everything else); the encoder then runs on the live clouds only.  Applies to the schedule the sampler loop uses --
+    // loop-invariant, group-batched, bf16 modes; every other path keeps all B x 9 clouds.
+    struct EncReset { lsdm_ctx* c; ~EncReset() { c->enc_nc = 0; } } enc_reset{c};
+    c->enc_nc = 0;
+    const float* enc_clouds = given_objs;
+    const int64_t* enc_starts = starts;
+    int nu = 0;
+    bool compacted = false;
+    if (inv && c->deg_fast && c->cls_host && K > 1 && group_batched(c) && c->batch_den && c->den_reg && c->prec != LSDM_PREC_F32) {
+        if (!ensure_group_ws(c, B)) return LSDM_ERR_HIP;
+        hipLaunchKernelGGL(cloud_class_kernel, dim3(nc_all), dim3(256), 0, st, given_objs, c->cls_flag, c->cls_first);
+        unsigned char* hflag = static_cast<unsigned char*>(c->cls_host);
+        float* hfirst = reinterpret_cast<float*>(hflag + (((size_t)nc_all + 15) & ~(size_t)15));
+        HIP_TRY(c, hipMemcpyAsync(hflag, c->cls_flag, (size_t)nc_all, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(hfirst, c->cls_first, (size_t)nc_all * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        std::vector<int> live, reps, exp((size_t)nc_all);
+        std::map<std::array<uint32_t, 3>, int> seen;      // distinct degenerate clouds by the bit pattern of their point
+        for (int i = 0; i < nc_all; ++i) {
+            if (!hflag[i]) { exp[i] = (int)live.size(); live.push_back(i); continue; }
+            std::array<uint32_t, 3> key;
+            memcpy(key.data(), hfirst + (size_t)i * 3, 12);
+            auto it = seen.find(key);
+            if (it == seen.end()) { it = seen.emplace(key, (int)reps.size()).first; reps.push_back(i); }
+            exp[i] = -(it->second + 1);
+        }
+        c->deg_last[0] = (int)live.size(); c->deg_last[1] = nc_all - (int)live.size(); c->deg_last[2] = (int)reps.size();
+        if (!reps.empty() && !live.empty()) {
+            const int nl = (int)live.size();
+            nu = (int)reps.size();
+            // (pageable sources: the runtime stages them before the calls return)
+            HIP_TRY(c, hipMemcpyAsync(c->enc_map, live.data(), live.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(c->rep_map, reps.data(), reps.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            HIP_TRY(c, hipMemcpyAsync(c->exp_src, exp.data(), exp.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            const size_t need = (size_t)K * 4 * nl;
+            if (need > c->enc_starts_cap) {
+                HIP_TRY(c, hipStreamSynchronize(st));
+                if (c->enc_starts) (void)hipFree(c->enc_starts);
+                c->enc_starts = nullptr; c->enc_starts_cap = 0;
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->enc_starts), need * sizeof(int64_t)));
+                c->enc_starts_cap = need;
+            }
+            hipLaunchKernelGGL(gather_clouds_kernel, dim3(nl), dim3(256), 0, st, given_objs, c->enc_map, c->enc_clouds);
+            hipLaunchKernelGGL(gather_clouds_kernel, dim3(nu), dim3(256), 0, st, given_objs, c->rep_map, c->rep_clouds);
+            hipLaunchKernelGGL(gather_starts_kernel, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, starts, c->enc_map, nc_all, nl, (long long)need, c->enc_starts);
+            hipLaunchKernelGGL(gather_starts_kernel, dim3((4 * nu + 255) / 256), dim3(256), 0, st, starts, c->rep_map, nc_all, nu, (long long)4 * nu, c->rep_starts);
+            // the representatives through the encoder ONCE (the first step's draws; any would do), on the single-step workspace -- before the
+            // per-call invariants below, which reuse parts of it (sa_U[2] / sa_V[2], the step lists) for the live clouds
+            run_geometry(c, c->fs0, c->rep_clouds, c->rep_starts, nu, 1, st);
+            run_encoder_dense(c, c->fs0, c->rep_clouds, nu, c->rep_pcd, st);
+            enc_clouds = c->enc_clouds;
+            enc_starts = c->enc_starts;
+            c->enc_nc = nl;
+            compacted = true;
+        }
+    }
+    const int nc = compacted ? c->enc_nc : nc_all;        // clouds per step of the encoder
     // Steps are processed in groups of up to kGroup: the geometry of the whole group (it reads neither x nor anything a
     // step produces) is evaluated first, one launch per stage over group x B x 9 clouds, then the steps run in order.
     // (the cloud index of a batched geometry launch is gridDim.y: at most 65535 clouds per launch)
@@ -1605,10 +1775,10 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         }
         const float r2 = (float)(kRadius[0] * kRadius[0]);
         prof_mark(c, K_BALL1, si);
-        launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2, c->inv_ball, 0, si);
+        launch_ball_query(enc_clouds, enc_clouds, nc, 1024, 1024, r2, c->inv_ball, 0, si);
         prof_mark(c, K_SA1, si);
         if (c->prec == LSDM_PREC_F32) {
-            launch_sa(0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), si);
+            launch_sa(0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), si);
             prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
@@ -1617,14 +1787,14 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             if (items1) {
                 // (r = 0.1: seven distinct neighbours per group on the bench clouds -- half the blocks)
                 launch_sa_pair_plan(1, nc * kN, kN, kN, c->inv_ball, nullptr, c->step_chunk[0], c->step_rows[0], c->step_meta[0], c->step_cnt, si);
-                launch_sa_r_items(given_objs, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, static_cast<float*>(c->inv_F1), si);
+                launch_sa_r_items(enc_clouds, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, static_cast<float*>(c->inv_F1), si);
                 prof_exec_dev(c, K_SA1, c->step_cnt, xm::SA1_ITEM, si);
-            } else if (c->sa_reg > 0) launch_sa_r(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
-            else launch_sa_h(np, 0, nc, given_objs, given_objs, given_objs, c->inv_ball, c->sa_h[0], c->inv_F1, si);
+            } else if (c->sa_reg > 0) launch_sa_r(np, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
+            else launch_sa_h(np, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_h[0], c->inv_F1, si);
         }
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
         {
-            launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), given_objs, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
+            launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), enc_clouds, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
             prof_exec(c, K_SA1 + 1, nc * xm::SA2_UV);       // (timed inside the sa1 interval of the call's prelude)
         }
         // memo of sa2 (geometry.hip::memo_src_kernel): the stage's output of every source point with fewer than 32 points within r, once
@@ -1634,7 +1804,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             const float r2b = (float)(kRadius[1] * kRadius[1]);
             prof_mark(c, K_BALL1 + 1, si);
             (void)hipMemsetAsync(gw.memo_cnt, 0, 2 * sizeof(int), si);
-            launch_ball_query(given_objs, given_objs, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si, nullptr, /*scan=*/true);
+            launch_ball_query(enc_clouds, enc_clouds, nc, 1024, 1024, r2b, gw.memo_ball2, 0, si, nullptr, /*scan=*/true);
             launch_memo_src(gw.memo_ball2, (long long)nc * kN, gw.memo_unc, gw.memo_src_list, gw.memo_cnt, si);
             prof_mark(c, K_SA1 + 1, si);
             if (c->sa_pair && gw.memo_rows && (long long)nc * kN < kItemRowLimit) {
@@ -1650,8 +1820,8 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             c->memo_ready = true;
         }
         prof_mark(c, K_NN1, si);
-        launch_nn8(nc, given_objs, c->inv_nn8_d, c->inv_nn8_i, si);
-        launch_morton_order(nc, given_objs, c->inv_order, si);      // fp2's walking order of the source points (encoder_d.hip)
+        launch_nn8(nc, enc_clouds, c->inv_nn8_d, c->inv_nn8_i, si);
+        launch_morton_order(nc, enc_clouds, c->inv_order, si);      // fp2's walking order of the source points (encoder_d.hip)
         prof_mark(c, -1, si);
         if (si != st) {
             (void)hipEventRecord(c->ev_join[0], si);
@@ -1665,12 +1835,12 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         const int g = K - k0 < gmax ? K - k0 : gmax;
         hipLaunchKernelGGL(fill_steps_kernel, dim3((B * g + 63) / 64), dim3(64), 0, st, c->fs0.tbuf, (int64_t)(t_first - k0), B, g);
         run_conditioning(c, c->fs0, B, g, c->fs0.tbuf, mask, given_objs, given_cats, text, out_cat, /*reuse_hm=*/k0 > 0, st, /*shared=*/true);
-        const bool grp = inv && g > 1 && group_batched(c);
-        run_geometry(c, c->fs0, given_objs, starts + (size_t)k0 * 4 * nc, nc, g, st, inv, grp && c->memo_ready);
+        const bool grp = inv && (g > 1 || compacted) && group_batched(c);
+        run_geometry(c, c->fs0, enc_clouds, enc_starts + (size_t)k0 * 4 * nc, nc, g, st, inv, grp && c->memo_ready);
         need_invariants();
         if (grp) {
             if (!ensure_group_ws(c, B)) return LSDM_ERR_HIP;
-            run_encoder_group_front(c, c->fs0, given_objs, B, g, st);
+            run_encoder_group_front(c, c->fs0, enc_clouds, B, g, st);
         }
         if (grp && c->batch_den && c->den_reg && c->prec != LSDM_PREC_F32) {
             // Nothing of the encoder reads x: the rest of the encoder of every step of the group first (each step's output into its own
@@ -1678,15 +1848,19 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             // its 32 points' x on chip between the steps and forms each step's guidance from that step's slot (denoise_reg.hip); the
             // launch ramp, the weight-panel prologue and the tail are paid once per group instead of once per step.
             const lsdm_ctx::GroupWs& gw = c->gws;
-            const size_t pstep = (size_t)nc * kN * 3, ostep = (size_t)nc * 12;
+            const size_t pstep = (size_t)nc_all * kN * 3, ostep = (size_t)nc_all * 12;
+            const size_t estep = (size_t)nc * kN * 3;                      // the encoder's own output stride (compacted: the live clouds)
+            float* const pcd_enc = compacted ? gw.pcd_c : gw.pcd;
             const int nl = lanes(c);
             if (nl > 1) stream_fork(c, st);
             for (int j = 0; j < g; ++j) {
                 const int ln = j % nl;
-                run_encoder_group_step(c, c->fset_steps(j, B), B, j, gw.pcd + (size_t)j * pstep, ln ? c->side[ln - 1] : st, ln);
+                run_encoder_group_step(c, c->fset_steps(j, B), B, j, pcd_enc + (size_t)j * estep, ln ? c->side[ln - 1] : st, ln);
             }
             if (nl > 1) stream_join(c, st);
             prof_mark(c, K_SATTN, st, g);
+            // (compacted: every (step, chain, slot) row block from its live slot or its call-constant representative)
+            if (compacted) hipLaunchKernelGGL(expand_pcd_kernel, dim3(nc_all, g), dim3(256), 0, st, gw.pcd_c, c->rep_pcd, c->exp_src, nc_all, nc, gw.pcd);
             launch_scene_attn(c->sattn, gw.pcd, c->fs0.w, c->fs0.tr, B, gw.o12, st, g);
             prof_mark(c, K_DENOISE, st, g);
             launch_denoise_r(c->prec == LSDM_PREC_BF16X3 ? 2 : 1, c->den_r, c->den_h.pwt, c->sched, mode, eta, B, g, 0, cur, c->fs0.tbuf, mask, gw.pcd, c->fs0.w,

@@ -1606,6 +1606,11 @@ void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStre
     hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
 }
 
+// fp4's Y: the 16 coarse points of a cloud carry 512 channels
+void launch_fp_y512(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
+    hipLaunchKernelGGL((lin_u_kernel<512, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
+}
+
 // LSDM_FP2_WS: fp2 on 4 = the two-stage persistent kernel over Morton-ordered tiles with deduplicated rows (fp_d_kernel, encoder_d.hip; the default),
 // 2 = the persistent kernel with register-resident weights (fp_rw_kernel), 1 / 3 = the persistent wave-specialised kernel (fp_ws_kernel, 64- / 32-row
 // tiles), 0 = the tile-per-work-group form (fp_pre_kernel).  Same results bit for bit.

@@ -104,6 +104,11 @@ void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const 
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
 // y = coarse-level FP output x Wb^T (the pre-multiplied interpolation operand of the next finer FP stage), R rows of 256 channels
 void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
+void launch_fp_y512(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
+// fp3 (which = 3) / fp4 (4) as one register-chained stack per 32 points (encoder_w.hip): y = the stage's pre-multiplied interpolation operand,
+// out = the stage's output rows or NULL, ynext = the next finer stage's pre-multiplied operand
+void launch_fp_w(int which, int num_clouds, const float* points1, const float* y, const int* nn_idx, const float* nn_w, const __bf16* blob_w,
+                 const float* blob_b, float* out, float* ynext, int num_cus, hipStream_t st);
 // fp1 + head as one register-chained stack (bf16x3): points2 (nc,1024,128) fp32, out (nc,1024,3)
 // order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
 void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b,

@@ -174,9 +174,15 @@ def test_config3_b64_chain_vs_oracle_with_tie_attribution(b64, precision, tol_in
         errs = {key: (maxabs(h[key], raw[key]), maxabs(h[key], inj[key])) for key in ("sample", "x0", "guid", "cat")}
         print("B=64 %s step %d: max-abs (raw, tie-injected) %s" % (precision, k, errs))
         assert errs["cat"][0] <= 1e-6
-        for key in ("sample", "x0", "guid"):
+        # contractual RAW: what the caller of the loop reads (pred_xstart = the final sample at t = 0, saved_cat, the guiding points)
+        for key in ("x0", "guid"):
             assert errs[key][0] <= 1e-3, (k, key, errs)
+        # a per-step `sample` carries coef2 x the in-place guided x (Q5), i.e. the reference's unspecified order of exactly tied 3-NN distances
+        # at full weight: held to rounding with the kernel's equally-near choice injected; the raw figure is printed with the tie count above
+        # (8.8e-4 at another seed, profiles/r06_parity_extra.txt) and bounded loosely -- a kernel fault shows in the injected comparison
+        for key in ("sample", "x0", "guid"):
             assert errs[key][1] <= tol_inj, (k, key, errs)
+        assert errs["sample"][0] <= 5e-3, (k, errs, b64.ties[k])
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
@@ -185,6 +191,110 @@ def test_config3_b64_bulk_calls_bit_equal_to_single_steps(b64, precision):
     for entry, (x, guid, cat) in b64.hip[precision + "_bulk"].items():
         assert torch.equal(x, last["sample"]), entry
         assert torch.equal(guid, last["guid"]) and torch.equal(cat, last["cat"]), entry
+
+
+# ---- the same bar away from t = 999: one step with a different timestep per chain, and a mid-schedule segment (round 6) ----------------
+def _b64_case(seed, ts, x_init):
+    """len(ts) consecutive single-step calls at B = 64 (bench workload, batch seed `seed`) from x_init with per-chain timesteps ts[k] (B,),
+    in f32 and bf16x3, against the oracle run twice -- raw, and with the kernel's equally-near 3-NN choice injected.  Returns
+    {precision: [per step {key: (raw, injected)}]}, the tie rows per step."""
+    B, C, nc, K = 64, 13, 576, len(ts)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count()))
+    sd = make_synthetic_state_dict(seed=0, max_cats=C)
+    bt = make_synthetic_batch(B, seed=seed, max_cats=C, num_objects=8)
+    d = {k: v.to(DEV).contiguous() for k, v in bt.items()}
+    torch.manual_seed(100 + seed)
+    starts = [cpu_ref.draw_fps_starts(nc) for _ in range(K)]
+    noise = [torch.randn(B, 1024, 3) for _ in range(K)]
+    hip, geo = {}, []
+    for prec in ("f32", "bf16x3"):
+        m, diff = create_model_and_diffusion("proxd", precision=prec)
+        m.load_state_dict(sd)
+        m._set_schedule(diff._schedule_key(), diff._device_tables())
+        x = x_init.clone().to(DEV)
+        steps = []
+        for k in range(K):
+            nk = noise[k].to(DEV).contiguous()
+            x = x.contiguous()
+            _, x0, smp = m._run(_lib.MODE_P_SAMPLE, 0.0, x, d["mask"], ts[k].to(DEV), d["given_objs"], d["given_cats"], d["text_features"],
+                                fps_starts=starts[k], noise_fn=lambda: nk)
+            if prec == "f32":
+                geo.append({name: ws(m, wsn, (nc, n_fine, 3), torch.int32).long() for name, (wsn, n_fine, _) in NN_WS.items()})
+            steps.append(dict(sample=smp.cpu(), x0=x0.cpu(), cat=m.saved_cat.cpu(), guid=m.saved_guiding_points.cpu()))
+            x = smp
+        hip[prec] = steps
+        del m
+        torch.cuda.empty_cache()
+    smp = cpu_ref.Sampler(sd)
+    clouds = bt["given_objs"].reshape(nc, 1024, 3)
+    x_raw, x_inj = x_init.clone(), x_init.clone()
+    errs, ties = {"f32": [], "bf16x3": []}, []
+    for k in range(K):
+        taps = {}
+        pcd = cpu_ref.scene_encoder(sd, clouds, starts[k], taps)
+        bad, rows = torch.zeros(nc, dtype=torch.bool), 0
+        for name in NN_WS:
+            differs = (geo[k][name] != taps[name + ".nn_idx"]).any(dim=-1)
+            rows += int(differs.sum())
+            bad |= differs.any(dim=-1)
+        sel = torch.nonzero(bad).flatten()
+        pcd_inj = pcd.clone()
+        if len(sel):
+            pcd_inj[sel] = cpu_ref.scene_encoder(sd, clouds[sel], [s_[sel] for s_ in starts[k]], None, {name: geo[k][name][sel] for name in NN_WS})
+        outs = []
+        for xk, pk in ((x_raw, pcd), (x_inj, pcd_inj)):
+            o = smp.p_sample(xk, bt["mask"], ts[k], bt["given_objs"], bt["given_cats"], bt["text_features"], fps_starts=starts[k], noise=noise[k],
+                             pcd_override=pk)
+            outs.append(dict(sample=o["sample"].clone(), x0=o["pred_xstart"], cat=smp.saved_cat, guid=smp.saved_guiding_points))
+        x_raw, x_inj = outs[0]["sample"], outs[1]["sample"]
+        ties.append(dict(rows=rows, clouds=int(len(sel))))
+        for prec in errs:
+            h = hip[prec][k]
+            e = {key: (maxabs(h[key], outs[0][key]), maxabs(h[key], outs[1][key])) for key in ("sample", "x0", "guid", "cat")}
+            e["scale"] = float(outs[0]["sample"].abs().max())
+            errs[prec].append(e)
+    torch.set_num_threads(threads)
+    return errs, ties
+
+
+def _b64_check(tag, errs, ties):
+    for prec, tol in (("f32", 5e-5), ("bf16x3", 1e-4)):
+        for k, e in enumerate(errs[prec]):
+            print("B=64 %s %s step %d: max-abs (raw, tie-injected) sample %.3e %.3e  pred_xstart %.3e %.3e  guiding %.3e %.3e  saved_cat %.1e; |sample|max %.1f; "
+                  "3-NN rows with another equally-near choice: %d in %d clouds" % (tag, prec, k, e["sample"][0], e["sample"][1], e["x0"][0], e["x0"][1], e["guid"][0],
+                                                                                  e["guid"][1], e["cat"][0], e["scale"], ties[k]["rows"], ties[k]["clouds"]))
+            assert e["cat"][0] <= 1e-6, (tag, prec, k, e)
+            for key in ("x0", "guid"):            # contractual, RAW: what the caller reads after the loop
+                assert e[key][0] <= 1e-3, (tag, prec, k, key, e)
+            # per-step sample: to rounding once the reference's unspecified tie order is taken out (relative to the sample's magnitude mid-schedule)
+            for key in ("sample", "x0", "guid"):
+                assert e[key][1] <= tol * max(1.0, e["scale"] / 4.0 if key == "sample" else 1.0), (tag, prec, k, key, e, ties[k])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_config3_b64_mixed_timesteps_one_step(seed):
+    """One p_sample step at the benched batch with a DIFFERENT timestep per chain (t_b = (991 - 7 b) mod 1000: the whole schedule in one batch --
+    tools/parity_b64.py's case, where the raw per-step sample sits at 8.8e-4 through the 3-NN tie order alone)."""
+    B = 64
+    torch.manual_seed(seed)
+    x = torch.randn(B, 1024, 3)
+    ts = [torch.tensor([(991 - 7 * b) % 1000 for b in range(B)])]
+    _b64_check("mixed-t seed %d" % seed, *_b64_case(seed, ts, x))
+
+
+@pytest.mark.parametrize("seed,K", [(1, 5), (2, 2)])
+def test_config3_b64_mid_schedule_segment(seed, K):
+    """Steps t = 524 .. 524 - K + 1 at the benched batch from x_524 = q_sample(0, 524, noise) (p_sample_loop(skip_timesteps=475)'s start): the
+    guidance term and coef2 are at full weight here, unlike at t = 999 .. 997.  (Five steps on the first seed, two on the second: an oracle
+    step at B = 64 is a minute of host time; tools/parity_b64_mid.py runs five on both -- profiles/r06_parity_extra.txt.)"""
+    B = 64
+    _, diff = create_model_and_diffusion("proxd")
+    torch.manual_seed(10 + seed)
+    t0 = torch.full((B,), 524, dtype=torch.long)
+    x = diff.q_sample(torch.zeros(B, 1024, 3), t0, torch.randn(B, 1024, 3))
+    ts = [t0 - k for k in range(K)]
+    _b64_check("t=524.. seed %d" % seed, *_b64_case(seed, ts, x))
 
 
 # ======================================================================================= configs[0]: the CLI on the HIP path
@@ -545,6 +655,78 @@ def test_every_retained_switch_setting_holds_the_parity_bar(golden, env):
         assert maxabs(a, b) <= 1e-3
         if all(k in _SAME_ARITHMETIC for k in env):
             assert torch.equal(a, b), env
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("precision", ["bf16x3"])
+def test_degenerate_clouds_fast_path_is_bit_identical(precision):
+    """A cloud whose 1024 points are bit-identical (the all-zero padding slots of a scene with fewer than 8 objects, posa/dataset.py:456) has an
+    encoder output that does not depend on the FPS draws (pointnet2_utils.py:60-104): lsdm_sample_steps_invariant evaluates one representative
+    per distinct such cloud once per call and runs the per-step encoder on the live clouds only (api.hip: deg_fast).  Bit-equality of a 6-step
+    chain's sample, guiding points and saved_cat against every cloud through the encoder every step (LSDM_DEG_FAST=0) and against the strict
+    entry point, on: G2's ragged batch (4 / 2 / 7 objects), a batch with a non-zero constant cloud in two chains, a +0 / -0 mix (NOT degenerate
+    by the bit rule), a cloud with one point moved (live), and a chain with NO objects; and the classification the call made."""
+    def scenes():
+        bt = make_synthetic_batch(3, seed=5)                          # G2's batch: 4 / 2 / 7 objects, the rest zero slots
+        yield "g2 ragged", bt, 3, int((bt["given_objs"].abs().amax(dim=(2, 3)) == 0).sum()), 1
+        bt = make_synthetic_batch(5, seed=21)
+        objs = bt["given_objs"].clone()
+        objs[0, 2] = torch.tensor([0.3, -1.2, 0.7])                   # a constant cloud ...
+        objs[3, 5] = torch.tensor([0.3, -1.2, 0.7])                   # ... twice: one representative
+        objs[1, 3] = 0.0
+        objs[1, 3, 0::2, 1] = -0.0                                    # +0 / -0 mix: live
+        objs[2, 4] = 0.0
+        objs[2, 4, 777, 2] = 1e-3                                     # one point moved: live
+        objs[4, 1:] = 0.0                                             # a chain without objects
+        bt["given_objs"] = objs
+        zero = objs.abs().amax(dim=(2, 3)) == 0
+        bitzero = zero & ~torch.signbit(objs).any(dim=3).any(dim=2)
+        yield "constructed", bt, 5, int(bitzero.sum()) + 2, 2
+    for name, bt, B, n_deg, n_rep in scenes():
+        d = {k: v.to(DEV) for k, v in bt.items()}
+
+        def run(**kw):
+            m, diff = _fresh(precision)
+            out = _chain(m, diff, d, B, 6, 31, **kw)
+            exp = ws(m, "exp_src", (B * 9,), torch.int32) if not kw and os.environ.get("LSDM_DEG_FAST") != "0" else None
+            return out, exp
+        fast, exp = run()
+        slow, _ = _with_env({"LSDM_DEG_FAST": "0"}, run)
+        strict, _ = run(hoist_invariants=False)
+        assert int((exp < 0).sum()) == n_deg and int((-exp[exp < 0]).max()) == n_rep, (name, exp)
+        live = exp[exp >= 0]
+        assert torch.equal(live, torch.arange(len(live), dtype=torch.int32)), (name, exp)
+        for a, b, c_ in zip(fast, slow, strict):
+            assert torch.equal(a, b) and torch.equal(a, c_), name
+
+
+def test_degenerate_clouds_fast_path_at_the_benched_batch():
+    """B = 64 with k ~ U{1..8} objects per scene (SURVEY.md 8d's ragged variant: the bench's `ragged_k` leg): three steps, fast path on / off."""
+    bt = make_synthetic_batch(64, seed=1, num_objects=None)
+    d = {k: v.to(DEV) for k, v in bt.items()}
+    n_zero = int((bt["given_objs"].abs().amax(dim=(2, 3)) == 0).sum())
+    assert 150 < n_zero < 330
+
+    def run():
+        m, diff = _fresh("bf16x3")
+        out = _chain(m, diff, d, 64, 3, 4)
+        return out, (ws(m, "exp_src", (576,), torch.int32) if os.environ.get("LSDM_DEG_FAST") != "0" else None)
+    fast, exp = run()
+    slow, _ = _with_env({"LSDM_DEG_FAST": "0"}, run)
+    assert int((exp < 0).sum()) == n_zero and int(exp.min()) == -1
+    assert all(torch.equal(a, b) for a, b in zip(fast, slow))
 
 
 def test_sa3_sa4_item_lists_agree_with_one_block_per_group():

@@ -278,11 +278,12 @@ def test_generated_code_has_no_barrier_without_the_lds_wait_and_no_packed_fp32_n
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "barrier_wait_check.py")] + [str(p) for p in bare.glob("*-gfx950.s")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "fp_ws_kernel" in r.stdout, r.stdout[-2000:]
-    # The same generated code holds NO packed fp32 arithmetic in any translation unit that issues matrix instructions (round 4's lost updates
-    # came from v_pk_fma_f32 with operand selection in a wave sharing its SIMD with an MFMA wave; the Makefile removes the instruction class
-    # with -packed-fp32-ops).  Negative control: a unit compiled WITHOUT the flag mixes the two and must be flagged.
+    # The same generated code holds NO packed fp32 arithmetic in any translation unit that issues matrix instructions, and NO operand-selected
+    # packed fp32 instruction in ANY unit (round 4's lost updates came from v_pk_fma_f32 with operand selection in a wave sharing its SIMD with
+    # an MFMA wave; the Makefile removes the compiler's own packing, geometry.hip keeps explicit plain-pair forms).  Negative controls: a
+    # unit compiled WITHOUT the flag mixes the two; geometry.hip compiled WITH the SLP vectoriser on gets operand-selected forms -- both flagged.
     r = subprocess.run(["make", "-C", csrc, "check-packed", "ASMDIR=%s" % (tmp_path / "asm")], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "0 unit(s) mix" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "0 violation(s)" in r.stdout and "all on plain register pairs" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     pk = tmp_path / "pk"
     pk.mkdir()
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-inline-asm",
@@ -290,3 +291,10 @@ def test_generated_code_has_no_barrier_without_the_lds_wait_and_no_packed_fp32_n
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "packed_fp32_check.py")] + [str(p) for p in pk.glob("*-gfx950.s")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "denoise_r_kernel" in r.stdout, r.stdout[-2000:]
+    geo = tmp_path / "geo"
+    geo.mkdir()
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-inline-asm", "-ffp-contract=off",
+                    "--save-temps=obj", "-c", os.path.join(csrc, "geometry.hip"), "-o", str(geo / "geometry.o")], capture_output=True, timeout=900, check=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "packed_fp32_check.py")] + [str(p) for p in geo.glob("*-gfx950.s")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "op_sel" in r.stdout, r.stdout[-2000:]
