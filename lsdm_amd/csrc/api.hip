@@ -53,7 +53,7 @@ struct lsdm_ctx {
     // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
     // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
     DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
-    DenseH fp1_s{};              // fp1 + head as a register-chained blob (encoder_reg.hip::fp_s_kernel)
+    DenseH fp1_s{};              // fp1 + head as a register-chained blob (encoder_d.hip::fp_c_kernel)
     int fuse_y = getenv("LSDM_FUSE_Y") ? atoi(getenv("LSDM_FUSE_Y")) : 1;      // A/B switch: fp2's Y as an extra layer of the fp3 launch
     bool keep_taps = true;       // stage outputs that only feed a fused consumer (fp3) are still stored: off inside multi-step calls
     int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
@@ -75,7 +75,6 @@ struct lsdm_ctx {
     std::vector<int> step_host;          // (profiled passes: the step lists' block counts on the host, prof_read_counts)
     std::vector<int> pair_host[2];       // (... and the group's sa3 / sa4 lists')
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
-    int fp1_pipe = getenv("LSDM_FP1_PIPE") ? atoi(getenv("LSDM_FP1_PIPE")) : 1;      // A/B switch: fp1 + head on fp_c_kernel (stage pipeline, weights in registers) / fp_s_kernel
     int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = every ball-query group gets a 32-row block of its own; 2 = item lists for single steps of any batch
     int fp1_order = getenv("LSDM_FP1_ORDER") ? atoi(getenv("LSDM_FP1_ORDER")) : 1;   // A/B switch: fp1 + head walks the source points along that order
     int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
@@ -805,8 +804,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
     prof_exec(c, K_FP2, nc * (np == 2 && c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
     prof_mark(c, K_FP1, st);
-    if (np == 2 && c->fp1_reg && c->fp1_pipe) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
-    else if (np == 2 && c->fp1_reg) launch_fp_s(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
+    if (np == 2 && c->fp1_reg) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
     else launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
     prof_exec(c, K_FP1, nc * xm::FP1);
 }
@@ -1032,7 +1030,7 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         prof_exec(c, K_FP2, ncp * xm::FP2_PRE);
         prof_mark(c, K_FP1, st);
         // (fp1's fine level is the source cloud: walked along the Z curve sorted once per call, LSDM_FP1_ORDER=0: in index order)
-        (c->fp1_pipe ? launch_fp_c : launch_fp_s)(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
+        launch_fp_c(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
                                                   c->fp1_order ? c->inv_order + o * 1024 : nullptr, 0);
         prof_exec(c, K_FP1, ncp * xm::FP1);
     }

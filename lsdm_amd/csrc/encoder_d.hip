@@ -265,9 +265,6 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
     // rows of tile t (hdr: header byte `lane` of the tile) -> landing zone `buf`: each distinct row once, one 1 KB LDS-DMA per row, the rows dealt
     // round-robin over ALL EIGHT waves (issuing one takes a wave ~80 ns under load: the four A waves alone spent 0.6 of their 2.25 us per tile on it)
     auto fetch_rows = [&](int t, int hdr, int buf) {
-#ifdef LSDM_X_FPD_NODMA     // (timing experiment: results are wrong)
-        if (t != R.first) return;
-#endif
         const int nr = __builtin_amdgcn_readlane(hdr, 0);
         const float* yb = y + (size_t)(t / TPC) * S * C1 + 4 * lane;
         const unsigned dst0 = lds_addr(&rows[buf][0]);
@@ -419,9 +416,6 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
     auto p1_request = [&](int t, int prow) {
         const int c = t / TPC;
         const float* pr = points1 + ((size_t)(p1_mod > 0 ? c % p1_mod : c) * N + prow) * D1 + xc;
-#ifdef LSDM_X_FPD_NOP1      // (timing experiment: results are wrong)
-        if (t != R.first) return;
-#endif
         xa = load4f(pr); xb = load4f(pr + 4);
     };
     auto p1_store = [&](int buf) {
@@ -482,9 +476,6 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
             }
             FD_MARK(0);
             float* ob = out + (size_t)c * N * C2 + cb2 * 32 + pv;
-#ifdef LSDM_X_FPD_NOSTORE   // (timing experiment: results are wrong)
-            if (a2[0] == 12345.678f)
-#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int4 nl = *reinterpret_cast<const int4*>(&nlist[(i - 1) & 1][8 * g + 4 * hv]);      // accumulator r = 4 g + j <-> point 8 g + 4 h + j of the tile
@@ -507,10 +498,10 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
 // ---------------------------------------------------------------------------------------------
 // fp1 + head as a PIPELINE OF STAGES (round 5): fp_c_kernel.
 //
-// fp_s_kernel (encoder_reg.hip) carries 32 points per wave through the five layers in registers and streams every layer's 64 KB of weight
-// fragments through LDS: each 1 KB fragment read feeds two or three matrix instructions, so eight waves read 2 MB of fragments per round -- the
-// LDS port is ~90 % busy against the matrix time -- and one barrier per layer keeps all waves of a CU in the same phase (MFMA pipe 37 %).
-// Here the roles are swapped once more: the WEIGHTS stay in registers and the ACTIVATIONS move.  A persistent work-group of eight waves per CU;
+// Round 4's form (fp_s_kernel, removed in round 6) carried 32 points per wave through the five layers in registers and streamed every layer's
+// 64 KB of weight fragments through LDS: each 1 KB fragment read feeds two or three matrix instructions, so eight waves read 2 MB of fragments
+// per round -- the LDS port is ~90 % busy against the matrix time -- and one barrier per layer keeps all waves of a CU in the same phase (MFMA
+// pipe 37 %).  Here the roles are swapped once more: the WEIGHTS stay in registers and the ACTIVATIONS move.  A persistent work-group of eight waves per CU;
 // wave 2 s + f owns channel blocks 2 f, 2 f + 1 of layer s (128 registers of hi + lo fragments, loaded once) for s = 0 .. 3 (the three fp1
 // layers and conv1); a 32-point tile moves from stage to stage through double-buffered LDS tiles (bf16 hi / lo planes, stored in the k-slot
 // order the next layer's fragments expect: one 16-byte piece per lane, k-step and plane), ONE barrier per tile, every stage working on a
@@ -521,8 +512,8 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
 //                 conv2 (128 -> 3, zero-padded block): its k-steps are the fragments conv1's two waves hold in registers -- wave 6 contracts
 //                 k-steps 0..3 of tile i - 4 and parks the accumulators in LDS, wave 7 continues with k-steps 4..7 an iteration later (the same
 //                 accumulation order as one wave doing all eight) and stores the tile's rows.
-// Same arithmetic in the same order as fp_s_kernel on the same fragment blob (api.hip::build_chain_blob): bit-identical.
-// The points of a cloud are walked along `order` (see fp_s_kernel); position -> point -> neighbour list -> rows is a chain of three dependent
+// Same arithmetic in the same order as that form on the same fragment blob (api.hip::build_chain_blob): it was bit-identical to it.
+// The points of a cloud are walked along `order` (optional; cloud c % order_mod's when order_mod > 0: the source cloud's Z curve); position -> point -> neighbour list -> rows is a chain of three dependent
 // loads, each link requested one iteration ahead of the next.
 namespace fpc {
 constexpr int TM = 32, C = 128, KS = C / 16, NB = C / 32, NP = 2, NL = 4;
@@ -636,33 +627,18 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
         auto request = [&](int g, int pv, int hv) {               // rows of tile g (its list in ixq / wq); then the plan words shift by one tile
             const int t = R.first + g * R.stride;
             const float* pb = points2 + (size_t)(t / TPC) * S * C + 4 * pv;
-#if defined(LSDM_X_FPC) && (LSDM_X_FPC & 1)      // (timing experiment: no row loads after the first tile; results are wrong)
-            if (g == 0)
-#endif
 #pragma unroll
             for (int q = 0; q < npair; ++q) {
-#if defined(LSDM_X_FPC) && (LSDM_X_FPC & 4)      // (timing experiment: row numbers without the cross-lane shuffles; results are wrong)
-                const int src = 2 * q + hv;
-                ra[q] = load4f(pb + (size_t)((ixq[0] + src) & 1023) * C);
-                rb[q] = load4f(pb + (size_t)((ixq[1] + src) & 1023) * C);
-                rd[q] = load4f(pb + (size_t)((ixq[2] + src) & 1023) * C);
-#else
                 const int src = 2 * q + hv;
                 ra[q] = load4f(pb + (size_t)__shfl(ixq[0], src) * C);
                 rb[q] = load4f(pb + (size_t)__shfl(ixq[1], src) * C);
                 rd[q] = load4f(pb + (size_t)__shfl(ixq[2], src) * C);
-#endif
             }
             ni = nq;
 #pragma unroll
             for (int j = 0; j < 3; ++j) wi[j] = wq[j];
-#if defined(LSDM_X_FPC) && (LSDM_X_FPC & 2)      // (timing experiment: no plan-word loads; results are wrong)
-            if (g == 0)
-#endif
-            {
             if (g + 1 < ntile) list_load(g + 1, nq1, ixq1, wq1);
             if (g + 2 < ntile) nq2 = point_load(g + 2);
-            }
         };
         auto shift = [&]() {                                      // (after the loads of request() have been waited for: next iteration's top)
             nq = nq1; nq1 = nq2;

@@ -355,345 +355,6 @@ __global__ __launch_bounds__(NW * 64) void sa_s_kernel(const float* __restrict__
     }
 }
 
-// Measurement hooks of tools/ubench/chain_bench.hip (never defined in the library build): drop one cost at a time from fp_s_kernel
-//   LSDM_X_NOLDS  weight fragments come from a register instead of LDS      LSDM_X_NOMFMA  no matrix instructions
-//   LSDM_X_NOEPI  no ReLU + hi/lo split between the layers                  LSDM_X_NOBAR   no barrier / panel wait per layer
-#ifdef LSDM_X_NOLDS
-#define XWFRAG(W, KS, NBI, s, pl, lane) xfrag_const
-#else
-#define XWFRAG(W, KS, NBI, s, pl, lane) wfrag_lds<NP>(W, KS, NBI, s, pl, lane)
-#endif
-#ifdef LSDM_X_NOMFMA
-#define XMFMA(a, b, c) xfake_mfma(a, b, c)
-__device__ __forceinline__ f32x16 xfake_mfma(const bf16x8& a, const bf16x8& b, f32x16 c) {
-    c[0] += (float)a[0] * (float)b[0];
-    return c;
-}
-#else
-#define XMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
-#ifdef LSDM_X_NOBAR
-#define XBARRIER
-#else
-#define XBARRIER lds_dma_wait(); __syncthreads();
-#endif
-#ifdef LSDM_X_NOEPI
-#define XSPLIT(v, oh, ol) { oh[0] = (__bf16)v[0]; ol[0] = (__bf16)v[7]; }
-#else
-#define XSPLIT(v, oh, ol) split8<NP>(v, oh, ol)
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// fp1 + head as a register-chained stack (bf16x3): interpolation of the three nearest level-1 rows (pointnet2_utils.py:286-297)
-// -> 3 x (conv 128 -> 128 + BN + ReLU) -> conv1 + bn1 + ReLU -> conv2 (128 -> 3)   (pointnet2.py:72-80).
-// fp_h_kernel runs the five layers on a 64-point LDS tile: every layer is an LDS round trip with a work-group barrier and
-// every work-group streams the 320 KB of weight fragments for 64 points (MFMA pipe 25 % busy).  Here a wave owns 32 points and
-// carries their activations through the whole stack in registers (layer_reg's accumulator -> operand identity).  The weights
-// of one LAYER (64 KB as hi + lo fragments) are a panel: two panels in LDS, the next layer's is copied global -> LDS by the
-// LDS-DMA path (no staging registers) while the waves work on the current one, ONE barrier per layer -- inside a layer the
-// waves drift apart, so one wave's epilogue / gather overlaps another's MFMAs (measured with tools/ubench/chain_bench.hip:
-// sixteen 16 KB panels with a barrier each cost 75 us of 272; the barriers keep all waves of a CU in the same phase and expose
-// the gather latency of every round).  conv2's padded block stays resident.  Weight traffic per point: 1 KB instead of 5 KB.
-// (Round 3: requesting the first half of the NEXT round's gather -- 24 x 16 bytes per lane -- in front of conv2 and the second half
-// next to the first half's interpolation arithmetic was measured slower, 349 vs 290 us: the 96 staging registers do not fit next
-// to the two operand sets at two waves per SIMD and part of them goes through scratch.  The two half-work-groups OUT OF PHASE -- waves
-// 0-3 gathering while waves 4-7 run the layers and vice versa, so that each SIMD's matrix pipe always has exactly one wave feeding it and
-// the other wave's loads and interpolation arithmetic issue in its gaps; panels streamed once per phase -- was measured slower as well,
-// 294 vs 271 us, 318 with the round's 48 row requests issued at once: a SIMD's pipe is fed better by two waves that both issue MFMAs and
-// drift apart inside a layer than by one wave with dependent accumulator chains and block-placed epilogues.)
-// (The gather as four batches of two k-steps with two batches in flight -- the L2 round trips of consecutive batches overlapping --
-// measured the same as two batches of four: 276 vs 275 us.)
-// blob: four layers [nb][s][plane][lane][8] (layer 1 in channel order, later layers in accumulator order) + conv2 zero-padded
-// to 32 channels; biases [4 x 128 | 32].
-template <int NW, int NP, int PH = 1>
-__global__ __launch_bounds__(NW * 64, NW / 4) void fp_s_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx,
-                                                        const float* __restrict__ nn_w, int N, int S, long long total_points,
-                                                        const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b,
-                                                        float* __restrict__ out, int dbg, const int* __restrict__ order, int order_mod) {
-    constexpr int C = 128, NT = NW * 64, KS = C / 16, NB = C / 32, F = KS * NP;
-    constexpr int NL = 4, FL = NB * F;                       // fragments (1 KiB) per layer
-    constexpr int FPN = FL / PH, NBP = NB / PH;              // PH panels per layer: fragments / channel blocks per panel
-    static_assert(NB % PH == 0 && (NL * PH) % 2 == 0, "panel split");
-    constexpr int GK = NW > 8 ? 2 : 4;                       // k-steps per batch of gather requests (staging registers)
-    __shared__ __attribute__((aligned(16))) __bf16 wl[2][FPN * 512];
-    // LSDM_FP1_ROWS = 1 (A/B, round 4; default 0): the gather fetches WHOLE rows -- one wave instruction = two 512-byte rows, lanes 0-31 one
-    // point's row, lanes 32-63 the next point's: 8 full lines per instruction -- interpolates and splits them in that layout and turns them
-    // into the operand layout (lane (p, h) <- channels 16 s + 8 h .. of ITS point p) through a 2 KB LDS slot of the wave, four points at a
-    // time; conv2's block moves out of LDS to make room (read through the L1, as with PH > 1).  The direct form has every lane fetch its own
-    // operand slices: an instruction touches 32 rows and 32 bytes of each of their lines, every line is requested by four instructions.
-    // Bit-identical results; measured the SAME time (271.5 / 273.1 against 270.5 / 270.2 us, same box): the repeated requests of a line are
-    // L1 hits and cost nothing that shows -- what bounds the stage's gather is the round trip of its first touch, not the number of touches.
-#ifndef LSDM_FP1_ROWS
-#define LSDM_FP1_ROWS 0
-#endif
-    constexpr bool ROWS = LSDM_FP1_ROWS != 0 && NP == 2;
-    constexpr bool W5LDS = PH == 1 && !ROWS;
-    constexpr int TRP = 4 * C;                                  // plane stride of a wave's transposition slot [plane][4 points][C]
-    __shared__ __attribute__((aligned(16))) __bf16 tr[ROWS ? NW * NP * TRP : 8];
-    // conv2's padded block: resident in LDS, or (PH > 1: two work-groups share a CU's LDS; ROWS) read from global memory through the L1
-    __shared__ __attribute__((aligned(16))) __bf16 w5[W5LDS ? F * 512 : 8];
-    __shared__ __attribute__((aligned(16))) float bl[NL * C + 32];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if constexpr (W5LDS)
-        for (int e = tid; e < F * 64; e += NT) *reinterpret_cast<bf16x8*>(w5 + (size_t)e * 8) = gload<bf16x8>(blob_w + (size_t)NL * FL * 512 + (size_t)e * 8);
-    const __bf16* w5g = blob_w + (size_t)NL * FL * 512;
-    for (int e = tid; e < NL * C + 32; e += NT) bl[e] = blob_b[e];
-    const int p = lane & 31, h = lane >> 5;
-#ifdef LSDM_X_NOLDS
-    bf16x8 xfrag_const = gload<bf16x8>(blob_w + lane * 8);
-    asm volatile("" : "+v"(xfrag_const));
-#endif
-
-    // panel q (PH per layer, channel-block major) -> LDS buffer q & 1: each wave copies FPN / NW fragments, a fragment = one 1 KiB
-    // wave-wide LDS-DMA
-    auto fetch = [&](int q) {
-        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FPN * 512);   // (round-invariant: keep the copy inside the loop)
-#pragma unroll
-        for (int i = 0; i < (FPN + NW - 1) / NW; ++i) {
-            const int fr = wave + i * NW;
-            if (FPN % NW == 0 || fr < FPN)
-                lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
-        }
-    };
-    // the same copy piecewise, issued from inside the channel blocks of the panel before it (LSDM_FPS_SPREAD): the copies of a wave then
-    // issue in the shadow of its own matrix instructions instead of as one block in front of them (sa_w_kernel, encoder_u.hip)
-#ifndef LSDM_FPS_SPREAD
-#define LSDM_FPS_SPREAD 1
-#endif
-    constexpr bool SPREAD = LSDM_FPS_SPREAD != 0 && FPN % (NW * NBP) == 0;
-    constexpr int PPB = FPN / NW / NBP;                      // pieces per channel block and wave
-    auto fetch_pieces = [&](int q, int blk) {
-        const __bf16* src = opaque_ptr(blob_w + (size_t)q * FPN * 512);
-#pragma unroll
-        for (int i = blk * PPB; i < (blk + 1) * PPB; ++i) {
-            const int fr = wave + i * NW;
-            lds_dma16(src + (size_t)fr * 512 + lane * 8, __builtin_amdgcn_readfirstlane(lds_addr(&wl[q & 1][(size_t)fr * 512])));
-        }
-    };
-    fetch(0);
-    lds_dma_wait();
-    __syncthreads();
-
-    const long long rounds = total_points / (32 * NW);
-    const XcdRounds sched = xcd_rounds((int)rounds);       // the work-groups of an XCD walk the rounds together (common.hpp)
-    const long long rbeg = sched.first, rend = sched.end, rstep = sched.stride;
-    // neighbour indices / weights of a round are requested during the previous one
-    // order (optional; round 5): the points of a cloud are walked along its Z curve (encoder_d.hip::morton_order_kernel, once per call on the
-    // source clouds) instead of in index order, so that the 32 points of a wave are neighbours in space and share their level-1 neighbours:
-    // ~49 distinct rows per wave and round instead of ~93 of the 96 requested -- half the first-touch round trips of the gather.  Position k of
-    // cloud c is point order[(c % order_mod) * N + k]; its neighbour list and its output row are addressed by the point.  Rows of the stack
-    // are independent: results do not depend on the walking order.  The point number of a round is requested two rounds ahead, its neighbour
-    // list one round ahead.
-    int ni[3] = {0, 0, 0};
-    float nw[3] = {0.0f, 0.0f, 0.0f};
-    int pn_next = 0, pn_cur = 0;            // point (within its cloud) of this lane in the next round / in the round whose list is in ni, nw
-    auto point_of = [&](long long rd) -> int {
-        const long long k = rd * (32 * NW) + wave * 32 + p;
-        const long long c = k / N;
-        return order ? order[(size_t)(order_mod > 0 ? c % order_mod : c) * N + (k - c * N)] : (int)(k - c * N);
-    };
-    auto request = [&](long long rd, int pn) {
-        const long long c = (rd * (32 * NW) + wave * 32 + p) / N;
-        const size_t o = ((size_t)c * N + pn) * 3;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { ni[j] = nn_idx[o + j]; nw[j] = nn_w[o + j]; }
-        if (dbg == 1) { ni[0] = ni[1] = ni[2] = (int)((o / 3) % S); }          // experiment: sequential rows
-        if (dbg == 2) { ni[0] = ni[1] = ni[2] = (int)(wave * 4); }               // experiment: one row per wave
-    };
-    if (rbeg < rend) {
-        pn_cur = point_of(rbeg);
-        request(rbeg, pn_cur);
-        if (rbeg + rstep < rend) pn_next = point_of(rbeg + rstep);
-    }
-    for (long long rd = rbeg; rd < rend; rd += rstep) {
-        const long long pt = rd * (32 * NW) + wave * 32 + p;    // this lane's walking position (both halves of the wave: same point)
-        const long long c = pt / N;
-        const int pn_this = pn_cur;                             // the point at that position
-        [[maybe_unused]] const float* r0 = points2 + ((size_t)c * S + ni[0]) * C + 8 * h;
-        const float* r1 = points2 + ((size_t)c * S + ni[1]) * C + 8 * h;
-        const float* r2 = points2 + ((size_t)c * S + ni[2]) * C + 8 * h;
-        const float w0 = nw[0], w1 = nw[1], w2 = nw[2];
-        bf16x8 yh[KS], yl[KS], zh[KS], zl[KS];
-        if constexpr (ROWS) {
-            // ---- row-wise gather: chunk ch = points 4 ch .. 4 ch + 3 of the wave as two instructions per neighbour (pair g: lanes 0-31 <- point
-            // 4 ch + 2 g, lanes 32-63 <- the next); four chunks (24 loads, 96 registers) in flight
-            __bf16* trw = tr + (size_t)wave * NP * TRP;
-            const float* pb = points2 + (size_t)c * S * C + 4 * p;
-            auto pick_i = [&](int v, int la) { const int a = __builtin_amdgcn_readlane(v, la), b = __builtin_amdgcn_readlane(v, la + 1); return h ? b : a; };
-            auto pick_f = [&](float v, int la) { return __builtin_bit_cast(float, pick_i(__builtin_bit_cast(int, v), la)); };
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f32x4 a[4][2], b[4][2], d[4][2];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int la = 4 * (4 * half + q) + 2 * g;          // lane (= point of the wave) that holds pair g's first point
-                        a[q][g] = load4f(pb + (size_t)pick_i(ni[0], la) * C);
-                        b[q][g] = load4f(pb + (size_t)pick_i(ni[1], la) * C);
-                        d[q][g] = load4f(pb + (size_t)pick_i(ni[2], la) * C);
-                    }
-                // (the weights of this round are still needed below: the next round's indices are requested after the last chunk)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ch = 4 * half + q;
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int la = 4 * ch + 2 * g;
-                        const float u0 = pick_f(nw[0], la), u1 = pick_f(nw[1], la), u2 = pick_f(nw[2], la);
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = interp3(a[q][g][j], b[q][g][j], d[q][g][j], u0, u1, u2);
-                        store_split4<NP>(trw + (2 * g + h) * C + 4 * p, TRP, v[0], v[1], v[2], v[3]);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    if ((p >> 2) == ch) {
-#pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            yh[s] = *reinterpret_cast<const bf16x8*>(trw + (p & 3) * C + 16 * s + 8 * h);
-                            yl[s] = *reinterpret_cast<const bf16x8*>(trw + (p & 3) * C + 16 * s + 8 * h + TRP);
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            if (rd + rstep < rend) { request(rd + rstep, pn_next); pn_cur = pn_next; if (rd + 2 * rstep < rend) pn_next = point_of(rd + 2 * rstep); }
-        } else {
-        // ---- interpolated operand, k-step s = channels 16 s + 8 h .. + 7 of this lane's point (four k-steps per batch of loads)
-#pragma unroll
-        for (int s0 = 0; s0 < KS; s0 += GK) {
-            f32x4 a[GK][2], b[GK][2], d[GK][2];
-            // (row-major request order: the four 16-byte pieces a lane pair takes from one 128-byte line are consecutive
-            // instructions, so the line is still in the L1 when its last piece is asked for)
-#pragma unroll
-            for (int s = 0; s < GK; ++s)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) a[s][q] = load4f(r0 + 16 * (s0 + s) + 4 * q);
-#pragma unroll
-            for (int s = 0; s < GK; ++s)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) b[s][q] = load4f(r1 + 16 * (s0 + s) + 4 * q);
-#pragma unroll
-            for (int s = 0; s < GK; ++s)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) d[s][q] = load4f(r2 + 16 * (s0 + s) + 4 * q);
-            if (s0 + GK >= KS && rd + rstep < rend) { request(rd + rstep, pn_next); pn_cur = pn_next; if (rd + 2 * rstep < rend) pn_next = point_of(rd + 2 * rstep); }
-#pragma unroll
-            for (int s = 0; s < GK; ++s) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[4 * q + j] = interp3(a[s][q][j], b[s][q][j], d[s][q][j], w0, w1, w2);
-                split8<NP>(v, yh[s0 + s], yl[s0 + s]);
-            }
-        }
-        }
-        // one channel block of a layer: accumulators start from the bias, MFMAs against the resident panel, ReLU + split into the
-        // next layer's two k-step fragments
-#define FP_BLOCK(L, NBI, XH, XL, OH, OL)   /* channel block NBI of layer L, read from the panel that holds it */                                                                                     \
-    {                                                                                                                        \
-        if constexpr (SPREAD) fetch_pieces(nextq, (NBI) % NBP);                                                              \
-        f32x16 acc;                                                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                      \
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bl + lz + (L) * C + 32 * (NBI) + 8 * q + 4 * h);               \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[4 * q + j] = bq[j];                                            \
-        }                                                                                                                    \
-        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                     \
-            const bf16x8 wh = XWFRAG(W, KS, (NBI) % NBP, s, 0, lane);                                                              \
-            if constexpr (NP == 2) {                                                                                         \
-                const bf16x8 wlo = XWFRAG(W, KS, (NBI) % NBP, s, 1, lane);                                                         \
-                acc = XMFMA(wh, XL[s], acc);                                                                                 \
-                acc = XMFMA(wlo, XH[s], acc);                                                                                \
-            }                                                                                                                \
-            acc = XMFMA(wh, XH[s], acc);                                                                                     \
-            if (s % 3 == 2) __builtin_amdgcn_sched_barrier(0);                                                               \
-        }                                                                                                                    \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                                   \
-            float v[8];                                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = reluf(acc[8 * s2 + j]);                                     \
-            XSPLIT(v, OH[2 * (NBI) + s2], OL[2 * (NBI) + s2]);                                                               \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-    }
-        // a layer: start the copy of the next layer's panel (its buffer was last read one barrier ago), four channel blocks from
-        // this layer's panel, then wait for the own copies and the barrier that publishes the panel
-#define FP_PANEL(L, H, XH, XL, OH, OL, BODY)                                                                                 \
-    {                                                                                                                        \
-        constexpr int nextq = ((L) * PH + (H) + 1) % (NL * PH);                                                              \
-        if constexpr (!SPREAD) fetch(nextq);                                                                                 \
-        const __bf16* W = &wl[((L) * PH + (H)) & 1][0];                                                                      \
-        int lz = 0;                                                                                                          \
-        asm volatile("" : "+v"(lz));                                                                                         \
-        W += lz;                                                                                                             \
-        BODY                                                                                                                 \
-        XBARRIER                                                                                                             \
-    }
-#define FP_LAYER(L, XH, XL, OH, OL)                                                                                          \
-    if constexpr (PH == 1) {                                                                                                 \
-        FP_PANEL(L, 0, XH, XL, OH, OL, FP_BLOCK(L, 0, XH, XL, OH, OL) FP_BLOCK(L, 1, XH, XL, OH, OL) FP_BLOCK(L, 2, XH, XL, OH, OL) FP_BLOCK(L, 3, XH, XL, OH, OL)) \
-    } else {                                                                                                                 \
-        FP_PANEL(L, 0, XH, XL, OH, OL, FP_BLOCK(L, 0, XH, XL, OH, OL) FP_BLOCK(L, 1, XH, XL, OH, OL))                        \
-        FP_PANEL(L, 1, XH, XL, OH, OL, FP_BLOCK(L, 2, XH, XL, OH, OL) FP_BLOCK(L, 3, XH, XL, OH, OL))                        \
-    }
-        FP_LAYER(0, yh, yl, zh, zl)
-        FP_LAYER(1, zh, zl, yh, yl)
-        FP_LAYER(2, yh, yl, zh, zl)
-        FP_LAYER(3, zh, zl, yh, yl)
-#undef FP_LAYER
-#undef FP_PANEL
-#undef FP_BLOCK
-        // ---- conv2 (128 -> 3, rows zero-padded to one 32-channel block), direct orientation D[point][channel] -------------------
-        {
-            int lz = 0;
-            asm volatile("" : "+v"(lz));
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 wh = W5LDS ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 0, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP) * 64 + lane) * 8);
-                if constexpr (NP == 2) {
-                    const bf16x8 wlo = W5LDS ? wfrag_lds<NP>(w5 + lz, KS, 0, s, 1, lane) : gload<bf16x8>(opaque_ptr(w5g) + ((size_t)(s * NP + 1) * 64 + lane) * 8);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], wh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], wlo, acc, 0, 0, 0);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], wh, acc, 0, 0, 0);
-            }
-            {
-                // accumulator r of lane (p, h) = channel p of the wave's point acc_row(r, lane): its output row is that point's -- read out of the
-                // lane that owns it
-                const float bv = bl[lz + NL * C + (p < 3 ? p : 0)];
-                const size_t cb = (size_t)c * N;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pr = __shfl(pn_this, acc_row(r, lane));
-                    if (p < 3) out[(cb + pr) * 3 + p] = acc[r] + bv;
-                }
-            }
-        }
-    }
-}
-
-void launch_fp_s(int nc, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
-                 hipStream_t st, const int* order, int order_mod) {
-    // timing experiment (compile-time only, `make TIMING=1`; results are wrong with it): 1 sequential rows, 2 one row per wave
-#ifdef LSDM_TIMING_EXPERIMENTS
-    static const int dbg = getenv("LSDM_DBG_GATHER") ? atoi(getenv("LSDM_DBG_GATHER")) : 0;
-#else
-    constexpr int dbg = 0;
-#endif
-    const long long tot = (long long)nc * 1024;
-    // (12 waves -- three per SIMD, as sa3 runs -- do not fit: two 128-channel operand sets + accumulators + fragments need ~172 VGPRs against
-    // the 168 of that occupancy and the build spills 95 of them)
-    // (two work-groups of four waves per CU on half-layer panels -- fp_s_kernel<4, 2, 2>, grid 512: the two groups drift out of phase, one gathers
-    // while the other multiplies, for twice the panel traffic -- measured 290 against 271 us, round 4)
-    hipLaunchKernelGGL((fp_s_kernel<8, 2>), dim3(256), dim3(512), 0, st, points2, nn_idx, nn_w, 1024, 1024, tot, blob_w, blob_b, out, dbg, order, order_mod);
-}
-
 void launch_sa_r(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st) {
     // persistent grids: sa1 (15 KB of LDS, 57 VGPRs) 4 workgroups of 8 waves per CU, sa2 (69 KB, 123 VGPRs) 2 per CU

@@ -581,7 +581,7 @@ extern "C" __attribute__((visibility("default"))) int lsdm_debug_saw_phase(unsig
 template <int NP, bool PAIR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sa_w_kernel(
     const float* __restrict__ U, const float* __restrict__ V, const int* __restrict__ cent_idx, const int* __restrict__ ball,
-    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out, int dbg,
+    long long total_centroids, const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out,
     const int4* __restrict__ pmeta, const int* __restrict__ pcount) {
     constexpr int C1 = 256, C2 = 256, C3 = 512, NSRC = 64, S = 16, NW = 4, NT = NW * 64;
     constexpr int KS = C1 / 16;
@@ -689,8 +689,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (rd + rstep < rend) request_idx(item_of(rd + rstep));
         }
         SAW_MARK(0);
-#define SAW_BEGIN(Q) { if (!(dbg & 1) && !SPREAD) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
-#define SAW_END(Q) lds_dma_wait(); if (!(dbg & 2)) __syncthreads(); SAW_MARK(5); }
+#define SAW_BEGIN(Q) { if (!SPREAD) fetch(((Q) + 1) % NPANEL); const __bf16* W = &wl[(Q) & 1][0]; int lz = 0; asm volatile("" : "+v"(lz)); W += lz;
+#define SAW_END(Q) lds_dma_wait(); __syncthreads(); SAW_MARK(5); }
         // ---- layer 2 (transposed): two channel blocks per panel as two interleaved accumulator chains
 #pragma unroll
         for (int q = 0; q < NB2 / PB; ++q) {
@@ -854,13 +854,12 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     // fp2 333 us in the loop-invariant schedule against 303 in the strict one, whose p1 rows are contiguous.)
     const int arow = tid / TPP, sub = tid % TPP;
     const size_t ao = ((size_t)c * N + n0 + arow) * 3;
-    const int dbg = keep_out >> 1;                       // timing experiments (LSDM_DBG_FP2): 1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs
     int xrow[XIT];
     if (p1_remap) {
 #pragma unroll
         for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)c * N + n0 + (tid + it * NT) / (D1 / 4)];
     }
-    const int i0 = (dbg & 1) ? 0 : nn_idx[ao + 0], i1 = (dbg & 1) ? 0 : nn_idx[ao + 1], i2 = (dbg & 1) ? 0 : nn_idx[ao + 2];
+    const int i0 = nn_idx[ao + 0], i1 = nn_idx[ao + 1], i2 = nn_idx[ao + 2];
     const float w0 = nn_w[ao + 0], w1 = nn_w[ao + 1], w2 = nn_w[ao + 2];
     if (p1_remap) {
 #pragma unroll
@@ -874,6 +873,19 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
 #pragma unroll
         for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4);
     }
+    // The weight fragments a wave needs FIRST in a channel block's k loop are requested a whole block (or phase) ahead -- the first k-group of
+    // layer 1 here, in front of the gather; every later block's while the block before it runs (FUSE form: fp3 / fp4): a k loop that requests
+    // its own first group waits a loaded L2 round trip per channel block, six times per tile.  Same fragments, same order of arithmetic.
+    using TS0 = SplitH<NW, TM, C1>;
+    constexpr int U1 = kgroup(D1 / 16), U2 = kgroup(C1 / 16);
+    static_assert(!FUSE || (U1 == U2 && kgroup(C2 / 16) == U2), "one fragment-group type for the chained prefetch");
+    [[maybe_unused]] WFrag<NP, U1> wpre;
+#ifdef LSDM_FPPRE_NOCHAIN      // (A/B build only: every k loop requests its own first k-group)
+    constexpr bool CHAIN = false;
+#else
+    constexpr bool CHAIN = FUSE;
+#endif
+    if constexpr (CHAIN) wfrag_load<NP, D1 / 16>(wpre, l1.w, C1, wave % TS0::CSTEP, 0, lane);
     // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
     {
         const int row = arow;
@@ -936,16 +948,27 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
     }
     __syncthreads();
+    using T2 = SplitH<NW, TM, C2>;
+    const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int q = 0; q < NCB; ++q)
-        if (!((keep_out >> 1) & 8)) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
+        for (int q = 0; q < NCB; ++q) {
+            WFrag<NP, U1> wnext;
+            if (q + 1 < NCB) wfrag_load<NP, D1 / 16>(wnext, l1.w, C1, cb0 + (q + 1) * TS::CSTEP, 0, lane);
+            else wfrag_load<NP, C1 / 16>(wnext, l2.w, C2, cb2, 0, lane);               // layer 2's first block: lands under the epilogue + barrier
+            mma_kloop_pre_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane, wpre);
+            wpre = wnext;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NCB; ++q)
+            mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
+    }
     __syncthreads();
     // ---- phase D: layer-1 epilogue -> bufB, layer 2 (direct orientation) -> global -----------------------------------------------
 #pragma unroll
     for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
     __syncthreads();
-    using T2 = SplitH<NW, TM, C2>;
-    const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
     if constexpr (!FUSE) {
 #pragma unroll 1
         for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
@@ -953,8 +976,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
             acc_zero_h(a2);
             const int col = cb * 32 + (lane & 31);
             const float bv = l2.b[col];
-            if (!((keep_out >> 1) & 4)) mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
-            if (((keep_out >> 1) & 2) && a2[0][0] != 12345.0f) continue;
+            mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, l2.w, C2, cb, 0, lane);
 #pragma unroll
             for (int rb = 0; rb < T2::RB; ++rb)
 #pragma unroll
@@ -975,7 +997,14 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
             f32x4 bv2[4];
             load_bias_h(bv2, l2.b, cb2 + q * T2::CSTEP, lane);
             acc_bias_h(a2[q], bv2);
-            mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
+            if constexpr (CHAIN) {
+                WFrag<NP, U2> wnext;
+                if (q + 1 < NCB2) wfrag_load<NP, C1 / 16>(wnext, l2.w, C2, cb2 + (q + 1) * T2::CSTEP, 0, lane);
+                else wfrag_load<NP, C2 / 16>(wnext, l3.w, 256, wave % SplitH<NW, TM, 256>::CSTEP, 0, lane);      // the extra layer's first block
+                mma_kloop_pre_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane, wpre);
+                wpre = wnext;
+            } else
+                mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
         }
         __syncthreads();
 #pragma unroll
@@ -995,12 +1024,20 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         __syncthreads();
         using T3 = SplitH<NW, TM, 256>;
         const int cb3 = wave % T3::CSTEP, rg3 = wave / T3::CSTEP;
-#pragma unroll 1
-        for (int cb = cb3; cb < T3::CB; cb += T3::CSTEP) {
+        constexpr int NCB3 = T3::CB / T3::CSTEP;
+#pragma unroll
+        for (int q3 = 0; q3 < NCB3; ++q3) {
+            const int cb = cb3 + q3 * T3::CSTEP;
             f32x16 a3[T3::RB];
             acc_zero_h(a3);
             const int col = cb * 32 + (lane & 31);
-            mma_kloop_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane);
+            if constexpr (CHAIN) {
+                WFrag<NP, U2> wnext;
+                if (q3 + 1 < NCB3) wfrag_load<NP, C2 / 16>(wnext, l3.w, 256, cb + T3::CSTEP, 0, lane);
+                mma_kloop_pre_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane, wpre);
+                if (q3 + 1 < NCB3) wpre = wnext;
+            } else
+                mma_kloop_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane);
 #pragma unroll
             for (int rb = 0; rb < T3::RB; ++rb)
 #pragma unroll
@@ -1011,594 +1048,6 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         }
     }
 }
-
-// ---------------------------------------------------------------------------------------------
-// fp2 as a PERSISTENT, WAVE-SPECIALISED work-group (one per CU, 8 waves): the same arithmetic as fp_pre_kernel<D1, C1, C2> in the same
-// order (bit-identical results), but the gather of tile n + 1 runs NEXT TO the matrix work of tile n instead of in front of its own.
-// fp_pre_kernel spends a tile as [indices -> 192 KB of Y rows through L1 -> interpolation -> 5 barriers of dependent phases]; its MFMAs
-// are 13 % of a tile's time, and the second work-group of the CU is usually in the same phase (PMC: MFMA pipe 23 % busy).
-//   waves 0..3 ("matrix"): accumulators <- interpolated tile T (LDS), layer 1 over the p1 operand tile, ReLU + split -> bufB, layer 2, stores
-//   waves 4..7 ("gather"): indices, the three Y rows and the p1 row of every point of the NEXT tile -> T / bufX
-// A work-group's waves are placed on the SIMDs cyclically, so every SIMD holds one wave of each role: the gather wave's VMEM / VALU /
-// LDS-store stream fills the issue slots next to the matrix wave's MFMAs without any compiler scheduling.  Three barriers per tile:
-//   B1  T(n), bufX(n) complete; bufB free     | matrix: acc <- T, layer-1 MFMAs            | gather: requests rows of tile n + 1 (batch 1) + p1
-//   B2  T, bufX free                          | matrix: ReLU + split -> bufB                | gather: batch 1 -> T, requests batch 2
-//   B3  bufB complete                         | matrix: layer 2 + output stores             | gather: batch 2 -> T, p1 -> bufX, indices of tile n + 2
-// T (64 KB fp32) + bufX + bufB (hi / lo planes) = 150 KB of LDS.  Tiles are walked in the XCD-cooperative round order (common.hpp).
-#ifdef LSDM_PHASE_TIMING
-__device__ unsigned long long g_ws_phase[64 * 16];   // 64 spread copies of 16 slots: matrix role 0..5 (+7 = tiles), gather role 8..13
-#define WS_T0() unsigned long long wt_ = __builtin_amdgcn_s_memtime(); unsigned long long wd_[6] = {}
-#define WS_MARK(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); wd_[slot] += n_ - wt_; wt_ = n_; } while (0)
-#define WS_FLUSH(base, ntiles) do { if (lane == 0 && (wave & 3) == 0) { unsigned long long* g_ = g_ws_phase + (blockIdx.x & 63) * 16 + (base); \
-        for (int i_ = 0; i_ < 6; ++i_) atomicAdd(g_ + i_, wd_[i_]); atomicAdd(g_ + 7, (unsigned long long)(ntiles)); } } while (0)
-#else
-#define WS_T0() do {} while (0)
-#define WS_MARK(slot) do {} while (0)
-#define WS_FLUSH(base, ntiles) do {} while (0)
-#endif
-// TM_ = 32 (LSDM_FP2_WS=3): half the tile, and the layer-1 weight fragments (64 KB as hi + lo) RESIDENT IN LDS next to it -- with the layer-2
-// fragments in the matrix waves' registers a tile then pulls nothing but its own rows through the L1.
-template <int D1, int C1, int C2, int TM_ = 64>
-__global__ __launch_bounds__(512) void fp_ws_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
-                                                    const float* __restrict__ y, const int* __restrict__ nn_idx,
-                                                    const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
-                                                    float* __restrict__ out, int p1_mod, int total_tiles) {
-    constexpr int TM = TM_, NWM = 4, NP = 2, NTG = 256;
-    constexpr bool W1LDS = TM_ == 32;
-    static_assert((TM == 64 || TM == 32) && C1 % 64 == 0, "tile rows are whole bank rounds");
-    constexpr int LDT = C1;
-    auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
-    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
-    __shared__ __attribute__((aligned(16))) float tile[TM * LDT];
-    __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
-    __shared__ __attribute__((aligned(16))) __bf16 bufB[NP * PB];
-    __shared__ __attribute__((aligned(16))) float b1s[C1];
-    __shared__ __attribute__((aligned(16))) __bf16 w1s[W1LDS ? (D1 / 16) * C1 * NP * 16 : 8];      // l1.w as it lies in memory: [k-step][channel][plane][16]
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const bool gath = wave >= NWM;
-    for (int e = tid; e < C1; e += 512) b1s[e] = l1.b[e];
-    if constexpr (W1LDS)
-        for (int e = tid; e < (D1 / 16) * C1 * NP * 2; e += 512) *reinterpret_cast<bf16x8*>(w1s + (size_t)e * 8) = gload<bf16x8>(l1.w + (size_t)e * 8);
-    const int tpc = N / TM;
-    const XcdRounds R = xcd_rounds(total_tiles);
-
-    // ---------------- gather role: state of the tile being fetched ----------------
-    const int gt = tid & (NTG - 1);
-    constexpr int XIT = TM * (D1 / 4) / NTG;
-    // One wave instruction fetches ONE WHOLE Y ROW -- 64 lanes x 16 bytes = 1 KB = eight full cache lines, its address wave-uniform (index
-    // and weights of the point are read out of a lane with v_readlane: scalar address arithmetic, weights as SGPR operands) -- and the
-    // interpolated row is one conflict-free 1 KB LDS store.  (The round-3 mapping of fp_pre_kernel -- four lanes per point, each lane 16 bytes
-    // of every other 32: an instruction touches 16 rows and HALF of each of their lines, every line is requested by two instructions --
-    // measured 255 against 244 us here.)
-    constexpr int PPW = TM / (NTG / 64), GB = PPW / 2;               // points per gather wave; two batches of GB points x 3 rows per tile
-    static_assert(C1 == 4 * 64 && 3 * PPW <= 64, "a Y row is one wave-wide 16-byte load; a wave's indices fit its lanes");
-    const int gwv = wave - NWM;                                      // gather wave 0 .. 3: points PPW gwv .. of the tile
-    // state of the tile being fetched (gc, gn0, gi, gw, xrow) and of the one after it (*_nx: requested a whole tile ahead, so that no phase
-    // starts by waiting for an index)
-    int gc = 0, gn0 = 0, gi = 0, gc_nx = 0, gn0_nx = 0, gi_nx = 0;   // gi / gw: lane L < 3 PPW holds (point L / 3, neighbour L % 3) of the wave's points
-    float gw = 0.0f, gw_nx = 0.0f;
-    int xrow[XIT], xrow_nx[XIT];
-    f32x4 gx[XIT], ga[GB], gb[GB], gd[GB];
-    auto g_indices_request = [&](int t) {
-        gc_nx = t / tpc;
-        gn0_nx = (t - gc_nx * tpc) * TM;
-        if (p1_remap) {
-#pragma unroll
-            for (int it = 0; it < XIT; ++it) xrow_nx[it] = p1_remap[(size_t)gc_nx * N + gn0_nx + (gt + it * NTG) / (D1 / 4)];
-        }
-        const size_t ao = ((size_t)gc_nx * N + gn0_nx + PPW * gwv) * 3 + (lane < 3 * PPW ? lane : 3 * PPW - 1);      // one coalesced load each
-        gi_nx = nn_idx[ao];
-        gw_nx = nn_w[ao];
-    };
-    auto g_indices_take = [&]() {
-        gc = gc_nx; gn0 = gn0_nx; gi = gi_nx; gw = gw_nx;
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) xrow[it] = xrow_nx[it];
-    };
-    auto g_request = [&](int q0) {
-        const float* yb = y + (size_t)gc * S * C1 + 4 * lane;
-#pragma unroll
-        for (int q = 0; q < GB; ++q) {
-            const int ia = __builtin_amdgcn_readlane(gi, 3 * (q0 + q) + 0), ib = __builtin_amdgcn_readlane(gi, 3 * (q0 + q) + 1),
-                      ic = __builtin_amdgcn_readlane(gi, 3 * (q0 + q) + 2);
-            ga[q] = load4f(yb + (size_t)ia * C1); gb[q] = load4f(yb + (size_t)ib * C1); gd[q] = load4f(yb + (size_t)ic * C1);
-        }
-    };
-    auto g_request_p1 = [&]() {
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = gt + it * NTG;
-            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
-            if (p1_remap) gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? gc % p1_mod : gc) * N + xrow[it]) * D1 + 4 * c4);
-            else gx[it] = load4f(points1 + ((size_t)gc * N + gn0) * D1 + (size_t)e * 4);
-        }
-    };
-    auto g_interp = [&](int q0) {
-#if defined(LSDM_PK_NOPS)      // (hazard experiment: idle cycles between the wave's wake-up from its load wait and the first packed instruction)
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-        const int gwf = __builtin_bit_cast(int, gw);
-#pragma unroll
-        for (int q = 0; q < GB; ++q) {
-            const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 0)),
-                        wb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 1)),
-                        wc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gwf, 3 * (q0 + q) + 2));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ga[q][j] = interp3(ga[q][j], gb[q][j], gd[q][j], wa, wb, wc);
-            const int row = PPW * gwv + q0 + q;
-            *reinterpret_cast<f32x4*>(tile + row * LDT + ((4 * lane) ^ tile_swz(row))) = ga[q];
-        }
-    };
-    auto g_store_p1 = [&]() {
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = gt + it * NTG;
-            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
-            store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
-        }
-    };
-
-    // The two roles run their own loops (same trip count, three barriers per tile each): with the role test inside one loop the register
-    // allocator keeps both roles' state live together (453 spilled VGPRs).
-    // (Gather schedule measured and not kept, round 4c: the WHOLE next-but-one tile requested in phase 3 -- 48 pieces + the p1 row, 208
-    // registers of loads in flight -- and interpolated in phase 2: 285 against 252 us, also with the layer-2 weights resident, i.e. with no
-    // other loads in that phase: 52 back-to-back requests per thread are throttled at the texture addresser; two batches spread over the
-    // three phases keep more of them in flight.)
-    if (gath) {
-        // (s_setprio 3 for this role -- its requests ahead of the matrix wave of the SIMD -- measured 250 vs 247 us: nothing)
-        // prologue: the first tile of the work-group, the indices of the second and the first batch of its rows
-        if (R.first < R.end) {
-            g_indices_request(R.first);
-            g_indices_take();
-            g_request(0);
-            g_request_p1();
-            const bool second = R.first + R.stride < R.end;
-            if (second) g_indices_request(R.first + R.stride);
-            g_interp(0);
-            g_request(GB);
-            g_interp(GB);
-            g_store_p1();
-            g_indices_take();
-            if (second) g_request(0);
-        }
-        WS_T0();
-        [[maybe_unused]] int ntl = 0;
-#pragma unroll 1
-        for (int t = R.first; t < R.end; t += R.stride) {
-            const bool has_next = t + R.stride < R.end, has_next2 = t + 2 * R.stride < R.end;
-            wg_sync();                                   // B1   (batch 1 of tile t + stride is in flight since the end of phase 3)
-            WS_MARK(0);
-            if (has_next) {
-                g_request_p1();
-                if (has_next2) g_indices_request(t + 2 * R.stride);
-            }
-            WS_MARK(1);
-            wg_sync();                                   // B2
-            WS_MARK(2);
-            if (has_next) {
-                g_interp(0);
-                g_request(GB);
-            }
-            WS_MARK(3);
-            wg_sync();                                   // B3
-            WS_MARK(4);
-            if (has_next) {
-                g_interp(GB);
-                g_store_p1();
-                g_indices_take();
-                if (has_next2) g_request(0);             // (the registers are free: the first batch of the tile after next, a phase early)
-            }
-#ifdef LSDM_PHASE_TIMING
-            ++ntl;
-#endif
-            WS_MARK(5);
-        }
-        WS_FLUSH(8, ntl);
-        return;
-    }
-    // ---------------- matrix role: work split of fp_pre_kernel on four waves ----------------
-    using TS = SplitH<NWM, TM, C1>;
-    constexpr int NCB = TS::CB / TS::CSTEP, RB1 = TS::RB;
-    static_assert(TS::WPC == 1, "split");
-    using T2 = SplitH<NWM, TM, C2>;
-    static_assert(T2::CB == T2::CSTEP, "one layer-2 channel block per matrix wave");
-    const int mw = wave & (NWM - 1);
-    const int p = lane & 31, h = lane >> 5;
-    const int cb0 = mw % TS::CSTEP;
-    const int cb2 = mw % T2::CSTEP, rg2 = mw / T2::CSTEP;
-    const float bv2 = l2.b[cb2 * 32 + (lane & 31)];
-    // LSDM_FP2_W2REG: the wave's layer-2 fragments (its channel block x all of K: 128 registers) stay resident -- a third of what a tile
-    // pulls through the L1
-#ifndef LSDM_FP2_W2REG
-#define LSDM_FP2_W2REG 1
-#endif
-    constexpr bool W2REG = LSDM_FP2_W2REG != 0;
-    constexpr int KS2 = C1 / 16;
-    [[maybe_unused]] bf16x8 w2h[KS2], w2l[KS2];
-    if constexpr (W2REG) {
-        static_assert(T2::WPC == 1 && T2::RB == TM / 32, "one layer-2 channel block per matrix wave, all rows");
-        const size_t ws2 = (size_t)C2 * NP * 16;
-        const __bf16* wp2 = l2.w + ((size_t)(cb2 * 32 + p) * NP) * 16 + 8 * h;
-#pragma unroll
-        for (int u = 0; u < KS2; ++u) { w2h[u] = gload<bf16x8>(wp2 + (size_t)u * ws2); w2l[u] = gload<bf16x8>(wp2 + (size_t)u * ws2 + 16); }
-#pragma unroll
-        for (int u = 0; u < KS2; ++u) asm volatile("" : "+v"(w2h[u]), "+v"(w2l[u]));
-    }
-    // layer-1 weights of the wave's channel blocks stay in registers for the life of the work-group (D1 = 64: 16 fragments = 64 VGPRs):
-    // a third of the weight bytes a tile pulls through the L1 (the kernel is bound by that path: TA 68 % busy, profiles/r04_a_pmc_mem.json)
-#ifndef LSDM_FP2_W1REG
-#define LSDM_FP2_W1REG 0
-#endif
-    constexpr bool W1REG = LSDM_FP2_W1REG != 0 && D1 <= 64;
-    [[maybe_unused]] bf16x8 w1h[NCB][D1 / 16], w1l[NCB][D1 / 16];
-    if constexpr (W1REG) {
-        const size_t ws = (size_t)C1 * NP * 16;
-#pragma unroll
-        for (int q = 0; q < NCB; ++q) {
-            const __bf16* wp = l1.w + ((size_t)((cb0 + q * TS::CSTEP) * 32 + p) * NP) * 16 + 8 * h;
-#pragma unroll
-            for (int u = 0; u < D1 / 16; ++u) { w1h[q][u] = gload<bf16x8>(wp + (size_t)u * ws); w1l[q][u] = gload<bf16x8>(wp + (size_t)u * ws + 16); }
-        }
-    }
-    WS_T0();
-    [[maybe_unused]] int ntl = 0;
-#pragma unroll 1
-    for (int t = R.first; t < R.end; t += R.stride) {
-        f32x16 acc[NCB][RB1];
-        // (the weight streams are loop-invariant: laundered, or hipcc hoists their addresses and first fragments out of the tile loop
-        // and spills them)
-        const __bf16* const w1p = opaque_ptr(l1.w);
-        [[maybe_unused]] const __bf16* const w2p = opaque_ptr(l2.w);
-        int pv = p, hv = h, lv = lane;
-        asm volatile("" : "+v"(pv), "+v"(hv), "+v"(lv));       // (per-lane addresses formed per tile, not hoisted and kept across the loop)
-        wg_sync();                                   // B1
-        WS_MARK(0);
-        // accumulators start from the interpolated rows (transposed product: lane owns channels 8 qd + 4 h + j of point p)
-#pragma unroll
-        for (int q = 0; q < NCB; ++q)
-#pragma unroll
-            for (int rb = 0; rb < RB1; ++rb)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + pv) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * hv) ^ tile_swz(pv)));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
-                }
-        if constexpr (W1REG) {
-            // layer 1 against the wave's RESIDENT weight fragments (same instruction order as mma_kloop_pre_h: per k-step and point block
-            // hi x lo, lo x hi, hi x hi)
-            const __bf16* xp = bufX + pv * LDX + 8 * hv;
-#pragma unroll
-            for (int q = 0; q < NCB; ++q)
-#pragma unroll
-                for (int u = 0; u < D1 / 16; ++u) {
-                    bf16x8 xh[RB1], xl[RB1];
-#pragma unroll
-                    for (int rb = 0; rb < RB1; ++rb) {
-                        xh[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16);
-                        xl[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16 + PX);
-                    }
-#pragma unroll
-                    for (int rb = 0; rb < RB1; ++rb) {
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xl[rb], acc[q][rb], 0, 0, 0);
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[q][u], xh[rb], acc[q][rb], 0, 0, 0);
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xh[rb], acc[q][rb], 0, 0, 0);
-                    }
-                }
-        } else if constexpr (W1LDS) {
-            // layer 1 against the weight fragments resident in LDS (same instruction order)
-            const __bf16* xp = bufX + pv * LDX + 8 * hv;
-#pragma unroll
-            for (int q = 0; q < NCB; ++q) {
-                const __bf16* wq = w1s + ((size_t)((cb0 + q * TS::CSTEP) * 32 + pv) * NP) * 16 + 8 * hv;
-#pragma unroll
-                for (int u = 0; u < D1 / 16; ++u) {
-                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wq + (size_t)u * C1 * NP * 16);
-                    const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wq + (size_t)u * C1 * NP * 16 + 16);
-                    bf16x8 xh[RB1], xl[RB1];
-#pragma unroll
-                    for (int rb = 0; rb < RB1; ++rb) {
-                        xh[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16);
-                        xl[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16 + PX);
-                    }
-#pragma unroll
-                    for (int rb = 0; rb < RB1; ++rb) {
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[rb], acc[q][rb], 0, 0, 0);
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, xh[rb], acc[q][rb], 0, 0, 0);
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[rb], acc[q][rb], 0, 0, 0);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < NCB; ++q) mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, w1p, C1, cb0 + q * TS::CSTEP, 0, lv);
-        }
-        WS_MARK(1);
-        wg_sync();                                   // B2
-        WS_MARK(2);
-#pragma unroll
-        for (int q = 0; q < NCB; ++q) {
-            f32x4 bv1[4];        // (from LDS at its use: 32 registers less across the tile loop)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * hv);
-            store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1, bufB, LDB, PB, lv);
-        }
-        WS_MARK(3);
-        wg_sync();                                   // B3
-        WS_MARK(4);
-        {
-            const int c = t / tpc, n0 = (t - c * tpc) * TM;
-            // (direct orientation: 32 consecutive channels of a row per half-wave -- coalesced 128-byte row segments.  The transposed form with
-            // one 16-byte store per lane and quad was measured SLOWER here and in lin_u / fp3's extra layer: sa3 315 -> 329, fp2 310 -> 323 us)
-            f32x16 a2[T2::RB];
-            acc_zero_h(a2);
-            const int col = cb2 * 32 + (lv & 31);
-            if constexpr (W2REG) {
-                const __bf16* bp = bufB + pv * LDB + 8 * hv;
-#pragma unroll
-                for (int u = 0; u < KS2; ++u) {
-                    bf16x8 xh[T2::RB], xl[T2::RB];
-#pragma unroll
-                    for (int rb = 0; rb < T2::RB; ++rb) {
-                        xh[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16);
-                        xl[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16 + PB);
-                    }
-#pragma unroll
-                    for (int rb = 0; rb < T2::RB; ++rb) {
-                        a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], w2h[u], a2[rb], 0, 0, 0);
-                        a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2l[u], a2[rb], 0, 0, 0);
-                        a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2h[u], a2[rb], 0, 0, 0);
-                    }
-                }
-            } else
-                mma_kloop_h<T2::RB, NP, false, C1 / 16>(a2, bufB + rg2 * T2::RB * 32 * LDB, LDB, PB, w2p, C2, cb2, 0, lv);
-#pragma unroll
-            for (int rb = 0; rb < T2::RB; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (rg2 * T2::RB + rb) * 32 + acc_row(r, lv);
-                    out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv2);
-                }
-        }
-#ifdef LSDM_PHASE_TIMING
-        ++ntl;
-#endif
-        WS_MARK(5);
-    }
-    WS_FLUSH(0, ntl);
-}
-
-// ---------------------------------------------------------------------------------------------
-// fp2 with the weights RESIDENT IN REGISTERS (round 4c).  fp_ws_kernel showed what the stage is bound by: the L2 -> L1 fill path of the
-// CU (TA 68 % busy), and half of what a tile pulls through it are the 192 KB of weight fragments every tile re-reads.  Here a
-// work-group is four waves, ONE per SIMD, each with the whole 512-entry register file (as sa_w_kernel): wave w keeps the fragments of
-// ITS channel blocks for the life of the persistent work-group -- layer 1 blocks {w, w + 4} (64 registers), layer 2 block w (128) --
-// so a tile moves only its own data through the L1: the three Y rows and the p1 row of its points (208 KB) and its output.  The
-// four waves are also the gatherers (256 threads, the mapping of fp_pre_kernel's phase A); the rows of tile n + 1 are requested in two
-// batches of 24 pieces inside tile n's barrier intervals and interpolated behind its matrix instructions.  Same arithmetic in the
-// same order as fp_pre_kernel / fp_ws_kernel: bit-identical results.
-//   A   T(n), bufX(n) complete              requests batch 1 + p1 of tile n + 1;  accumulators <- T
-//   B   T free                              layer 1 (resident W1 x bufX);  batch 1 -> T, requests batch 2;  ReLU + split -> bufB
-//   C   bufB complete, bufX free            p1 -> bufX;  layer 2 (resident W2 x bufB);  batch 2 -> T;  stores;  indices of tile n + 2
-template <int D1, int C1, int C2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void fp_rw_kernel(
-    const float* __restrict__ points1, const int* __restrict__ p1_remap, const float* __restrict__ y, const int* __restrict__ nn_idx,
-    const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2, float* __restrict__ out, int p1_mod, int total_tiles) {
-    constexpr int TM = 64, NW = 4, NP = 2, NT = 256, TPP = NT / TM;
-    static_assert(TPP == 4 && C1 % 64 == 0 && D1 % 16 == 0, "tile");
-    constexpr int LDT = C1;
-    auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
-    constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB;
-    __shared__ __attribute__((aligned(16))) float tile[TM * LDT];
-    __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
-    __shared__ __attribute__((aligned(16))) __bf16 bufB[NP * PB];
-    __shared__ __attribute__((aligned(16))) float b1s[C1];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    for (int e = tid; e < C1; e += NT) b1s[e] = l1.b[e];
-    const int tpc = N / TM;
-    const XcdRounds R = xcd_rounds(total_tiles);
-    int p = lane & 31, h = lane >> 5;
-
-    // ---- resident weights ----
-    using TS = SplitH<NW, TM, C1>;
-    constexpr int NCB = TS::CB / TS::CSTEP, RB1 = TS::RB, KS1 = D1 / 16, KS2 = C1 / 16;
-    static_assert(TS::WPC == 1 && TS::CSTEP == NW, "layer-1 split");
-    using T2 = SplitH<NW, TM, C2>;
-    static_assert(T2::CB == NW && T2::RB == TM / 32, "one layer-2 channel block per wave");
-    constexpr int RB2 = T2::RB;
-    bf16x8 w1h[NCB][KS1], w1l[NCB][KS1], w2h[KS2], w2l[KS2];
-    {
-        const size_t ws1 = (size_t)C1 * NP * 16, ws2 = (size_t)C2 * NP * 16;
-#pragma unroll
-        for (int q = 0; q < NCB; ++q) {
-            const __bf16* wp = l1.w + ((size_t)((wave + q * NW) * 32 + p) * NP) * 16 + 8 * h;
-#pragma unroll
-            for (int u = 0; u < KS1; ++u) { w1h[q][u] = gload<bf16x8>(wp + (size_t)u * ws1); w1l[q][u] = gload<bf16x8>(wp + (size_t)u * ws1 + 16); }
-        }
-        const __bf16* wp2 = l2.w + ((size_t)(wave * 32 + p) * NP) * 16 + 8 * h;
-#pragma unroll
-        for (int u = 0; u < KS2; ++u) { w2h[u] = gload<bf16x8>(wp2 + (size_t)u * ws2); w2l[u] = gload<bf16x8>(wp2 + (size_t)u * ws2 + 16); }
-        // (opaque from here on: values in registers, not loads the compiler may sink back into the tile loop)
-#pragma unroll
-        for (int q = 0; q < NCB; ++q)
-#pragma unroll
-            for (int u = 0; u < KS1; ++u) asm volatile("" : "+a"(w1h[q][u]), "+a"(w1l[q][u]));
-#pragma unroll
-        for (int u = 0; u < KS2; ++u) asm volatile("" : "+a"(w2h[u]), "+a"(w2l[u]));
-    }
-    const float bv2 = l2.b[wave * 32 + (lane & 31)];
-
-    // ---- gather state (fp_pre_kernel's phase A mapping on 256 threads) ----
-    int arow = tid / TPP, sub = tid % TPP, tidv = tid, lanev = lane;
-    constexpr int XIT = TM * (D1 / 4) / NT;
-    constexpr int PIECES = C1 / (4 * TPP), GB = PIECES / 2;
-    int gi0 = 0, gi1 = 0, gi2 = 0, gc = 0, gn0 = 0;
-    float gw0 = 0.0f, gw1 = 0.0f, gw2 = 0.0f;
-    int xrow[XIT];
-    f32x4 gx[XIT], ga[GB], gb[GB], gd[GB];
-#define FPR_CH(sub, k) (4 * (2 * (sub) + ((k) & 1) + 2 * TPP * ((k) >> 1)))
-    auto g_indices = [&](int t) {
-        gc = t / tpc;
-        gn0 = (t - gc * tpc) * TM;
-        const size_t ao = ((size_t)gc * N + gn0 + arow) * 3;
-        if (p1_remap) {
-#pragma unroll
-            for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)gc * N + gn0 + (tidv + it * NT) / (D1 / 4)];
-        }
-        gi0 = nn_idx[ao + 0]; gi1 = nn_idx[ao + 1]; gi2 = nn_idx[ao + 2];
-        gw0 = nn_w[ao + 0]; gw1 = nn_w[ao + 1]; gw2 = nn_w[ao + 2];
-    };
-    auto g_request = [&](int k0) {
-        const float* yb = y + (size_t)gc * S * C1;
-        const float* r0 = yb + (size_t)gi0 * C1;
-        const float* r1 = yb + (size_t)gi1 * C1;
-        const float* r2 = yb + (size_t)gi2 * C1;
-#pragma unroll
-        for (int k = 0; k < GB; ++k) {
-            const int ch = FPR_CH(sub, k0 + k);
-            ga[k] = load4f(r0 + ch); gb[k] = load4f(r1 + ch); gd[k] = load4f(r2 + ch);
-        }
-    };
-    auto g_request_p1 = [&]() {
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = tidv + it * NT;
-            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
-            if (p1_remap) gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? gc % p1_mod : gc) * N + xrow[it]) * D1 + 4 * c4);
-            else gx[it] = load4f(points1 + ((size_t)gc * N + gn0) * D1 + (size_t)e * 4);
-        }
-    };
-    auto g_interp = [&](int k0) {
-#pragma unroll
-        for (int k = 0; k < GB; ++k) {
-            const int ch = FPR_CH(sub, k0 + k);
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = interp3(ga[k][j], gb[k][j], gd[k][j], gw0, gw1, gw2);
-            *reinterpret_cast<f32x4*>(tile + arow * LDT + (ch ^ tile_swz(arow))) = v;
-        }
-    };
-    auto g_store_p1 = [&]() {
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int e = tidv + it * NT;
-            const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
-            store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
-        }
-    };
-
-    if (R.first < R.end) {
-        g_indices(R.first);
-        g_request(0);
-        g_request_p1();
-        g_interp(0);
-        g_request(GB);
-        g_interp(GB);
-        g_store_p1();
-        if (R.first + R.stride < R.end) g_indices(R.first + R.stride);
-    }
-#pragma unroll 1
-    for (int t = R.first; t < R.end; t += R.stride) {
-        const bool has_next = t + R.stride < R.end;
-        f32x16 acc[NCB][RB1];
-        // (per-lane indices laundered once per tile: every LDS / global element address below is loop-invariant per lane, and hipcc hoists
-        // ~100 of them out of the persistent loop into registers it then spills)
-        asm volatile("" : "+v"(p), "+v"(h), "+v"(arow), "+v"(sub), "+v"(tidv), "+v"(lanev));
-        wg_sync();                                   // A
-        if (has_next) {
-            g_request(0);
-            g_request_p1();
-        }
-#pragma unroll
-        for (int q = 0; q < NCB; ++q)
-#pragma unroll
-            for (int rb = 0; rb < RB1; ++rb)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((wave + q * NW) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = tv[j];
-                }
-        wg_sync();                                   // B
-        {
-            // layer 1: per channel block and k-step, per point block: hi x lo, lo x hi, hi x hi (the order of mma_kloop_pre_h)
-            const __bf16* xp = bufX + p * LDX + 8 * h;
-#pragma unroll
-            for (int q = 0; q < NCB; ++q)
-#pragma unroll
-                for (int u = 0; u < KS1; ++u) {
-                    bf16x8 xh[RB1], xl[RB1];
-#pragma unroll
-                    for (int rb = 0; rb < RB1; ++rb) {
-                        xh[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16);
-                        xl[rb] = *reinterpret_cast<const bf16x8*>(xp + rb * 32 * LDX + u * 16 + PX);
-                    }
-#pragma unroll
-                    for (int rb = 0; rb < RB1; ++rb) {
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xl[rb], acc[q][rb], 0, 0, 0);
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[q][u], xh[rb], acc[q][rb], 0, 0, 0);
-                        acc[q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xh[rb], acc[q][rb], 0, 0, 0);
-                    }
-                }
-        }
-        if (has_next) {
-            g_interp(0);
-            g_request(GB);
-        }
-#pragma unroll
-        for (int q = 0; q < NCB; ++q) {
-            f32x4 bv1[4];
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) bv1[qd] = *reinterpret_cast<const f32x4*>(b1s + (wave + q * NW) * 32 + 8 * qd + 4 * h);
-            store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, wave + q * NW, bv1, bufB, LDB, PB, lanev);
-        }
-        wg_sync();                                   // C
-        if (has_next) g_store_p1();
-        {
-            const int c = t / tpc, n0 = (t - c * tpc) * TM;
-            f32x16 a2[RB2];
-            acc_zero_h(a2);
-            // layer 2, direct orientation D[point][channel] (coalesced 128-byte row segments on the way out)
-            const __bf16* bp = bufB + p * LDB + 8 * h;
-#pragma unroll
-            for (int u = 0; u < KS2; ++u) {
-                bf16x8 xh[RB2], xl[RB2];
-#pragma unroll
-                for (int rb = 0; rb < RB2; ++rb) {
-                    xh[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16);
-                    xl[rb] = *reinterpret_cast<const bf16x8*>(bp + rb * 32 * LDB + u * 16 + PB);
-                }
-#pragma unroll
-                for (int rb = 0; rb < RB2; ++rb) {
-                    a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[rb], w2h[u], a2[rb], 0, 0, 0);
-                    a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2l[u], a2[rb], 0, 0, 0);
-                    a2[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[rb], w2h[u], a2[rb], 0, 0, 0);
-                }
-            }
-            if (has_next) g_interp(GB);
-            const int col = wave * 32 + (lanev & 31);
-#pragma unroll
-            for (int rb = 0; rb < RB2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb * 32 + acc_row(r, lanev);
-                    out[((size_t)c * N + n0 + row) * C2 + col] = reluf(a2[rb][r] + bv2);
-                }
-        }
-        if (t + 2 * R.stride < R.end) g_indices(t + 2 * R.stride);
-    }
-#undef FPR_CH
-}
-
-#ifdef LSDM_PHASE_TIMING
-extern "C" __attribute__((visibility("default"))) int lsdm_debug_ws_phase(unsigned long long* out16, int reset) {
-    static unsigned long long h[64 * 16], z[64 * 16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ws_phase), sizeof h) != hipSuccess) return -1;
-    for (int s = 0; s < 16; ++s) { out16[s] = 0; for (int c = 0; c < 64; ++c) out16[s] += h[c * 16 + s]; }
-    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ws_phase), z, sizeof z) != hipSuccess) return -1;
-    return 0;
-}
-#endif
 
 // which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
 // Y = coarse-level FP output x Wb^T, R = num_clouds * S rows of 256 channels
@@ -1612,14 +1061,10 @@ void launch_fp_y512(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipS
 }
 
 // LSDM_FP2_WS: fp2 on 4 = the two-stage persistent kernel over Morton-ordered tiles with deduplicated rows (fp_d_kernel, encoder_d.hip; the default),
-// 2 = the persistent kernel with register-resident weights (fp_rw_kernel), 1 / 3 = the persistent wave-specialised kernel (fp_ws_kernel, 64- / 32-row
-// tiles), 0 = the tile-per-work-group form (fp_pre_kernel).  Same results bit for bit.
-#ifndef LSDM_FP2_DEFAULT
-#define LSDM_FP2_DEFAULT 4
-#endif
+// 0 = the tile-per-work-group form (fp_pre_kernel: the reference form of the stage for the bit-equality tests).  Same results bit for bit.
 int fp2_ws() {
     const char* e = getenv("LSDM_FP2_WS");      // (read per launch: the A/B tests flip it inside one process)
-    return e ? atoi(e) : LSDM_FP2_DEFAULT;
+    return e ? (atoi(e) ? 4 : 0) : 4;
 }
 
 // y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):
@@ -1649,29 +1094,9 @@ void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap,
     if (which == 2 && plan) {
         launch_fp_d(nc, points1, ybuf, nn_w, l1a, l2, out, plan, st, p1_mod);
     }
-    else if (which == 2 && fp2_ws() == 2) {
-        const int total = 1024 / 64 * nc;
-        hipLaunchKernelGGL((fp_rw_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
-                           out, p1_mod, total);
-    }
-    else if (which == 2 && fp2_ws() == 3) {
-        const int total = 1024 / 32 * nc;
-        hipLaunchKernelGGL((fp_ws_kernel<64, 256, 128, 32>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
-                           out, p1_mod, total);
-    }
-    else if (which == 2 && fp2_ws()) {
-        const int total = 1024 / 64 * nc;
-        hipLaunchKernelGGL((fp_ws_kernel<64, 256, 128>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2,
-                           out, p1_mod, total);
-    }
     else if (which == 2) {
-#ifdef LSDM_TIMING_EXPERIMENTS   // `make TIMING=1` only: results are wrong with these (1 gather from one row, 2 no stores, 4 / 8 no layer-2 / layer-1 MFMAs)
-        static const int dbg = getenv("LSDM_DBG_FP2") ? atoi(getenv("LSDM_DBG_FP2")) : 0;
-#else
-        constexpr int dbg = 0;
-#endif
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, LSDM_FP2_NW>), dim3(1024 / 64 * nc), dim3(LSDM_FP2_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
-                           none, nullptr, 1 | (dbg << 1), p1_mod);
+                           none, nullptr, 1, p1_mod);
     }
     else if (ynext) {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
@@ -1702,12 +1127,7 @@ void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx
 void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod) {
     if (level == 3) {
-#ifdef LSDM_TIMING_EXPERIMENTS   // `make TIMING=1` only: results are wrong with these (1 no panel copy, 2 no barrier)
-        static const int dbg = getenv("LSDM_DBG_SAW") ? atoi(getenv("LSDM_DBG_SAW")) : 0;
-#else
-        constexpr int dbg = 0;
-#endif
-        hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, dbg, nullptr, nullptr);
+        hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, nullptr, nullptr);
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;
         // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
@@ -1729,7 +1149,7 @@ void launch_sa_u_items(int level, const float* U, const float* V, const int* row
         hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2, true>), dim3(512), dim3(512), 0, st, U, V, nullptr, rows, nullptr, 1024, 1024, 0LL, blob_w, blob_b, out, 0,
                            nullptr, count, meta);
     else if (level == 3)
-        hipLaunchKernelGGL((sa_w_kernel<2, true>), dim3(256), dim3(256), 0, st, U, V, nullptr, rows, 0LL, blob_w, blob_b, out, 0, meta, count);
+        hipLaunchKernelGGL((sa_w_kernel<2, true>), dim3(256), dim3(256), 0, st, U, V, nullptr, rows, 0LL, blob_w, blob_b, out, meta, count);
     else
         hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2, true>), dim3(256), dim3(12 * 64), 0, st, U, V, nullptr, rows, 256, 64, 0LL, blob_w, blob_b, out, meta,
                            count);

@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         request_nn(b);
         request_p1(b);
         request_rows(b, i_n, 0);
+#ifndef LSDM_FPW_SIMPLE
         split_p1();
         interp_rows(w_n);
+#endif
     }
     FPW_T0();
     [[maybe_unused]] int nrounds = 0;
@@ -161,6 +163,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int ii[3] = {i_n[0], i_n[1], i_n[2]};
         const float ww[3] = {w_n[0], w_n[1], w_n[2]};
         bf16x8 ah[KS], al[KS], zh[KS], zl[KS];
+#ifdef LSDM_FPW_SIMPLE       // (A/B: everything of a round formed at its use -- p1 split at the round's top, a panel's rows interpolated at its top)
+        split_p1();
+#endif
         const bool more = rd + 1 < rend;
         const long long nblk = more ? block_of(rd + 1) : blk;
         if (more) request_nn(nblk);
@@ -192,10 +197,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         sfor<NPL>([&](auto q_) {
             constexpr int q = decltype(q_)::value;
             FPW_BEGIN(q)
+#ifdef LSDM_FPW_SIMPLE
+            interp_rows(ww);
+#endif
             f32x16 a0 = n0, a1 = n1;
             if constexpr (q + 1 < NPL) request_rows(blk, ii, q + 1);
             FPW_MARK(1);
+#ifdef LSDM_FPW_SIMPLE
+            FPW_KLOOP(q, KS1, -1, ,
+#else
             FPW_KLOOP(q, KS1, KS1 - 2, if constexpr (q + 1 < NPL) interp_rows(ww);,
+#endif
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0h, xl[s], a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h, xl[s], a1, 0, 0, 0);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0l, xh[s], a0, 0, 0, 0);
@@ -269,10 +281,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f32x16 a0, a1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+#ifdef LSDM_FPW_SIMPLE
+            if constexpr (q == NPL - 1) {
+                if (more) request_rows(nblk, i_n, 0);
+            }
+            FPW_KLOOP(2 * NPL + q, KS, -1, ,
+#else
             if constexpr (q == NPL - 2) {
                 if (more) { split_p1(); request_rows(nblk, i_n, 0); }
             }
             FPW_KLOOP(2 * NPL + q, KS, KS - 4, if constexpr (q == NPL - 1) { if (more) interp_rows(w_n); },
+#endif
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], w0h, a0, 0, 0, 0);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], w1h, a1, 0, 0, 0);
                 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], w0l, a0, 0, 0, 0);

@@ -109,11 +109,9 @@ void launch_fp_y512(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipS
 // out = the stage's output rows or NULL, ynext = the next finer stage's pre-multiplied operand
 void launch_fp_w(int which, int num_clouds, const float* points1, const float* y, const int* nn_idx, const float* nn_w, const __bf16* blob_w,
                  const float* blob_b, float* out, float* ynext, int num_cus, hipStream_t st);
-// fp1 + head as one register-chained stack (bf16x3): points2 (nc,1024,128) fp32, out (nc,1024,3)
+// fp1 + head as one register-chained stack (bf16x3), a pipeline of stages with register-resident weights (encoder_d.hip: fp_c_kernel):
+// points2 (nc,1024,128) fp32, out (nc,1024,3)
 // order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
-void launch_fp_s(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b,
-                 float* out, hipStream_t st, const int* order = nullptr, int order_mod = 0);
-// encoder_d.hip: the same stack as a pipeline of stages with register-resident weights (fp_c_kernel; same blob, same results)
 void launch_fp_c(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
                  hipStream_t st, const int* order = nullptr, int order_mod = 0);
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source

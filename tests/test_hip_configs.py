@@ -616,10 +616,9 @@ def test_chain_on_a_caller_stream_with_work_queued_behind_it():
 _SWITCHES = [{"LSDM_SA_SPLIT": "0"}, {"LSDM_SA_SPLIT": "1"}, {"LSDM_SA_SPLIT": "2"}, {"LSDM_SA_REG": "0"}, {"LSDM_SA_REG": "2", "LSDM_SA_SPLIT": "0"},
              {"LSDM_FP_PRE": "0"}, {"LSDM_FP_PRE": "1"}, {"LSDM_FP4_PRE": "0"}, {"LSDM_FUSE_Y": "0"}, {"LSDM_FP1_REG": "0"}, {"LSDM_DEN_REG": "0"},
              {"LSDM_GROUP": "3"}, {"LSDM_BATCH_ENC": "0"}, {"LSDM_BATCH_DEN": "0"}, {"LSDM_STREAMS": "1"}, {"LSDM_INV_SIDE": "0"}, {"LSDM_SA2_MEMO": "0"},
-             {"LSDM_FP2_WS": "0"}, {"LSDM_FP2_WS": "1"}, {"LSDM_FP2_WS": "2"}, {"LSDM_FP2_WS": "3"}, {"LSDM_FP1_PIPE": "0"}, {"LSDM_FP1_ORDER": "0"},
-             {"LSDM_FP1_PIPE": "0", "LSDM_FP1_ORDER": "0"}, {"LSDM_SA_PAIR": "0"}, {"LSDM_SA_PAIR": "2"}]
-_SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN", "LSDM_STREAMS", "LSDM_INV_SIDE", "LSDM_SA2_MEMO", "LSDM_FP2_WS", "LSDM_FP1_PIPE",
-                    "LSDM_FP1_ORDER", "LSDM_SA_PAIR")      # launch shapes / kernel forms with the same arithmetic in the same order: bit-identical results
+             {"LSDM_FP2_WS": "0"}, {"LSDM_FP1_ORDER": "0"}, {"LSDM_SA_PAIR": "0"}, {"LSDM_SA_PAIR": "2"}, {"LSDM_FP_W": "0"}, {"LSDM_DEG_FAST": "0"}]
+_SAME_ARITHMETIC = ("LSDM_GROUP", "LSDM_BATCH_ENC", "LSDM_BATCH_DEN", "LSDM_STREAMS", "LSDM_INV_SIDE", "LSDM_SA2_MEMO", "LSDM_FP2_WS", "LSDM_FP1_ORDER",
+                    "LSDM_SA_PAIR", "LSDM_DEG_FAST")      # launch shapes / kernel forms with the same arithmetic in the same order: bit-identical results
 
 
 @pytest.mark.parametrize("env", _SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
@@ -872,9 +871,9 @@ def test_fp2_fp1_kernel_forms_agree_on_degenerate_and_scattered_clouds():
     starts = torch.stack([torch.randint(0, n, (nc,)) for n in (1024, 1024, 256, 64)]).to(DEV)
     sd = make_synthetic_state_dict(seed=0)
     outs = {}
-    keep = {k: os.environ.get(k) for k in ("LSDM_FP2_WS", "LSDM_FP1_PIPE", "LSDM_SA_PAIR")}
+    keep = {k: os.environ.get(k) for k in ("LSDM_FP2_WS", "LSDM_SA_PAIR")}
     try:
-        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_FP1_PIPE": "1", "LSDM_SA_PAIR": "2"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_FP1_PIPE": "0", "LSDM_SA_PAIR": "0"})):
+        for name, env in (("new", {"LSDM_FP2_WS": "4", "LSDM_SA_PAIR": "2"}), ("old", {"LSDM_FP2_WS": "0", "LSDM_SA_PAIR": "0"})):
             os.environ.update(env)
             m, _ = create_model_and_diffusion("proxd", precision="bf16x3")
             m.load_state_dict(sd)

@@ -261,7 +261,7 @@ def test_generated_code_has_no_barrier_without_the_lds_wait_and_no_packed_fp32_n
     """hipcc (ROCm 7.2, gfx950) emitted a loop-header s_barrier WITHOUT `s_waitcnt lgkmcnt(0)` after the loop latch's LDS stores in round 4
     (fp_ws_kernel: another wave read the tile before the stores had landed; common.hpp::wg_sync now waits explicitly).
     tools/barrier_wait_check.py walks the control-flow graph of every compiled kernel backwards from each barrier; the negative control
-    compiles the same source with the explicit wait removed and must be flagged."""
+    is that loop shape as a listing and must be flagged."""
     import shutil
     import subprocess
     hipcc = "/opt/rocm/bin/hipcc"
@@ -271,13 +271,18 @@ def test_generated_code_has_no_barrier_without_the_lds_wait_and_no_packed_fp32_n
     csrc = os.path.join(root, "lsdm_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "-j8", "check-barriers", "ASMDIR=%s" % (tmp_path / "asm")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "0 unguarded barrier(s)" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # negative control: the shape hipcc produced for round 4's fp_ws_kernel (removed in round 6) -- a loop-header barrier whose only predecessor
+    # LDS store sits in the loop latch, no wait between them on the back edge -- as a hand-written listing; the guarded form beside it passes
     bare = tmp_path / "bare"
     bare.mkdir()
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-inline-asm", "-DLSDM_WGSYNC_BARE",
-                    "--save-temps=obj", "-c", os.path.join(csrc, "encoder_u.hip"), "-o", str(bare / "encoder_u.o")], capture_output=True, timeout=900, check=True)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "barrier_wait_check.py")] + [str(p) for p in bare.glob("*-gfx950.s")],
-                       capture_output=True, text=True)
-    assert r.returncode == 1 and "fp_ws_kernel" in r.stdout, r.stdout[-2000:]
+    body = ("\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n.LBB0_1:\n\ts_barrier\n\tds_read_b128 v[0:3], v4\n\ts_waitcnt lgkmcnt(0)\n\tv_add_f32 v0, v0, v1\n"
+            "\tds_write_b64 v5, v[0:1]\n%s\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n")
+    for name, guard in (("unguarded", ""), ("guarded", "\ts_waitcnt lgkmcnt(0)\n")):
+        (bare / (name + "-gfx950.s")).write_text("_Z6kernelPf:\n" + body % guard + ".Lfunc_end0:\n")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "barrier_wait_check.py"), str(bare / "guarded-gfx950.s")], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 unguarded barrier(s)" in r.stdout, r.stdout[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "barrier_wait_check.py"), str(bare / "unguarded-gfx950.s")], capture_output=True, text=True)
+    assert r.returncode == 1 and "_Z6kernelPf" in r.stdout and "1 unguarded barrier(s)" in r.stdout, r.stdout[-2000:]
     # The same generated code holds NO packed fp32 arithmetic in any translation unit that issues matrix instructions, and NO operand-selected
     # packed fp32 instruction in ANY unit (round 4's lost updates came from v_pk_fma_f32 with operand selection in a wave sharing its SIMD with
     # an MFMA wave; the Makefile removes the compiler's own packing, geometry.hip keeps explicit plain-pair forms).  Negative controls: a

@@ -8,7 +8,7 @@ O=/tmp/lsdm_var_$NAME; mkdir -p $O $R/lsdm_amd/variants
 cd $R/lsdm_amd/csrc
 pids=()
 for f in *.hip; do
-  extra="-Xclang -target-feature -Xclang -packed-fp32-ops"; [ "$f" = geometry.hip ] && extra="-ffp-contract=off"; [ "$f" = api.hip -o "$f" = metrics.hip ] && extra=""
+  extra="-Xclang -target-feature -Xclang -packed-fp32-ops"; [ "$f" = geometry.hip ] && extra="-ffp-contract=off -fno-slp-vectorize"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function -Wno-inline-asm $extra $FLAGS -c $f -o $O/${f%.hip}.o &
   pids+=($!)
 done

@@ -1,4 +1,4 @@
-"""fp2's implementations (LSDM_FP2_WS = 0 fp_pre_kernel, 1 fp_ws_kernel, 2 fp_rw_kernel, 4 fp_d_kernel) on the same inputs: the stage's output
+"""fp2's implementations (LSDM_FP2_WS = 0 fp_pre_kernel, 4 fp_d_kernel) on the same inputs: the stage's output
 (workspace tensor fpo2) and the encoder output, pairwise max-abs and bit equality, plus run-to-run equality of each."""
 import os
 import sys
@@ -23,7 +23,7 @@ clouds = bt["given_objs"].reshape(B * 9, 1024, 3).contiguous()
 torch.manual_seed(0)
 starts = torch.stack([torch.randint(0, n, (B * 9,)) for n in (1024, 1024, 256, 64)]).to(dev)
 res = {}
-for v in ("0", "1", "4", "2", "1", "0", "4"):
+for v in ("0", "4", "0", "4"):
     os.environ["LSDM_FP2_WS"] = v
     out = torch.empty(B * 9, 1024, 3, device=dev)
     ctx.call("lsdm_scene_encoder", clouds.data_ptr(), starts.data_ptr(), B * 9, out.data_ptr(), None)
@@ -34,7 +34,7 @@ for v in ("0", "1", "4", "2", "1", "0", "4"):
     assert hip.hipMemcpy(ctypes.c_void_p(fpo2.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(fpo2.numel() * 4), 3) == 0
     key = v + ("b" if v in res else "")
     res[key] = (fpo2.clone(), out.clone())
-for a, b in (("0", "1"), ("0", "2"), ("0", "4"), ("1", "4"), ("0", "0b"), ("1", "1b"), ("4", "4b")):
+for a, b in (("0", "4"), ("0", "0b"), ("4", "4b")):
     d = (res[a][0] - res[b][0]).abs()
     print("fpo2 %s vs %s: max-abs %.3e, differing elements %d of %d; encoder out max-abs %.3e" % (
         a, b, float(d.max()), int((d > 0).sum()), d.numel(), float((res[a][1] - res[b][1]).abs().max())))
