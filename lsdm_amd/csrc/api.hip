@@ -64,9 +64,6 @@ struct lsdm_ctx {
     // index 0: fp3, 1: fp2
     DenseH fp_a[3], fp_y[3];     // first FP layer split at the concat boundary: [0] fp3, [1] fp2, [2] fp4
     float* fp_ybuf[3] = {};
-    // fp3 [0] / fp4 [1] as register-chained blobs of encoder_w.hip::fp_w_kernel: [Wa (256 x D1) | second layer | the next finer stage's Wb], biases [b1 | b2 | 0]
-    DenseH fp_w[2];
-    int fp_wk = getenv("LSDM_FP_W") ? atoi(getenv("LSDM_FP_W")) : 1;   // A/B switch: 0 = fp3 / fp4 on the tile-per-work-group form (fp_pre_kernel)
     int* fp2_plan = nullptr;     // fp2's tile plan (encoder_d.hip::fp_plan_kernel) of a single step, rewritten by every such step
     int* fp2_order = nullptr;    // Morton order of the step's level-1 points (single steps / the strict schedule)
     // item lists of the SA stages of a single step (geometry.hip: sa_pair_kernel; the groups of the loop-invariant schedule have their own in gws)
@@ -82,8 +79,6 @@ struct lsdm_ctx {
     const float* sa_wx[3] = {};
     float *sa_U[3] = {}, *sa_V[3] = {};
     int sa_split = getenv("LSDM_SA_SPLIT") ? atoi(getenv("LSDM_SA_SPLIT")) : 3;   // A/B switch: 1 sa3, 2 + sa4, 3 + sa2
-    void* feat_b[4] = {};               // bf16 level features / FP outputs (prec == BF16 only)
-    void* fpo_b[3] = {};
     CondParams cond{};
     PosaParams posa{};
     SceneAttnParams sattn{};
@@ -423,13 +418,19 @@ bool fold_dense(lsdm_ctx* c, const std::string& wname, const std::string& bname,
 //                 8*(s%2) .. 8*(s%2)+7 of block s/2 of the previous layer's transposed product
 // followed (separately) by the fp32 biases of the layers back to back, BatchNorm folded.
 struct ChainLayer { std::string w, b, bn; int N, K; int padN = 0; };   // padN: rows zero-padded to that many channels
-struct ChainMat { std::vector<float> W, Bv; int N, K; };               // a layer as a folded (N, K) matrix + bias (the split first FP layers)
-bool build_chain_blob_mats(lsdm_ctx* c, const std::vector<ChainMat>& mats, const std::vector<int>& first_map, int np, DenseH* out) {
+bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const std::vector<int>& first_map, int np, DenseH* out) {
     std::vector<uint16_t> blob;
     std::vector<float> biases;
-    for (size_t li = 0; li < mats.size(); ++li) {
-        const int N = mats[li].N, K = mats[li].K;
-        const std::vector<float>&W = mats[li].W, &Bv = mats[li].Bv;
+    for (size_t li = 0; li < layers.size(); ++li) {
+        int N = layers[li].N;
+        const int K = layers[li].K;
+        std::vector<float> W, Bv;
+        if (!fold_dense(c, layers[li].w, layers[li].b, layers[li].bn, N, K, W, Bv)) return false;
+        if (layers[li].padN > N) {
+            N = layers[li].padN;
+            W.resize((size_t)N * K, 0.0f);
+            Bv.resize(N, 0.0f);
+        }
         const int KS = li == 0 ? ((int)first_map.size() + 15) / 16 : K / 16;
         for (int nb = 0; nb < N / 32; ++nb)
             for (int s = 0; s < KS; ++s)
@@ -453,20 +454,6 @@ bool build_chain_blob_mats(lsdm_ctx* c, const std::vector<ChainMat>& mats, const
     out->w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(blob.data()), blob.size() / 2));
     out->b = upload(c, biases.data(), biases.size());
     return out->w && out->b;
-}
-bool build_chain_blob(lsdm_ctx* c, const std::vector<ChainLayer>& layers, const std::vector<int>& first_map, int np, DenseH* out) {
-    std::vector<ChainMat> mats(layers.size());
-    for (size_t li = 0; li < layers.size(); ++li) {
-        ChainMat& m = mats[li];
-        m.N = layers[li].N; m.K = layers[li].K;
-        if (!fold_dense(c, layers[li].w, layers[li].b, layers[li].bn, m.N, m.K, m.W, m.Bv)) return false;
-        if (layers[li].padN > m.N) {
-            m.N = layers[li].padN;
-            m.W.resize((size_t)m.N * m.K, 0.0f);
-            m.Bv.resize(m.N, 0.0f);
-        }
-    }
-    return build_chain_blob_mats(c, mats, first_map, np, out);
 }
 
 // Fragment blob of denoise_reg.hip::denoise_r_kernel, fragments [nb][k-step s][plane][lane][8] per layer, layers back to back:
@@ -662,7 +649,7 @@ void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* 
 // skip_sa1 (loop-invariant schedule): level 1 comes from the call's invariants.  In bf16x3 with the split sa2 / fp2 layers the
 // invariants stay in SOURCE order (inv_F1, sa_U[2] / sa_V[2]) and are read through the step's FPS order f.idx[0]; otherwise
 // l1_remap_kernel has re-ordered the feature rows into feat[0].
-bool inv_in_source_order(const lsdm_ctx* c) { return c->prec == LSDM_PREC_BF16X3 && c->sa_split >= 3 && c->sa_reg > 1 && c->fp_pre >= 1; }
+bool inv_in_source_order(const lsdm_ctx* c) { return c->prec != LSDM_PREC_F32 && c->sa_split >= 3 && c->sa_reg > 1 && c->fp_pre >= 1; }
 
 void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int nc, float* out, hipStream_t st, bool skip_sa1 = false) {
     const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
@@ -684,14 +671,9 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         launch_fp(1, nc, nullptr, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp[3], c->head, out, st);
         return;
     }
-    // split-bf16 core: bf16x3 keeps the fp32 feature tensors, bf16 uses the bf16 ones
+    // split-bf16 core (np = 2: bf16x3, np = 1: plain bf16): level features, U / V and Y are fp32 tensors in both
     const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
-    void* feat[4];
-    void* fpo[3];
-    for (int l = 0; l < 4; ++l) feat[l] = np == 2 ? (void*)c->feat[l] : c->feat_b[l];
-    fpo[0] = np == 2 ? (void*)c->fpo4 : c->fpo_b[0];
-    fpo[1] = np == 2 ? (void*)c->fpo3 : c->fpo_b[1];
-    fpo[2] = np == 2 ? (void*)c->fpo2 : c->fpo_b[2];
+    float* const* feat = c->feat;
     const void* lvl_feat[5] = {clouds, feat[0], feat[1], feat[2], feat[3]};
     // the step's item lists (geometry only): two ball-query groups whose distinct neighbours fit into 32 rows together share a block
     const bool src1 = skip_sa1 && inv_in_source_order(c);      // sa2 reads the per-call U / V through the step's level-1 order
@@ -699,7 +681,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     const bool fits1 = (long long)nc * 1024 < kItemRowLimit;
     // (a single step pays two planner launches for its lists: measured break-even around 4 chains -- strict schedule 2262 vs 2269 steps/s at
     // B = 4, 1790 vs 1705 at B = 8, 1177 vs 1099 at B = 16, 400 vs 361 at B = 64; LSDM_SA_PAIR=2 forces them at any size)
-    const bool on = np == 2 && c->sa_pair && (nc >= 54 || c->sa_pair > 1);
+    const bool on = c->sa_pair && (nc >= 54 || c->sa_pair > 1);
     const bool items[4] = {on && !skip_sa1 && c->sa_reg > 0 && fits1, on && c->sa_split >= 3 && c->sa_reg > 1 && !src1, on && c->sa_split >= 1, on && c->sa_split >= 2};
     {
         const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};
@@ -722,41 +704,43 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         if (l == 0 && items[0]) {
             launch_sa_r_items(clouds, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, c->feat[0], st);
             prof_exec(c, K_SA1, c->step_host[0] * xm::SA1_ITEM);
-        } else if (np == 2 && l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
+        } else if (l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
             // sa2: U, V per level-1 point -- per step in FPS order, or (loop-invariant schedule) once per call in source order
             const bool src = src1;
-            if (!src) launch_lin_u(1, nc * 1024, c->feat[0], lvl_xyz[1], c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
+            if (!src) launch_lin_u(np, 1, nc * 1024, c->feat[0], lvl_xyz[1], c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
             if (items[1]) {
-                launch_sa_u_items(1, c->sa_U[2], c->sa_V[2], c->step_rows[1], c->step_meta[1], c->step_cnt + 1, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
+                launch_sa_u_items(np, 1, c->sa_U[2], c->sa_V[2], c->step_rows[1], c->step_meta[1], c->step_cnt + 1, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
                 prof_exec(c, K_SA1 + 1, nc * xm::SA2_UV + c->step_host[1] * xm::SA2_CENT);
             } else {
-                launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
+                launch_sa_u(np, 1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
                 prof_exec(c, K_SA1 + 1, nc * ((src ? 0.0 : xm::SA2_UV) + 256 * xm::SA2_CENT));
             }
-        } else if (np == 2 && l == 2 && c->sa_split >= 1) {
+        } else if (l == 2 && c->sa_split >= 1) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
-            launch_lin_u(2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
+            launch_lin_u(np, 2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
             if (items[2]) {
-                launch_sa_u_items(2, c->sa_U[0], c->sa_V[0], c->step_rows[2], c->step_meta[2], c->step_cnt + 2, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+                launch_sa_u_items(np, 2, c->sa_U[0], c->sa_V[0], c->step_rows[2], c->step_meta[2], c->step_cnt + 2, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
                 prof_exec(c, K_SA1 + 2, nc * xm::SA3_UV + c->step_host[2] * xm::SA3_ITEM);
             } else {
-                launch_sa_u(2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
+                launch_sa_u(np, 2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
                 prof_exec(c, K_SA1 + 2, nc * xm::SA3);
             }
-        } else if (np == 2 && l == 3 && c->sa_split >= 2) {
-            launch_lin_u(3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
+        } else if (l == 3 && c->sa_split >= 2) {
+            launch_lin_u(np, 3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
             if (items[3]) {
-                launch_sa_u_items(3, c->sa_U[1], c->sa_V[1], c->step_rows[3], c->step_meta[3], c->step_cnt + 3, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
+                launch_sa_u_items(np, 3, c->sa_U[1], c->sa_V[1], c->step_rows[3], c->step_meta[3], c->step_cnt + 3, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
                 prof_exec(c, K_SA1 + 3, nc * xm::SA4_UV + c->step_host[3] * xm::SA4_ITEM);
             } else {
-                launch_sa_u(3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
+                launch_sa_u(np, 3, nc, c->sa_U[1], c->sa_V[1], f.idx[3], f.ball[3], nullptr, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
                 prof_exec(c, K_SA1 + 3, nc * xm::SA4);
             }
         } else {
+            // the reference forms of the bf16x3 build (LSDM_SA_SPLIT / LSDM_SA_REG), and sa1 of a small batch (two planes in every mode)
+            const int npl = l == 0 ? 2 : np;
             if (l < c->sa_reg)
-                launch_sa_r(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
+                launch_sa_r(npl, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
             else
-                launch_sa_h(np, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
+                launch_sa_h(npl, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
             const double full[4] = {xm::SA1, xm::SA2_FULL, xm::SA3_FULL, xm::SA4_FULL};
             prof_exec(c, K_SA1 + l, nc * full[l]);
         }
@@ -765,30 +749,24 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     prof_mark(c, K_FP4, st);
     // fp4 / fp3 also write the next finer stage's pre-multiplied interpolation operand (one more layer on their rows) when that stage
     // takes the pre-multiplied form
-    const bool fuse_y = np == 2 && c->fp_pre >= 2 && c->fuse_y;
-    const bool fpw = fuse_y && c->fp4_pre && c->fp_wk && c->fp_w[0].w;      // fp3 / fp4 on the register-chained panel kernel (encoder_w.hip)
-    if (fpw) {
-        launch_fp_y512(nc * 16, c->feat[3], c->fp_y[2], c->fp_ybuf[2], st);
-        launch_fp_w(4, nc, c->feat[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_w[1].w, c->fp_w[1].b, c->keep_taps ? c->fpo4 : nullptr, c->fp_ybuf[0], c->num_cus, st);
-    } else if (fuse_y && c->fp4_pre)
+    const bool fuse_y = c->fp_pre >= 2 && c->fuse_y;
+    if (fuse_y && c->fp4_pre)
         // fp4 in the pre-multiplied form too: Y4 = feat4 x Wb^T on the 16 coarse points of a cloud, the matrix pipe then contracts over the
         // 256 columns of points1 only (K = 256 instead of 768: a third of the fragments every 64-row tile streams from L2)
-        launch_fp_pre(4, nc, c->feat[2], nullptr, c->feat[3], c->fp_y[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], c->fpo4, false,
+        launch_fp_pre(np, 4, nc, c->feat[2], nullptr, c->feat[3], c->fp_y[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], c->fpo4, false,
                       c->fp_y[0], c->fp_ybuf[0], c->keep_taps, st);
     else if (fuse_y) launch_fp4_y(nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], c->fp_y[0], c->fpo4, c->fp_ybuf[0], c->keep_taps, st);
-    else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, fpo[0], st);
+    else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, c->fpo4, st);
     prof_exec(c, K_FP4, nc * (fuse_y && c->fp4_pre ? xm::FP4_PRE : (fuse_y ? xm::FP4_Y : xm::FP4_FULL)));
     prof_mark(c, K_FP3, st);
-    if (fpw)
-        launch_fp_w(3, nc, c->feat[1], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_w[0].w, c->fp_w[0].b, c->keep_taps ? c->fpo3 : nullptr, c->fp_ybuf[1], c->num_cus, st);
-    else if (np == 2 && c->fp_pre >= 2)
-        launch_fp_pre(3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, fuse_y,
+    if (c->fp_pre >= 2)
+        launch_fp_pre(np, 3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, fuse_y,
                       c->fp_y[1], fuse_y ? c->fp_ybuf[1] : nullptr, c->keep_taps, st);
     else
-        launch_fp_h(np, 3, nc, feat[1], fpo[0], f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, fpo[1], st);
-    prof_exec(c, K_FP3, nc * (np == 2 && c->fp_pre >= 2 ? xm::FP3_PRE + (fuse_y ? xm::FP3_NEXT_Y : xm::FP3_OWN_Y) : xm::FP3_FULL));
+        launch_fp_h(np, 3, nc, feat[1], c->fpo4, f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, c->fpo3, st);
+    prof_exec(c, K_FP3, nc * (c->fp_pre >= 2 ? xm::FP3_PRE + (fuse_y ? xm::FP3_NEXT_Y : xm::FP3_OWN_Y) : xm::FP3_FULL));
     prof_mark(c, K_FP2, st);
-    if (np == 2 && c->fp_pre >= 1) {
+    if (c->fp_pre >= 1) {
         const bool src = skip_sa1 && inv_in_source_order(c);   // level-1 features in source order, read through f.idx[0]
         const float* p1 = src ? static_cast<const float*>(c->inv_F1) : c->feat[0];
         const int* remap = src ? f.idx[0] : nullptr;
@@ -798,14 +776,14 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
             launch_morton_order(nc, f.xyz[0], c->fp2_order, st);
             launch_fp_plan(nc, c->fp2_order, 0, nullptr, f.nn_idx[2], remap, c->fp2_plan, st);
         }
-        launch_fp_pre(2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
+        launch_fp_pre(np, 2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
                       DenseH{nullptr, nullptr}, nullptr, true, st, 0, planned ? c->fp2_plan : nullptr);
     } else
-        launch_fp_h(np, 2, nc, feat[0], fpo[1], f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, fpo[2], st);
-    prof_exec(c, K_FP2, nc * (np == 2 && c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
+        launch_fp_h(np, 2, nc, feat[0], c->fpo3, f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, c->fpo2, st);
+    prof_exec(c, K_FP2, nc * (c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
     prof_mark(c, K_FP1, st);
-    if (np == 2 && c->fp1_reg) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
-    else launch_fp_h(np, 1, nc, nullptr, fpo[2], f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
+    if (c->fp1_reg) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
+    else launch_fp_h(np, 1, nc, nullptr, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
     prof_exec(c, K_FP1, nc * xm::FP1);
 }
 
@@ -913,6 +891,7 @@ static void stream_join(lsdm_ctx* c, hipStream_t st) {
 void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds, int B, int steps, hipStream_t st0) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = c->enc_nc > 0 ? c->enc_nc : B * kO, nc = nc1 * steps;
+    const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
     const int nl = lanes(c);
     const bool two = nl > 1;
     hipStream_t st = st0;
@@ -926,11 +905,11 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
         prof_mark(c, K_BALL1 + 1, st, steps);
         launch_ball_query(f.xyz[0], f.xyz[1], nc, 1024, 256, (float)(kRadius[1] * kRadius[1]), f.ball[1], 0, st, g.memo_crowd);
         prof_mark(c, K_SA1 + 1, st, steps);
-        launch_sa_u_list(256, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1, g.memo_list,
+        launch_sa_u_list(np, 256, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1, g.memo_list,
                          g.memo_cnt + 1);
         prof_exec_dev(c, K_SA1 + 1, g.memo_cnt + 1, xm::SA2_CENT, st);      // the crowded centroids of the group only
     } else {
-        launch_sa_u(1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
+        launch_sa_u(np, 1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], f.idx[0], c->sa_ub[2].w, c->sa_ub[2].b, g.feat[1], st, nc1);
         prof_exec(c, K_SA1 + 1, nc * 256 * xm::SA2_CENT);
     }
     // fp2's tile plans of every step of the group in one launch: the source clouds' Z-curve order (once per call) read through each step's
@@ -968,23 +947,23 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
             float* const f2 = g.feat[2] + ((size_t)j * nc1 + o) * 64 * 256;
             float* const f3 = g.feat[3] + ((size_t)j * nc1 + o) * 16 * 512;
             prof_mark(c, K_SA1 + 2, st);
-            launch_lin_u(2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], U0, V0, st);
+            launch_lin_u(np, 2, ncp * 256, f1, fj.xyz[1] + o * 256 * 3, c->sa_uw[0], c->sa_wx[0], U0, V0, st);
             if (c->sa_pair) {
                 const size_t t1 = (size_t)j * nc1 * 64;
-                launch_sa_u_items(2, U0, V0, g.pair_rows[0] + t1 * 32, g.pair_meta[0] + t1, g.pair_cnt[0] + j, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+                launch_sa_u_items(np, 2, U0, V0, g.pair_rows[0] + t1 * 32, g.pair_meta[0] + t1, g.pair_cnt[0] + j, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
                 prof_exec(c, K_SA1 + 2, ncp * xm::SA3_UV + c->pair_host[0][j] * xm::SA3_ITEM);     // the blocks that ran
             } else {
-                launch_sa_u(2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
+                launch_sa_u(np, 2, ncp, U0, V0, fj.idx[2] + o * 64, fj.ball[2] + o * 64 * 32, nullptr, c->sa_ub[0].w, c->sa_ub[0].b, f2, st);
                 prof_exec(c, K_SA1 + 2, ncp * xm::SA3);
             }
             prof_mark(c, K_SA1 + 3, st);
-            launch_lin_u(3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], U1, V1, st);
+            launch_lin_u(np, 3, ncp * 64, f2, fj.xyz[2] + o * 64 * 3, c->sa_uw[1], c->sa_wx[1], U1, V1, st);
             if (c->sa_pair) {
                 const size_t t1 = (size_t)j * nc1 * 16;
-                launch_sa_u_items(3, U1, V1, g.pair_rows[1] + t1 * 32, g.pair_meta[1] + t1, g.pair_cnt[1] + j, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+                launch_sa_u_items(np, 3, U1, V1, g.pair_rows[1] + t1 * 32, g.pair_meta[1] + t1, g.pair_cnt[1] + j, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
                 prof_exec(c, K_SA1 + 3, ncp * xm::SA4_UV + c->pair_host[1][j] * xm::SA4_ITEM);
             } else {
-                launch_sa_u(3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
+                launch_sa_u(np, 3, ncp, U1, V1, fj.idx[3] + o * 16, fj.ball[3] + o * 16 * 32, nullptr, c->sa_ub[1].w, c->sa_ub[1].b, f3, st);
                 prof_exec(c, K_SA1 + 3, ncp * xm::SA4);
             }
         }
@@ -993,11 +972,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
     if (two) stream_join(c, st0);
     prof_mark(c, K_FP4, st, steps);
     // (fp4 / fp3 store only the next finer stage's pre-multiplied operand inside a multi-step call: keep_out = false, `out` unused)
-    if (c->fp_wk && c->fp_w[1].w) {
-        launch_fp_y512(nc * 16, g.feat[3], c->fp_y[2], g.ybuf[2], st);
-        launch_fp_w(4, nc, g.feat[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_w[1].w, c->fp_w[1].b, nullptr, g.ybuf[0], c->num_cus, st);
-    } else
-    launch_fp_pre(4, nc, g.feat[2], nullptr, g.feat[3], c->fp_y[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], nullptr, false,
+    launch_fp_pre(np, 4, nc, g.feat[2], nullptr, g.feat[3], c->fp_y[2], g.ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], nullptr, false,
                   c->fp_y[0], g.ybuf[0], false, st);
     prof_exec(c, K_FP4, nc * xm::FP4_PRE);
     prof_mark(c, -1, st);
@@ -1008,6 +983,7 @@ void run_encoder_group_front(lsdm_ctx* c, const FrontSet& f, const float* clouds
 void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float* pcd_out, hipStream_t st, int lane) {
     const lsdm_ctx::GroupWs& g = c->gws;
     const int nc1 = c->enc_nc > 0 ? c->enc_nc : B * kO;
+    const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
     float* const ybuf1 = lane ? g.alt[lane - 1].ybuf1 : c->fp_ybuf[1];
     float* const fpo2 = lane ? g.alt[lane - 1].fpo2 : c->fpo2;
     const int* const plan = fp2_ws() == 4 ? g.plan + (size_t)j * nc1 * fp_plan_ints(1024) : nullptr;
@@ -1017,15 +993,11 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         const size_t o = 0;
         const int ncp = nc1;
         prof_mark(c, K_FP3, st);
-        if (c->fp_wk && c->fp_w[0].w)
-            launch_fp_w(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256, fj.nn_idx[1] + o * 256 * 3,
-                        fj.nn_w[1] + o * 256 * 3, c->fp_w[0].w, c->fp_w[0].b, nullptr, ybuf1, c->num_cus, st);
-        else
-        launch_fp_pre(3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
+        launch_fp_pre(np, 3, ncp, g.feat[1] + ((size_t)j * nc1 + o) * 256 * 128, nullptr, nullptr, c->fp_y[0], g.ybuf[0] + ((size_t)j * nc1 + o) * 64 * 256,
                       fj.nn_idx[1] + o * 256 * 3, fj.nn_w[1] + o * 256 * 3, c->fp_a[0], c->fp_h[1][1], nullptr, true, c->fp_y[1], ybuf1, false, st);
         prof_exec(c, K_FP3, ncp * (xm::FP3_PRE + xm::FP3_NEXT_Y));
         prof_mark(c, K_FP2, st);
-        launch_fp_pre(2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], ybuf1, fj.nn_idx[2] + o * 1024 * 3,
+        launch_fp_pre(np, 2, ncp, static_cast<const float*>(c->inv_F1) + o * 1024 * 64, fj.idx[0] + o * 1024, nullptr, c->fp_y[1], ybuf1, fj.nn_idx[2] + o * 1024 * 3,
                       fj.nn_w[2] + o * 1024 * 3, c->fp_a[1], c->fp_h[2][1], fpo2, true, DenseH{nullptr, nullptr}, nullptr, true, st, 0, plan);
         prof_exec(c, K_FP2, ncp * xm::FP2_PRE);
         prof_mark(c, K_FP1, st);
@@ -1132,9 +1104,8 @@ void run_back(lsdm_ctx* c, const FrontSet& f, int mode, float eta, int B, float*
     if (inv) {
         // level 1 of the encoder from the call's invariants: feature rows and 3-NN positions in this step's FPS order
         prof_mark(c, K_REMAP, st);
-        const int np = c->prec == LSDM_PREC_F32 ? 0 : (c->prec == LSDM_PREC_BF16X3 ? 2 : 1);
-        launch_l1_remap(B * kO, c->inv_F1, np == 1 ? 128 : 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], given_objs,
-                        inv_in_source_order(c) ? nullptr : (np == 1 ? c->feat_b[0] : (void*)c->feat[0]), f.nn_idx[3], f.nn_w[3], st);
+        launch_l1_remap(B * kO, c->inv_F1, 256, f.idx[0], c->inv_nn8_d, c->inv_nn8_i, f.xyz[0], given_objs,
+                        inv_in_source_order(c) ? nullptr : (void*)c->feat[0], f.nn_idx[3], f.nn_w[3], st);
     }
     run_scene_conditioning(c, f, B, given_objs, st, inv);
     run_denoise(c, f, mode, eta, B, x, t, mask, noise, out_x0, out_guiding, out_sample, st, 1, shared);
@@ -1299,10 +1270,18 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                 ok = c->head_h[1].w != nullptr;
             }
         }
-        ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], np, &c->sa_r[0]) &&
+        // Plain bf16 (np = 1) runs the same kernel family as bf16x3 with single-plane operands -- lin_u (U / V, Y), sa2, sa3, sa4, fp4, fp3, the
+        // conditioning and the denoiser -- except three stages whose kernels exist in the two-plane form only and keep the split arithmetic there:
+        // sa1 (once per call), fp2 (fp_d_kernel) and fp1 + head (fp_c_kernel: weights register-resident as hi + lo fragment pairs).
+        if (np == 1) {      // the A/B switches select reference forms of the bf16x3 build; plain bf16 always takes the default family
+            c->sa_split = 3; c->sa_reg = 3; c->fp_pre = 2; c->fuse_y = 1; c->fp4_pre = 1; c->fp1_reg = 1;
+            const std::string p2 = "pcd_backbone.fp2";
+            ok = ok && load_dense_h(c, p2 + ".mlp_convs.1.weight", p2 + ".mlp_convs.1.bias", p2 + ".mlp_bns.1", 128, 256, 2, {}, &c->fp_h[2][1]);
+        }
+        ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], 2, &c->sa_r[0]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa3", 128, sa_mlp[2], np, &c->sa_r[2]);
-        if (np == 2 && ok) {
+        if (ok) {
             // sa3: first layer (128 x 131, reference column order [xyz (3) || features (128)]) split into Wx | Wf
             const std::string pre = "pcd_backbone.sa3";
             std::vector<float> W, Bv;
@@ -1355,7 +1334,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                                                   {pb + ".conv2.weight", pb + ".conv2.bias", "", 3, 128, 32}};
                 std::vector<int> ident(128);
                 for (int k = 0; k < 128; ++k) ident[k] = k;
-                ok = build_chain_blob(c, layers, ident, np, &c->fp1_s);
+                ok = build_chain_blob(c, layers, ident, 2, &c->fp1_s);
             }
             // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
             {
@@ -1372,35 +1351,14 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                         for (int k = 0; k < d1[i]; ++k) wa[(size_t)n * d1[i] + k] = Wf[(size_t)n * K + k];
                         for (int k = 0; k < d2[i]; ++k) wb[(size_t)n * d2[i] + k] = Wf[(size_t)n * K + d1[i] + k];
                     }
-                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], np, {}), pb = pack_weight_h(wb, 256, d2[i], np, {});
+                    // (i = 1, fp2: its first layer runs in fp_d_kernel, two planes in every mode; its Wb is the extra layer of fp3's launch)
+                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], i == 1 ? 2 : np, {}), pb = pack_weight_h(wb, 256, d2[i], np, {});
                     c->fp_a[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pa.data()), pa.size() / 2));
                     c->fp_a[i].b = upload(c, Bf.data(), Bf.size());
                     c->fp_y[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pb.data()), pb.size() / 2));
                     c->fp_y[i].b = nullptr;
                     ok = c->fp_a[i].w && c->fp_a[i].b && c->fp_y[i].w;
                 }
-            }
-            // fp3 / fp4 as chains for fp_w_kernel: [Wa | mlp_convs.1 | Wb of the next finer stage (fp2 / fp3)]
-            for (int i = 0; i < 2 && ok; ++i) {
-                const char* own = i == 0 ? "pcd_backbone.fp3" : "pcd_backbone.fp4";
-                const char* nxt = i == 0 ? "pcd_backbone.fp2" : "pcd_backbone.fp3";
-                const int d1 = i == 0 ? 128 : 256, d2 = i == 0 ? 256 : 512, nd1 = i == 0 ? 64 : 128;
-                std::vector<float> W0, B0, Wn, Bn;
-                std::vector<ChainMat> mats(3);
-                ok = fold_dense(c, std::string(own) + ".mlp_convs.0.weight", std::string(own) + ".mlp_convs.0.bias", std::string(own) + ".mlp_bns.0", 256, d1 + d2, W0, B0) &&
-                     fold_dense(c, std::string(own) + ".mlp_convs.1.weight", std::string(own) + ".mlp_convs.1.bias", std::string(own) + ".mlp_bns.1", 256, 256, mats[1].W, mats[1].Bv) &&
-                     fold_dense(c, std::string(nxt) + ".mlp_convs.0.weight", std::string(nxt) + ".mlp_convs.0.bias", std::string(nxt) + ".mlp_bns.0", 256, nd1 + 256, Wn, Bn);
-                if (!ok) break;
-                mats[0].N = 256; mats[0].K = d1; mats[0].W.resize((size_t)256 * d1); mats[0].Bv = B0;
-                mats[1].N = 256; mats[1].K = 256;
-                mats[2].N = 256; mats[2].K = 256; mats[2].W.resize((size_t)256 * 256); mats[2].Bv.assign(256, 0.0f);
-                for (int n = 0; n < 256; ++n) {
-                    for (int k = 0; k < d1; ++k) mats[0].W[(size_t)n * d1 + k] = W0[(size_t)n * (d1 + d2) + k];
-                    for (int k = 0; k < 256; ++k) mats[2].W[(size_t)n * 256 + k] = Wn[(size_t)n * (nd1 + 256) + nd1 + k];
-                }
-                std::vector<int> ident(d1);
-                for (int k = 0; k < d1; ++k) ident[k] = k;
-                ok = build_chain_blob_mats(c, mats, ident, np, &c->fp_w[i]);
             }
             // sa4: first layer (256 x 259) split the same way; layers 2-3 are the LDS-tiled operands sa_h[3][1..2]
             std::vector<float> W4, B4;
@@ -1649,13 +1607,6 @@ int lsdm_reserve(lsdm_ctx* c, int B) {
                  (c->step_chunk[l] = ws_alloc<int>(c, (std::string(nm[l]) + "_chunks").c_str(), (size_t)sa_pair_chunks((int)(nc * kS[l]))));
         ok = ok && (c->step_cnt = ws_alloc<int>(c, "sa_step_items", 4));      // blocks of the last single step's lists, by SA level
     }
-    if (ok && c->prec == LSDM_PREC_BF16) {
-        // 2-byte elements: ws_alloc<uint16_t>
-        for (int l = 0; l < 4 && ok; ++l)
-            ok = (c->feat_b[l] = ws_alloc<uint16_t>(c, (std::string("feat_bf") + lv[l]).c_str(), nc * kS[l] * kFeatC[l])) != nullptr;
-        ok = ok && (c->fpo_b[0] = ws_alloc<uint16_t>(c, "fp4_bf", nc * 64 * 256)) && (c->fpo_b[1] = ws_alloc<uint16_t>(c, "fp3_bf", nc * 256 * 256)) &&
-             (c->fpo_b[2] = ws_alloc<uint16_t>(c, "fp2_bf", nc * 1024 * 128));
-    }
     if (!ok) return LSDM_ERR_HIP;
     c->cap_B = B;
     return LSDM_OK;
@@ -1780,19 +1731,20 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
-            const bool items1 = c->sa_reg > 0 && np == 2 && c->sa_pair && (long long)nc * kN < kItemRowLimit;
+            const bool items1 = c->sa_reg > 0 && c->sa_pair && (long long)nc * kN < kItemRowLimit;
             if (!items1) prof_exec(c, K_SA1, nc * xm::SA1);
             if (items1) {
                 // (r = 0.1: seven distinct neighbours per group on the bench clouds -- half the blocks)
                 launch_sa_pair_plan(1, nc * kN, kN, kN, c->inv_ball, nullptr, c->step_chunk[0], c->step_rows[0], c->step_meta[0], c->step_cnt, si);
                 launch_sa_r_items(enc_clouds, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, static_cast<float*>(c->inv_F1), si);
                 prof_exec_dev(c, K_SA1, c->step_cnt, xm::SA1_ITEM, si);
-            } else if (c->sa_reg > 0) launch_sa_r(np, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);
+            } else if (c->sa_reg > 0) launch_sa_r(2, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);      // (sa1: two planes in every mode)
             else launch_sa_h(np, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_h[0], c->inv_F1, si);
         }
+        const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;      // (used by the split-bf16 branches below only)
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])
         {
-            launch_lin_u(1, nc * 1024, static_cast<const float*>(c->inv_F1), enc_clouds, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
+            launch_lin_u(np, 1, nc * 1024, static_cast<const float*>(c->inv_F1), enc_clouds, c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], si);
             prof_exec(c, K_SA1 + 1, nc * xm::SA2_UV);       // (timed inside the sa1 interval of the call's prelude)
         }
         // memo of sa2 (geometry.hip::memo_src_kernel): the stage's output of every source point with fewer than 32 points within r, once
@@ -1808,10 +1760,10 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             if (c->sa_pair && gw.memo_rows && (long long)nc * kN < kItemRowLimit) {
                 // every uncrowded point's group has fewer than 32 distinct entries: two to a block where they fit (geometry.hip: sa_pair_kernel)
                 launch_sa_pair_plan(1, (int)nc * kN, kN, kN, gw.memo_ball2, nullptr, gw.memo_chunks, gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, si, gw.memo_unc);
-                launch_sa_u_items(1, c->sa_U[2], c->sa_V[2], gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si);
+                launch_sa_u_items(np, 1, c->sa_U[2], c->sa_V[2], gw.memo_rows, gw.memo_meta, gw.memo_cnt + 2, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si);
                 prof_exec_dev(c, K_SA1 + 1, gw.memo_cnt + 2, xm::SA2_CENT, si);     // the blocks that ran
             } else {
-                launch_sa_u_list(1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
+                launch_sa_u_list(np, 1024, c->sa_U[2], c->sa_V[2], gw.memo_ident, gw.memo_ball2, nullptr, c->sa_ub[2].w, c->sa_ub[2].b, gw.memo_F2, si, 0,
                                  gw.memo_src_list, gw.memo_cnt);
                 prof_exec_dev(c, K_SA1 + 1, gw.memo_cnt, xm::SA2_CENT, si);     // sa2 once per call on the uncrowded source points
             }

@@ -69,10 +69,10 @@ __device__ __forceinline__ void relu_split_pair_u(const f32x16& acc, const float
 // measured: sa3 317 vs 318 us, sa4 344 vs 340 incl. the U / V launches: the stage is not bound by that write; not kept.  A persistent form -- 461 work-groups
 // walking five tiles each, the next tile's rows requested before this tile's matrix instructions -- measured slower as well, sa3 stage 323 vs 320 us, strict sa2
 // 363 vs 356, round 4: two one-tile work-groups per CU already overlap each other's loads and stores)
-template <int K, int N, bool XYZ = true>
+template <int K, int N, bool XYZ = true, int NP = 2>
 __global__ __launch_bounds__(256, 2) void lin_u_kernel(const float* __restrict__ X, const float* __restrict__ xyz, int R, DenseH W,
                                                        const float* __restrict__ wx, float* __restrict__ U, float* __restrict__ V) {
-    constexpr int TM = 64, NW = 4, NP = 2, NT = NW * 64;
+    constexpr int TM = 64, NW = 4, NT = NW * 64;
     constexpr int LDX = ldh(K), PX = TM * LDX;
     __shared__ __attribute__((aligned(16))) __bf16 bufX[NP * PX];
     __shared__ float sxyz[TM * 3];
@@ -168,14 +168,14 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 // scheduling pattern of one channel block of KS k-steps (3 MFMAs each) next to NV VALU instructions per MFMA: per k-step two LDS
 // fragment reads, then MFMA / VALU alternating; the first LEAD MFMAs run without VALU (the epilogue they cover reads the previous
 // block's accumulator, whose last MFMA is still in flight)
-template <int KS, int NV, int LEAD>
+template <int KS, int NV, int LEAD, int NM = 3>
 __device__ __forceinline__ void sgb_block() {
     static_for<KS>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
-        static_for<3>([&](auto m_) {
+        static_for<NM>([&](auto m_) {
             constexpr int m = decltype(m_)::value;
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (3 * s + m >= LEAD) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            if constexpr (NM * s + m >= LEAD) __builtin_amdgcn_sched_group_barrier(0x002, NV * 3 / NM, 0);
         });
     });
 }
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
                                                         long long total_centroids, const __bf16* __restrict__ blob_w,
                                                         const float* __restrict__ blob_b, float* __restrict__ out,
                                                         const int4* __restrict__ pmeta, const int* __restrict__ pcount) {
-    static_assert(NP == 2, "bf16x3 only");
     constexpr int NT = NW * 64;
     constexpr int KS2 = C1 / 16, KS3 = C2 / 16;
+    constexpr int NM = NP == 2 ? 3 : 1;                      // matrix instructions per k-step
     constexpr int NB2 = C2 / 32, NB3 = C3 / 32;
     constexpr int F2 = KS2 * NP, F3 = KS3 * NP;
     constexpr int W2E = NB2 * F2 * 512;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
         bf16x8 fh[3], fl[3];
         auto frag = [&](const __bf16* W, int KS, int t, bf16x8& oh, bf16x8& ol) {      // flat step t of a stream of blocks of KS k-steps
             oh = wfrag_lds_u<NP>(W, KS, 0, t, 0, lane);
-            ol = wfrag_lds_u<NP>(W, KS, 0, t, 1, lane);
+            if constexpr (NP == 2) ol = wfrag_lds_u<NP>(W, KS, 0, t, 1, lane);
         };
         auto l2_epi = [&](auto nb_, const f32x16& a) {
             constexpr int nb = decltype(nb_)::value;
@@ -338,11 +338,13 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
                 if constexpr (t + 2 < NB2 * KS2) frag(W2p, KS2, t + 2, fh[(t + 2) % 3], fl[(t + 2) % 3]);
                 else frag(&wl[0][0] + lz, KS3, t + 2 - NB2 * KS2, fh[(t + 2) % 3], fl[(t + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0x47f);      // the fragment reads keep their place two k-steps ahead; everything else may move
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[t % 3], yl[s], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[t % 3], yh[s], a, 0, 0, 0);
+                if constexpr (NP == 2) {
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[t % 3], yl[s], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[t % 3], yh[s], a, 0, 0, 0);
+                }
                 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[t % 3], yh[s], a, 0, 0, 0);
             });
-            if constexpr (nb > 0) sgb_block<KS2, 3, 2>();
+            if constexpr (nb > 0) sgb_block<KS2, 3, 2, NM>();
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- layer 3 (streamed panels of PB = 2 blocks): block j accumulates in acc[j & 1]; its pooled epilogue runs under block j + 1
@@ -367,12 +369,14 @@ __global__ __launch_bounds__(NW * 64) void sa_p_kernel(const float* __restrict__
                     constexpr int base = q == 0 ? (NB2 * KS2) % 3 : 0;   // ring slot of the panel's step 0 (panel 0 continues layer 2's ring)
                     if constexpr (t + 2 < PB * KS3) frag(W, KS3, t + 2, fh[(base + t + 2) % 3], fl[(base + t + 2) % 3]);
                     __builtin_amdgcn_sched_barrier(0x47f);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], fh[(base + t) % 3], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], fl[(base + t) % 3], a, 0, 0, 0);
+                    if constexpr (NP == 2) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl[s], fh[(base + t) % 3], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], fl[(base + t) % 3], a, 0, 0, 0);
+                    }
                     a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh[s], fh[(base + t) % 3], a, 0, 0, 0);
                 });
-                if constexpr (j == 0) sgb_block<KS3, 3, 2>();
-                else sgb_block<KS3, 1, 2>();
+                if constexpr (j == 0) sgb_block<KS3, 3, 2, NM>();
+                else sgb_block<KS3, 1, 2, NM>();
                 __builtin_amdgcn_sched_barrier(0);
             });
             lds_dma_wait();
@@ -816,12 +820,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // level: ynext = out x Wb_next^T is one more layer on the rows that are already on chip -- no separate row-wise GEMM launch, no
 // re-read of `out` (which is then stored only when keep_out: the parity taps of the stage entry points).
 // TM_ x NW_: 64 rows x 4 waves, two work-groups per CU; or 128 rows x 8 waves, one per CU (half the weight stream per row).
-template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4>
+template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4, int NP_ = 2>
 __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                         const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
                                                         float* __restrict__ out, DenseH l3, float* __restrict__ ynext, int keep_out, int p1_mod) {
-    constexpr int TM = TM_, NW = NW_, NP = 2, NT = NW * 64;
+    constexpr int TM = TM_, NW = NW_, NP = NP_, NT = NW * 64;
     constexpr int TPP = NT / TM;                               // threads per fine point in the interpolation phase
     static_assert(TPP == 4 || TPP == 8, "four or eight threads per fine point in the interpolation phase");
     // fp32 tile row: C1 floats, no padding (a row is a whole number of bank rounds), and the quad index of an access is XORed with
@@ -873,19 +877,6 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
 #pragma unroll
         for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4);
     }
-    // The weight fragments a wave needs FIRST in a channel block's k loop are requested a whole block (or phase) ahead -- the first k-group of
-    // layer 1 here, in front of the gather; every later block's while the block before it runs (FUSE form: fp3 / fp4): a k loop that requests
-    // its own first group waits a loaded L2 round trip per channel block, six times per tile.  Same fragments, same order of arithmetic.
-    using TS0 = SplitH<NW, TM, C1>;
-    constexpr int U1 = kgroup(D1 / 16), U2 = kgroup(C1 / 16);
-    static_assert(!FUSE || (U1 == U2 && kgroup(C2 / 16) == U2), "one fragment-group type for the chained prefetch");
-    [[maybe_unused]] WFrag<NP, U1> wpre;
-#ifdef LSDM_FPPRE_NOCHAIN      // (A/B build only: every k loop requests its own first k-group)
-    constexpr bool CHAIN = false;
-#else
-    constexpr bool CHAIN = FUSE;
-#endif
-    if constexpr (CHAIN) wfrag_load<NP, D1 / 16>(wpre, l1.w, C1, wave % TS0::CSTEP, 0, lane);
     // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
     {
         const int row = arow;
@@ -948,27 +939,16 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         store_split4<NP>(bufX + row * LDX + 4 * c4, PX, gx[it][0], gx[it][1], gx[it][2], gx[it][3]);
     }
     __syncthreads();
-    using T2 = SplitH<NW, TM, C2>;
-    const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
-    if constexpr (CHAIN) {
 #pragma unroll
-        for (int q = 0; q < NCB; ++q) {
-            WFrag<NP, U1> wnext;
-            if (q + 1 < NCB) wfrag_load<NP, D1 / 16>(wnext, l1.w, C1, cb0 + (q + 1) * TS::CSTEP, 0, lane);
-            else wfrag_load<NP, C1 / 16>(wnext, l2.w, C2, cb2, 0, lane);               // layer 2's first block: lands under the epilogue + barrier
-            mma_kloop_pre_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane, wpre);
-            wpre = wnext;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < NCB; ++q)
-            mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
-    }
+    for (int q = 0; q < NCB; ++q)
+        mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
     __syncthreads();
     // ---- phase D: layer-1 epilogue -> bufB, layer 2 (direct orientation) -> global -----------------------------------------------
 #pragma unroll
     for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
     __syncthreads();
+    using T2 = SplitH<NW, TM, C2>;
+    const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
     if constexpr (!FUSE) {
 #pragma unroll 1
         for (int cb = cb2; cb < T2::CB; cb += T2::CSTEP) {
@@ -997,14 +977,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
             f32x4 bv2[4];
             load_bias_h(bv2, l2.b, cb2 + q * T2::CSTEP, lane);
             acc_bias_h(a2[q], bv2);
-            if constexpr (CHAIN) {
-                WFrag<NP, U2> wnext;
-                if (q + 1 < NCB2) wfrag_load<NP, C1 / 16>(wnext, l2.w, C2, cb2 + (q + 1) * T2::CSTEP, 0, lane);
-                else wfrag_load<NP, C2 / 16>(wnext, l3.w, 256, wave % SplitH<NW, TM, 256>::CSTEP, 0, lane);      // the extra layer's first block
-                mma_kloop_pre_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane, wpre);
-                wpre = wnext;
-            } else
-                mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
+            mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
         }
         __syncthreads();
 #pragma unroll
@@ -1024,20 +997,12 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         __syncthreads();
         using T3 = SplitH<NW, TM, 256>;
         const int cb3 = wave % T3::CSTEP, rg3 = wave / T3::CSTEP;
-        constexpr int NCB3 = T3::CB / T3::CSTEP;
-#pragma unroll
-        for (int q3 = 0; q3 < NCB3; ++q3) {
-            const int cb = cb3 + q3 * T3::CSTEP;
+#pragma unroll 1
+        for (int cb = cb3; cb < T3::CB; cb += T3::CSTEP) {
             f32x16 a3[T3::RB];
             acc_zero_h(a3);
             const int col = cb * 32 + (lane & 31);
-            if constexpr (CHAIN) {
-                WFrag<NP, U2> wnext;
-                if (q3 + 1 < NCB3) wfrag_load<NP, C2 / 16>(wnext, l3.w, 256, cb + T3::CSTEP, 0, lane);
-                mma_kloop_pre_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane, wpre);
-                if (q3 + 1 < NCB3) wpre = wnext;
-            } else
-                mma_kloop_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane);
+            mma_kloop_h<T3::RB, NP, false, C2 / 16>(a3, bufC + rg3 * T3::RB * 32 * LDC, LDC, PC, l3.w, 256, cb, 0, lane);
 #pragma unroll
             for (int rb = 0; rb < T3::RB; ++rb)
 #pragma unroll
@@ -1049,15 +1014,14 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     }
 }
 
+// Every launcher below takes np, the number of bf16 planes of the operands and of the weight blobs handed in: 2 = bf16x3 (three matrix
+// instructions per product), 1 = plain bf16 (one).  Level features, U / V and Y are fp32 in HBM in both.
+#define LSDM_NP(np, ...) do { if ((np) == 2) { constexpr int NPK = 2; __VA_ARGS__; } else { constexpr int NPK = 1; __VA_ARGS__; } } while (0)
+
 // which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
 // Y = coarse-level FP output x Wb^T, R = num_clouds * S rows of 256 channels
-void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
-    hipLaunchKernelGGL((lin_u_kernel<256, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
-}
-
-// fp4's Y: the 16 coarse points of a cloud carry 512 channels
-void launch_fp_y512(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
-    hipLaunchKernelGGL((lin_u_kernel<512, 256, false>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr);
+void launch_fp_y(int np, int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
+    LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<256, 256, false, NPK>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr));
 }
 
 // LSDM_FP2_WS: fp2 on 4 = the two-stage persistent kernel over Morton-ordered tiles with deduplicated rows (fp_d_kernel, encoder_d.hip; the default),
@@ -1067,92 +1031,84 @@ int fp2_ws() {
     return e ? (atoi(e) ? 4 : 0) : 4;
 }
 
-// y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3 only, optional):
-// fuse fp2's Y = out x wb_next^T into this launch; `out` itself is then stored only when keep_out.
-#ifndef LSDM_FP2_NW
-#define LSDM_FP2_NW 4
-#endif
-#ifndef LSDM_FP3_NW
-#define LSDM_FP3_NW 4
-#endif
-#ifndef LSDM_FP4_NW
-#define LSDM_FP4_NW 4
-#endif
-void launch_fp_pre(int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
+// y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3, 4; optional):
+// fuse the next finer stage's Y = out x wb_next^T into this launch; `out` itself is then stored only when keep_out.
+// (fp2 -- which = 2 -- exists in the two-plane form only: fp_d_kernel / fp_pre_kernel<64, ...> take np = 2 operands in every mode.)
+void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
                    bool keep_out, hipStream_t st, int p1_mod, const int* plan) {
     const int S = which == 2 ? 256 : (which == 3 ? 64 : 16);
     const DenseH none{nullptr, nullptr};
     if (which == 4) {
         // fp4: 64 fine <- 16 coarse points per cloud, D1 = 256, the coarse features are 512 wide
-        hipLaunchKernelGGL((lin_u_kernel<512, 256, false>), dim3((nc * 16 + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, nc * 16, wb, nullptr, ybuf, nullptr);
-        hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true, 64, LSDM_FP4_NW>), dim3(64 / 64 * nc), dim3(LSDM_FP4_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16, l1a, l2,
-                           out, wb_next, ynext, keep_out ? 1 : 0, p1_mod);
+        LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<512, 256, false, NPK>), dim3((nc * 16 + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, nc * 16, wb, nullptr, ybuf, nullptr));
+        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true, 64, 4, NPK>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16,
+                                       l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0, p1_mod));
         return;
     }
-    if (!y_ready) launch_fp_y(nc * S, fpo_coarse, wb, ybuf, st);
+    if (!y_ready) launch_fp_y(which == 2 ? 2 : np, nc * S, fpo_coarse, wb, ybuf, st);
     if (which == 2 && plan) {
         launch_fp_d(nc, points1, ybuf, nn_w, l1a, l2, out, plan, st, p1_mod);
     }
     else if (which == 2) {
-        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, LSDM_FP2_NW>), dim3(1024 / 64 * nc), dim3(LSDM_FP2_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
+        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, 4>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
                            none, nullptr, 1, p1_mod);
     }
     else if (ynext) {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
         // each other's gather and barrier phases)
-        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 64, LSDM_FP3_NW>), dim3(256 / 64 * nc), dim3(LSDM_FP3_NW * 64), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2,
-                           out, wb_next, ynext, keep_out ? 1 : 0, p1_mod);
+        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 64, 4, NPK>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64,
+                                       l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0, p1_mod));
     }
     else
-        hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64, l1a, l2, out,
-                           none, nullptr, 1, p1_mod);
+        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, false, 64, 4, NPK>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64,
+                                       l1a, l2, out, none, nullptr, 1, p1_mod));
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st) {
+void launch_lin_u(int np, int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st) {
     const dim3 grid((R + 63) / 64), block(256);
-    if (level == 1) hipLaunchKernelGGL((lin_u_kernel<64, 64>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
-    else if (level == 2) hipLaunchKernelGGL((lin_u_kernel<128, 128>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
-    else hipLaunchKernelGGL((lin_u_kernel<256, 256>), grid, block, 0, st, X, xyz, R, W, wx, U, V);
+    if (level == 1) LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<64, 64, true, NPK>), grid, block, 0, st, X, xyz, R, W, wx, U, V));
+    else if (level == 2) LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<128, 128, true, NPK>), grid, block, 0, st, X, xyz, R, W, wx, U, V));
+    else LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<256, 256, true, NPK>), grid, block, 0, st, X, xyz, R, W, wx, U, V));
 }
 
 // sa2 (the level-1 kernel) over a LIST of centroids: S centroids per cloud in the numbering of the list, list_count on the device
-void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
+void launch_sa_u_list(int np, int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
                       const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count) {
-    hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, S, 0LL, blob_w, blob_b, out, src_mod,
-                       list, list_count, nullptr);
+    LSDM_NP(np, hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, NPK>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, S, 0LL, blob_w, blob_b, out, src_mod,
+                                   list, list_count, nullptr));
 }
 
-void launch_sa_u(int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
+void launch_sa_u(int np, int level, int nc, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod) {
     if (level == 3) {
-        hipLaunchKernelGGL((sa_w_kernel<2>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, nullptr, nullptr);
+        LSDM_NP(np, hipLaunchKernelGGL((sa_w_kernel<NPK>), dim3(256), dim3(256), 0, st, U, V, cent_idx, ball, (long long)nc * 16, blob_w, blob_b, out, nullptr, nullptr));
     } else if (level == 1) {
         const long long tot = (long long)nc * 256;
         // (two work-groups per CU = four waves per SIMD; three per CU measured the same, 305 vs 307 us, one per CU 325: the kernel is
         // issue-bound -- MFMA and VALU time add -- not latency-bound)
-        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out, src_mod,
-                           nullptr, nullptr, nullptr);
+        LSDM_NP(np, hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, NPK>), dim3(512), dim3(512), 0, st, U, V, cent_idx, ball, remap, 1024, 256, tot, blob_w, blob_b, out, src_mod,
+                                       nullptr, nullptr, nullptr));
     } else if (level == 2) {
         const long long tot = (long long)nc * 64;
-        hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out, nullptr,
-                           nullptr);
+        LSDM_NP(np, hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, NPK>), dim3(256), dim3(12 * 64), 0, st, U, V, cent_idx, ball, 256, 64, tot, blob_w, blob_b, out, nullptr,
+                                       nullptr));
     }
 }
 
 // sa2 (level 1: the memo's pass over the source points) / sa3 / sa4 over the item list of launch_sa_pair_plan (geometry.hip): rows = 32 U rows per
 // item, meta = {V rows, output rows}, *count items
-void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
+void launch_sa_u_items(int np, int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
                        const float* blob_b, float* out, hipStream_t st) {
     if (level == 1)
-        hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, 2, true>), dim3(512), dim3(512), 0, st, U, V, nullptr, rows, nullptr, 1024, 1024, 0LL, blob_w, blob_b, out, 0,
-                           nullptr, count, meta);
+        LSDM_NP(np, hipLaunchKernelGGL((sa_ur_kernel<64, 64, 128, 8, NPK, true>), dim3(512), dim3(512), 0, st, U, V, nullptr, rows, nullptr, 1024, 1024, 0LL, blob_w, blob_b, out, 0,
+                                       nullptr, count, meta));
     else if (level == 3)
-        hipLaunchKernelGGL((sa_w_kernel<2, true>), dim3(256), dim3(256), 0, st, U, V, nullptr, rows, 0LL, blob_w, blob_b, out, meta, count);
+        LSDM_NP(np, hipLaunchKernelGGL((sa_w_kernel<NPK, true>), dim3(256), dim3(256), 0, st, U, V, nullptr, rows, 0LL, blob_w, blob_b, out, meta, count));
     else
-        hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, 2, true>), dim3(256), dim3(12 * 64), 0, st, U, V, nullptr, rows, 256, 64, 0LL, blob_w, blob_b, out, meta,
-                           count);
+        LSDM_NP(np, hipLaunchKernelGGL((sa_p_kernel<128, 128, 256, 12, NPK, true>), dim3(256), dim3(12 * 64), 0, st, U, V, nullptr, rows, 256, 64, 0LL, blob_w, blob_b, out, meta,
+                                       count));
 }
 
 }  // namespace lsdm

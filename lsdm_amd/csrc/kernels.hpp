@@ -103,12 +103,7 @@ void launch_fp_h(int np, int which, int num_clouds, const void* points1, const v
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
 // y = coarse-level FP output x Wb^T (the pre-multiplied interpolation operand of the next finer FP stage), R rows of 256 channels
-void launch_fp_y(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
-void launch_fp_y512(int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
-// fp3 (which = 3) / fp4 (4) as one register-chained stack per 32 points (encoder_w.hip): y = the stage's pre-multiplied interpolation operand,
-// out = the stage's output rows or NULL, ynext = the next finer stage's pre-multiplied operand
-void launch_fp_w(int which, int num_clouds, const float* points1, const float* y, const int* nn_idx, const float* nn_w, const __bf16* blob_w,
-                 const float* blob_b, float* out, float* ynext, int num_cus, hipStream_t st);
+void launch_fp_y(int np, int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
 // fp1 + head as one register-chained stack (bf16x3), a pipeline of stages with register-resident weights (encoder_d.hip: fp_c_kernel):
 // points2 (nc,1024,128) fp32, out (nc,1024,3)
 // order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
@@ -117,15 +112,15 @@ void launch_fp_c(int num_clouds, const float* points2, const int* nn_idx, const 
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
 // point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
 // ReLU(U_j - V_i).  remap (level 1 only, optional): U / V rows are in SOURCE order and position i of a cloud is row remap[i].
-void launch_lin_u(int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
+void launch_lin_u(int np, int level, int R, const float* X, const float* xyz, DenseH W, const float* wx, float* U, float* V, hipStream_t st);
 // src_mod > 0 (level 1 with remap, a launch over the clouds of several steps): U / V are per-CALL tensors, those of cloud c % src_mod
 // memo of sa2 (geometry.hip): per call the uncrowded source points (flags + list), per group the copies / the crowded centroids' list
 void launch_memo_src(const int* ball2, long long total, unsigned char* unc, int* list, int* count, hipStream_t st);
 void launch_memo_cent(int clouds, const int* idx0, const int* idx1, const unsigned char* unc, const float* F2, int nc1, float* out, int* list, int* count,
                       unsigned char* crowd, hipStream_t st);
-void launch_sa_u_list(int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
+void launch_sa_u_list(int np, int S, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap, const __bf16* blob_w,
                       const float* blob_b, float* out, hipStream_t st, int src_mod, const int* list, const int* list_count);
-void launch_sa_u(int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
+void launch_sa_u(int np, int level, int num_clouds, const float* U, const float* V, const int* cent_idx, const int* ball, const int* remap,
                  const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st, int src_mod = 0);
 // sa3 / sa4 over ITEM lists (two ball-query groups whose distinct neighbours fit into 32 rows together share a block; geometry.hip: sa_pair_kernel):
 //   launch_sa_pair_plan: `segs` segments of T1 = clouds x S centroids each (ball (segs*T1, 32), cent_idx (segs*T1)) -> rows (segs*T1, 32),
@@ -141,13 +136,13 @@ void launch_sa_pair_plan(int segs, int T1, int S, int NSRC, const int* ball, con
                          hipStream_t st, const unsigned char* only = nullptr);
 void launch_sa_r_items(const float* src_xyz, const int* rows, const int4* meta, const int* count, const __bf16* blob_w, const float* blob_b, float* out,
                        hipStream_t st);      // sa1 (register-chained kernel, first layer included)
-void launch_sa_u_items(int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
+void launch_sa_u_items(int np, int level, const float* U, const float* V, const int* rows, const int4* meta, const int* count, const __bf16* blob_w,
                        const float* blob_b, float* out, hipStream_t st);
 // fp2 / fp3 with the interpolated operand pre-multiplied at the coarse level (encoder_u.hip)
 // p1_remap (optional): row i of a cloud's points1 is points1[p1_remap[i]]
 // y_ready: ybuf was written by the coarser stage's fused extra layer; wb_next / ynext (which = 3, optional): this launch also writes
 // fp2's pre-multiplied operand ynext = out x wb_next^T, and stores `out` itself only when keep_out (parity taps)
-void launch_fp_pre(int which, int num_clouds, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
+void launch_fp_pre(int np, int which, int num_clouds, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
                    bool keep_out, hipStream_t st, int p1_mod = 0,      // p1_mod > 0 (with p1_remap): points1 is a per-CALL tensor, cloud c % p1_mod
                    const int* plan = nullptr);

@@ -221,9 +221,9 @@ def test_scene_encoder_vs_oracle_and_golden(model13, sd13, golden):
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 0.6)])
 def test_scene_encoder_split_bf16_levels_vs_oracle_and_golden(sd13, golden, precision, tol):
-    """Every level of the encoder on the split-bf16 core -- register-chained sa1/sa2 (weights resident in LDS), streamed
-    sa3, LDS-tiled sa4 / FP stages -- against the oracle's taps and the reference's recorded output (G3, incl. the
-    all-zero cloud)."""
+    """Every level of the encoder on the split-bf16 core (bf16x3: three matrix instructions per product; bf16: one, through the same
+    kernels -- sa1, fp2 and fp1 + head keep two planes there) against the oracle's taps and the reference's recorded output (G3, incl.
+    the all-zero cloud)."""
     g = golden("g3_pointnet")
     clouds = T(g["clouds"])
     starts = [s.long() for s in T(g["starts"])]
@@ -238,13 +238,12 @@ def test_scene_encoder_split_bf16_levels_vs_oracle_and_golden(sd13, golden, prec
     d_clouds, d_starts = clouds.to(DEV).contiguous(), torch.stack(starts).to(DEV).contiguous()
     m._ctx.call("lsdm_scene_encoder", d_clouds.data_ptr(), d_starts.data_ptr(), nc, out.data_ptr(), None)
     torch.cuda.synchronize()
-    bf = precision == "bf16"
     C_, S = (64, 128, 256, 512), (1024, 256, 64, 16)
-    for l in range(4):
-        got = ws(m, ("feat_bf%d" if bf else "feat%d") % (l + 1), (nc, S[l], C_[l]), torch.bfloat16 if bf else torch.float32).float()
+    for l in range(4):          # (level features and FP outputs are fp32 tensors in both modes; plain bf16 = single-plane products)
+        got = ws(m, "feat%d" % (l + 1), (nc, S[l], C_[l]))
         assert maxabs(got, taps["sa%d.new_points" % (l + 1)]) <= tol, "sa%d" % (l + 1)
     for name, shape in (("fp4", (nc, 64, 256)), ("fp3", (nc, 256, 256)), ("fp2", (nc, 1024, 128))):
-        got = ws(m, name + ("_bf" if bf else ""), shape, torch.bfloat16 if bf else torch.float32).float()
+        got = ws(m, name, shape)
         assert maxabs(got, taps[name + ".out"]) <= tol, name
     assert maxabs(out, ref) <= tol
     assert maxabs(out, T(g["out"])) <= tol   # the real reference's output
@@ -629,9 +628,8 @@ def test_split_bf16_precisions_vs_oracle_and_reference_golden(golden, precision,
     for l, S_ in enumerate((1024, 256, 64, 16)):
         assert torch.equal(ws(m, "fps_idx%d" % (l + 1), (nc, S_), torch.int32).long(), taps["sa%d.fps_idx" % (l + 1)])
         assert torch.equal(ws(m, "ball%d" % (l + 1), (nc, S_, 32), torch.int32).long(), taps["sa%d.ball_idx" % (l + 1)])
-    if precision == "bf16x3":   # fp32 feature tensors
-        assert maxabs(ws(m, "feat4", (nc, 16, 512)), taps["sa4.new_points"]) <= tol_feat
-        assert maxabs(ws(m, "fp2", (nc, 1024, 128)), taps["fp2.out"]) <= tol_feat
+    assert maxabs(ws(m, "feat4", (nc, 16, 512)), taps["sa4.new_points"]) <= tol_feat
+    assert maxabs(ws(m, "fp2", (nc, 1024, 128)), taps["fp2.out"]) <= tol_feat
     assert maxabs(ws(m, "pcd", (3, 9, 3072)), taps["pcd"]) <= tol_feat
     assert maxabs(out_cat, cat_o) <= 1e-6
     assert maxabs(x, x_ref) <= tol_out and maxabs(out, out_o) <= tol_out
