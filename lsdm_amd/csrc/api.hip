@@ -45,16 +45,12 @@ struct lsdm_ctx {
     Dense sa[4][3], fp[4][3], head[2];  // fp index 0..3 = fp4, fp3, fp2, fp1
     int prec = LSDM_PREC_F32;           // arithmetic of the dense layers (lsdm_set_precision)
     DenseH sa_h[4][3], fp_h[4][3], head_h[2];   // head_h[1]: conv2 (3 x 128) zero-padded to one 32-channel block  // split-bf16 operands of the same layers (prec != F32)
-    // SA levels 0..sa_reg-1 use the register-chained kernels (encoder_reg.hip), the rest the LDS-tiled sa_h_kernel;
-    // LSDM_SA_REG=0..3 is an A/B switch for measurements (sa4 and the FP stages were measured slower in the chained form)
-    int sa_reg = getenv("LSDM_SA_REG") ? (atoi(getenv("LSDM_SA_REG")) < 3 ? atoi(getenv("LSDM_SA_REG")) : 3) : 3;
     DenseH sa_r[3];                     // sa1..sa3 as fragment blobs of the register-chained kernels (encoder_reg.hip)
     // First SA layer split across the grouping (encoder_u.hip, bf16x3): per level i (0: sa3, 1: sa4) the feature columns of
     // the first layer (+ bias) for the row-wise kernel, its xyz columns (C1 x 3, fp32), the fragment blob of layers 2-3, and
     // the per-source-point tensors U = Wf f + Wx x + b, V = Wx x
     DenseH sa_uw[3], sa_ub[3];   // [0] sa3, [1] sa4, [2] sa2
     DenseH fp1_s{};              // fp1 + head as a register-chained blob (encoder_d.hip::fp_c_kernel)
-    int fuse_y = getenv("LSDM_FUSE_Y") ? atoi(getenv("LSDM_FUSE_Y")) : 1;      // A/B switch: fp2's Y as an extra layer of the fp3 launch
     bool keep_taps = true;       // stage outputs that only feed a fused consumer (fp3) are still stored: off inside multi-step calls
     int fp1_reg = getenv("LSDM_FP1_REG") ? atoi(getenv("LSDM_FP1_REG")) : 1;   // A/B switch
     DenseH den_r{};              // the per-point denoiser as a register-chained blob (denoise_reg.hip)
@@ -74,11 +70,14 @@ struct lsdm_ctx {
     int* inv_order = nullptr;    // Morton order of the SOURCE clouds, once per call (loop-invariant schedule)
     int sa_pair = getenv("LSDM_SA_PAIR") ? atoi(getenv("LSDM_SA_PAIR")) : 1;         // A/B switch: 0 = every ball-query group gets a 32-row block of its own; 2 = item lists for single steps of any batch
     int fp1_order = getenv("LSDM_FP1_ORDER") ? atoi(getenv("LSDM_FP1_ORDER")) : 1;   // A/B switch: fp1 + head walks the source points along that order
-    int fp4_pre = getenv("LSDM_FP4_PRE") ? atoi(getenv("LSDM_FP4_PRE")) : 1;   // A/B switch: fp4 in the pre-multiplied form as well
-    int fp_pre = getenv("LSDM_FP_PRE") ? atoi(getenv("LSDM_FP_PRE")) : 2;   // A/B switch: 0 none, 1 fp2, 2 fp2 + fp3
+    // A/B switch: 0 = fp4 / fp3 / fp2 on the LDS-tiled reference form (fp_h_kernel, the whole concatenated first layer per fine point); default: the
+    // interpolated operand pre-multiplied at the coarse level, each stage writing the next finer stage's Y as one more layer on its rows
+    bool fp_pre = !(getenv("LSDM_FP_PRE") && atoi(getenv("LSDM_FP_PRE")) == 0);
     const float* sa_wx[3] = {};
     float *sa_U[3] = {}, *sa_V[3] = {};
-    int sa_split = getenv("LSDM_SA_SPLIT") ? atoi(getenv("LSDM_SA_SPLIT")) : 3;   // A/B switch: 1 sa3, 2 + sa4, 3 + sa2
+    // A/B switch: 0 = sa2 / sa3 / sa4 on the reference forms with the whole first layer per grouped row (sa_r_kernel, sa_s_kernel, sa_h_kernel); default:
+    // the first layer split across the grouping (U / V per source point)
+    bool sa_split = !(getenv("LSDM_SA_SPLIT") && atoi(getenv("LSDM_SA_SPLIT")) == 0);
     CondParams cond{};
     PosaParams posa{};
     SceneAttnParams sattn{};
@@ -190,7 +189,6 @@ struct lsdm_ctx {
     int batch_enc = getenv("LSDM_BATCH_ENC") ? atoi(getenv("LSDM_BATCH_ENC")) : 1;   // A/B switch: 0 = the dense encoder stages one step at a time
     int sa2_memo = getenv("LSDM_SA2_MEMO") ? atoi(getenv("LSDM_SA2_MEMO")) : 1;      // A/B switch: 0 = every sa2 centroid through the stage every step
     bool memo_ready = false;                  // this call's F2 / flags are in place (set by the per-call block, read by the groups)
-    int inv_side = getenv("LSDM_INV_SIDE") ? atoi(getenv("LSDM_INV_SIDE")) : 1;      // A/B switch: 0 = the per-call level-1 work on the caller's stream
     int batch_den = getenv("LSDM_BATCH_DEN") ? atoi(getenv("LSDM_BATCH_DEN")) : 1;   // A/B switch: 0 = scene attention + denoiser one launch per step
     size_t prof_cur = 0;
     double prof_exec[64] = {0};                      // executed MACs per stage id over the profiled window (prof_exec())
@@ -649,7 +647,7 @@ void run_geometry(lsdm_ctx* c, FrontSet& f, const float* clouds, const int64_t* 
 // skip_sa1 (loop-invariant schedule): level 1 comes from the call's invariants.  In bf16x3 with the split sa2 / fp2 layers the
 // invariants stay in SOURCE order (inv_F1, sa_U[2] / sa_V[2]) and are read through the step's FPS order f.idx[0]; otherwise
 // l1_remap_kernel has re-ordered the feature rows into feat[0].
-bool inv_in_source_order(const lsdm_ctx* c) { return c->prec != LSDM_PREC_F32 && c->sa_split >= 3 && c->sa_reg > 1 && c->fp_pre >= 1; }
+bool inv_in_source_order(const lsdm_ctx* c) { return c->prec != LSDM_PREC_F32 && c->sa_split && c->fp_pre; }
 
 void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int nc, float* out, hipStream_t st, bool skip_sa1 = false) {
     const float* lvl_xyz[5] = {clouds, f.xyz[0], f.xyz[1], f.xyz[2], f.xyz[3]};
@@ -682,7 +680,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     // (a single step pays two planner launches for its lists: measured break-even around 4 chains -- strict schedule 2262 vs 2269 steps/s at
     // B = 4, 1790 vs 1705 at B = 8, 1177 vs 1099 at B = 16, 400 vs 361 at B = 64; LSDM_SA_PAIR=2 forces them at any size)
     const bool on = c->sa_pair && (nc >= 54 || c->sa_pair > 1);
-    const bool items[4] = {on && !skip_sa1 && c->sa_reg > 0 && fits1, on && c->sa_split >= 3 && c->sa_reg > 1 && !src1, on && c->sa_split >= 1, on && c->sa_split >= 2};
+    const bool items[4] = {on && !skip_sa1 && fits1, on && c->sa_split && !src1, on && c->sa_split, on && c->sa_split};
     {
         const int S_[4] = {1024, 256, 64, 16}, N_[4] = {1024, 1024, 256, 64};
         PairLevel lv[4];
@@ -704,7 +702,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         if (l == 0 && items[0]) {
             launch_sa_r_items(clouds, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, c->feat[0], st);
             prof_exec(c, K_SA1, c->step_host[0] * xm::SA1_ITEM);
-        } else if (l == 1 && c->sa_split >= 3 && c->sa_reg > 1) {
+        } else if (l == 1 && c->sa_split) {
             // sa2: U, V per level-1 point -- per step in FPS order, or (loop-invariant schedule) once per call in source order
             const bool src = src1;
             if (!src) launch_lin_u(np, 1, nc * 1024, c->feat[0], lvl_xyz[1], c->sa_uw[2], c->sa_wx[2], c->sa_U[2], c->sa_V[2], st);
@@ -715,7 +713,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
                 launch_sa_u(np, 1, nc, c->sa_U[2], c->sa_V[2], f.idx[1], f.ball[1], src ? f.idx[0] : nullptr, c->sa_ub[2].w, c->sa_ub[2].b, c->feat[1], st);
                 prof_exec(c, K_SA1 + 1, nc * ((src ? 0.0 : xm::SA2_UV) + 256 * xm::SA2_CENT));
             }
-        } else if (l == 2 && c->sa_split >= 1) {
+        } else if (l == 2 && c->sa_split) {
             // first layer split across the grouping: U, V per level-2 point, then the two remaining layers on ReLU(U_j - V_i)
             launch_lin_u(np, 2, nc * 256, c->feat[1], lvl_xyz[2], c->sa_uw[0], c->sa_wx[0], c->sa_U[0], c->sa_V[0], st);
             if (items[2]) {
@@ -725,7 +723,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
                 launch_sa_u(np, 2, nc, c->sa_U[0], c->sa_V[0], f.idx[2], f.ball[2], nullptr, c->sa_ub[0].w, c->sa_ub[0].b, c->feat[2], st);
                 prof_exec(c, K_SA1 + 2, nc * xm::SA3);
             }
-        } else if (l == 3 && c->sa_split >= 2) {
+        } else if (l == 3 && c->sa_split) {
             launch_lin_u(np, 3, nc * 64, c->feat[2], lvl_xyz[3], c->sa_uw[1], c->sa_wx[1], c->sa_U[1], c->sa_V[1], st);
             if (items[3]) {
                 launch_sa_u_items(np, 3, c->sa_U[1], c->sa_V[1], c->step_rows[3], c->step_meta[3], c->step_cnt + 3, c->sa_ub[1].w, c->sa_ub[1].b, c->feat[3], st);
@@ -735,12 +733,12 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
                 prof_exec(c, K_SA1 + 3, nc * xm::SA4);
             }
         } else {
-            // the reference forms of the bf16x3 build (LSDM_SA_SPLIT / LSDM_SA_REG), and sa1 of a small batch (two planes in every mode)
-            const int npl = l == 0 ? 2 : np;
-            if (l < c->sa_reg)
-                launch_sa_r(npl, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
+            // the reference forms of the bf16x3 build (LSDM_SA_SPLIT=0: the whole stack per grouped row -- register-chained sa1 / sa2, streamed sa3,
+            // LDS-tiled sa4), and sa1 of a small batch (two planes in every mode)
+            if (l < 3)
+                launch_sa_r(2, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_r[l].w, c->sa_r[l].b, feat[l], st);
             else
-                launch_sa_h(npl, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
+                launch_sa_h(2, l, nc, lvl_xyz[l], lvl_feat[l], lvl_xyz[l + 1], f.ball[l], c->sa_h[l], feat[l], st);
             const double full[4] = {xm::SA1, xm::SA2_FULL, xm::SA3_FULL, xm::SA4_FULL};
             prof_exec(c, K_SA1 + l, nc * full[l]);
         }
@@ -749,24 +747,17 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
     prof_mark(c, K_FP4, st);
     // fp4 / fp3 also write the next finer stage's pre-multiplied interpolation operand (one more layer on their rows) when that stage
     // takes the pre-multiplied form
-    const bool fuse_y = c->fp_pre >= 2 && c->fuse_y;
-    if (fuse_y && c->fp4_pre)
-        // fp4 in the pre-multiplied form too: Y4 = feat4 x Wb^T on the 16 coarse points of a cloud, the matrix pipe then contracts over the
-        // 256 columns of points1 only (K = 256 instead of 768: a third of the fragments every 64-row tile streams from L2)
+    if (c->fp_pre) {
+        // fp4: Y4 = feat4 x Wb^T on the 16 coarse points of a cloud, the matrix pipe then contracts over the 256 columns of points1 only (K = 256
+        // instead of 768: a third of the fragments every 64-row tile streams from L2); it writes fp3's Y, fp3 writes fp2's
         launch_fp_pre(np, 4, nc, c->feat[2], nullptr, c->feat[3], c->fp_y[2], c->fp_ybuf[2], f.nn_idx[0], f.nn_w[0], c->fp_a[2], c->fp_h[0][1], c->fpo4, false,
                       c->fp_y[0], c->fp_ybuf[0], c->keep_taps, st);
-    else if (fuse_y) launch_fp4_y(nc, c->feat[2], c->feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], c->fp_y[0], c->fpo4, c->fp_ybuf[0], c->keep_taps, st);
-    else launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, c->fpo4, st);
-    prof_exec(c, K_FP4, nc * (fuse_y && c->fp4_pre ? xm::FP4_PRE : (fuse_y ? xm::FP4_Y : xm::FP4_FULL)));
-    prof_mark(c, K_FP3, st);
-    if (c->fp_pre >= 2)
-        launch_fp_pre(np, 3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, fuse_y,
-                      c->fp_y[1], fuse_y ? c->fp_ybuf[1] : nullptr, c->keep_taps, st);
-    else
-        launch_fp_h(np, 3, nc, feat[1], c->fpo4, f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, c->fpo3, st);
-    prof_exec(c, K_FP3, nc * (c->fp_pre >= 2 ? xm::FP3_PRE + (fuse_y ? xm::FP3_NEXT_Y : xm::FP3_OWN_Y) : xm::FP3_FULL));
-    prof_mark(c, K_FP2, st);
-    if (c->fp_pre >= 1) {
+        prof_exec(c, K_FP4, nc * xm::FP4_PRE);
+        prof_mark(c, K_FP3, st);
+        launch_fp_pre(np, 3, nc, c->feat[1], nullptr, c->fpo4, c->fp_y[0], c->fp_ybuf[0], f.nn_idx[1], f.nn_w[1], c->fp_a[0], c->fp_h[1][1], c->fpo3, true,
+                      c->fp_y[1], c->fp_ybuf[1], c->keep_taps, st);
+        prof_exec(c, K_FP3, nc * (xm::FP3_PRE + xm::FP3_NEXT_Y));
+        prof_mark(c, K_FP2, st);
         const bool src = skip_sa1 && inv_in_source_order(c);   // level-1 features in source order, read through f.idx[0]
         const float* p1 = src ? static_cast<const float*>(c->inv_F1) : c->feat[0];
         const int* remap = src ? f.idx[0] : nullptr;
@@ -776,11 +767,19 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
             launch_morton_order(nc, f.xyz[0], c->fp2_order, st);
             launch_fp_plan(nc, c->fp2_order, 0, nullptr, f.nn_idx[2], remap, c->fp2_plan, st);
         }
-        launch_fp_pre(np, 2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, fuse_y,
+        launch_fp_pre(np, 2, nc, p1, remap, c->fpo3, c->fp_y[1], c->fp_ybuf[1], f.nn_idx[2], f.nn_w[2], c->fp_a[1], c->fp_h[2][1], c->fpo2, true,
                       DenseH{nullptr, nullptr}, nullptr, true, st, 0, planned ? c->fp2_plan : nullptr);
-    } else
+        prof_exec(c, K_FP2, nc * xm::FP2_PRE);
+    } else {
+        launch_fp_h(np, 4, nc, feat[2], feat[3], f.nn_idx[0], f.nn_w[0], c->fp_h[0], nullptr, head2, c->fpo4, st);
+        prof_exec(c, K_FP4, nc * xm::FP4_FULL);
+        prof_mark(c, K_FP3, st);
+        launch_fp_h(np, 3, nc, feat[1], c->fpo4, f.nn_idx[1], f.nn_w[1], c->fp_h[1], nullptr, head2, c->fpo3, st);
+        prof_exec(c, K_FP3, nc * xm::FP3_FULL);
+        prof_mark(c, K_FP2, st);
         launch_fp_h(np, 2, nc, feat[0], c->fpo3, f.nn_idx[2], f.nn_w[2], c->fp_h[2], nullptr, head2, c->fpo2, st);
-    prof_exec(c, K_FP2, nc * (c->fp_pre >= 1 ? xm::FP2_PRE + (fuse_y ? 0.0 : xm::FP2_OWN_Y) : xm::FP2_FULL));
+        prof_exec(c, K_FP2, nc * xm::FP2_FULL);
+    }
     prof_mark(c, K_FP1, st);
     if (c->fp1_reg) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
     else launch_fp_h(np, 1, nc, nullptr, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
@@ -798,7 +797,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
 // with the per-call invariants (inv_F1, sa2's U / V in source order) read modulo the clouds of one step and the level features of the
 // group in c->gws.  Same kernels, same per-cloud arithmetic: bit-identical to the step-by-step form (LSDM_BATCH_ENC=0).
 bool group_batched(const lsdm_ctx* c) {
-    return c->batch_enc && inv_in_source_order(c) && c->sa_split >= 3 && c->sa_reg >= 3 && c->fp_pre >= 2 && c->fuse_y && c->fp4_pre && c->fp1_reg;
+    return c->batch_enc && inv_in_source_order(c) && c->fp1_reg;
 }
 
 bool ensure_group_ws(lsdm_ctx* c, int B) {
@@ -1274,7 +1273,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
         // conditioning and the denoiser -- except three stages whose kernels exist in the two-plane form only and keep the split arithmetic there:
         // sa1 (once per call), fp2 (fp_d_kernel) and fp1 + head (fp_c_kernel: weights register-resident as hi + lo fragment pairs).
         if (np == 1) {      // the A/B switches select reference forms of the bf16x3 build; plain bf16 always takes the default family
-            c->sa_split = 3; c->sa_reg = 3; c->fp_pre = 2; c->fuse_y = 1; c->fp4_pre = 1; c->fp1_reg = 1;
+            c->sa_split = true; c->fp_pre = true; c->fp1_reg = 1;
             const std::string p2 = "pcd_backbone.fp2";
             ok = ok && load_dense_h(c, p2 + ".mlp_convs.1.weight", p2 + ".mlp_convs.1.bias", p2 + ".mlp_bns.1", 128, 256, 2, {}, &c->fp_h[2][1]);
         }
@@ -1718,7 +1717,7 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
         // other's results); the caller's stream waits for it before the first stage that does (inv_pending).
         if (K > 1 && group_batched(c) && !ensure_group_ws(c, B)) return LSDM_ERR_HIP;
         hipStream_t si = st;
-        if (K > 1 && group_batched(c) && lanes(c) > 1 && c->inv_side) {
+        if (K > 1 && group_batched(c) && lanes(c) > 1) {
             stream_fork(c, st);
             si = c->side[0];
         }
@@ -1731,15 +1730,14 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
             const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
-            const bool items1 = c->sa_reg > 0 && c->sa_pair && (long long)nc * kN < kItemRowLimit;
+            const bool items1 = c->sa_pair && (long long)nc * kN < kItemRowLimit;
             if (!items1) prof_exec(c, K_SA1, nc * xm::SA1);
             if (items1) {
                 // (r = 0.1: seven distinct neighbours per group on the bench clouds -- half the blocks)
                 launch_sa_pair_plan(1, nc * kN, kN, kN, c->inv_ball, nullptr, c->step_chunk[0], c->step_rows[0], c->step_meta[0], c->step_cnt, si);
                 launch_sa_r_items(enc_clouds, c->step_rows[0], c->step_meta[0], c->step_cnt, c->sa_r[0].w, c->sa_r[0].b, static_cast<float*>(c->inv_F1), si);
                 prof_exec_dev(c, K_SA1, c->step_cnt, xm::SA1_ITEM, si);
-            } else if (c->sa_reg > 0) launch_sa_r(2, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);      // (sa1: two planes in every mode)
-            else launch_sa_h(np, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_h[0], c->inv_F1, si);
+            } else launch_sa_r(2, 0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa_r[0].w, c->sa_r[0].b, c->inv_F1, si);      // (sa1: two planes in every mode)
         }
         const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;      // (used by the split-bf16 branches below only)
         if (inv_in_source_order(c))   // sa2's split first layer per SOURCE point (rows of sa_U[2] / sa_V[2] are read through f.idx[0])

@@ -435,13 +435,7 @@ static void launch_sa_h_t(int level, int nc, const float* src_xyz, const void* s
     typedef typename FeatT<NP>::type F;
     const F* sf = static_cast<const F*>(src_feat);
     F* o = static_cast<F*>(out);
-    switch (level) {
-        case 0: hipLaunchKernelGGL((sa_h_kernel<3, 32, 32, 64, 128, 4, NP>), dim3(1024 / 4 * nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
-                                   ball, 1024, 1024, l[0], l[1], l[2], o); break;
-        case 1: hipLaunchKernelGGL((sa_h_kernel<64, 64, 64, 128, 128, 4, NP>), dim3(256 / 4 * nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
-                                   ball, 1024, 256, l[0], l[1], l[2], o); break;
-        case 2: hipLaunchKernelGGL((sa_h_kernel<128, 128, 128, 256, 64, 4, NP>), dim3(64 / 2 * nc), dim3(256), 0, st, src_xyz, sf, new_xyz,
-                                   ball, 256, 64, l[0], l[1], l[2], o); break;
+    switch (level) {      // (the reference form is kept for sa4 only: sa1 / sa2 / sa3 have register-chained ones, encoder_reg.hip)
         case 3: hipLaunchKernelGGL((sa_h_kernel<256, 256, 256, 512, 64, 8, NP>), dim3(16 / 2 * nc), dim3(512), 0, st, src_xyz, sf, new_xyz,
                                    ball, 64, 16, l[0], l[1], l[2], o); break;
     }
@@ -467,27 +461,16 @@ static void launch_fp_h_t(int which, int nc, const void* points1, const void* po
     }
 }
 
-// fp4 (bf16x3) that also writes fp3's pre-multiplied interpolation operand ynext = out x wb^T; out is stored only when keep_out
-void launch_fp4_y(int nc, const float* points1, const float* points2, const int* nn_idx, const float* nn_w, const DenseH* l, DenseH wb,
-                  float* out, float* ynext, bool keep_out, hipStream_t st) {
-    const DenseH none{nullptr, nullptr};
-    const Lin nol{nullptr, nullptr};
-    // (32-row tiles -- 1152 work-groups instead of 576 on 512 resident slots -- were measured slower, 130 vs 111 us: every tile streams
-    // the stage's 1.3 MB of fragments from L2, and that stream, not the second half-empty round, sets the pace)
-    hipLaunchKernelGGL((fp_h_kernel<256, 512, 256, 256, 0, false, 64, 128, 4, 2, 1, true>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, points2, nn_idx, nn_w,
-                       64, 16, l[0], l[1], wb, none, nol, none, out, ynext, keep_out ? 1 : 0);
-}
-
 void launch_sa_h(int np, int level, int nc, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const DenseH* l, void* out, hipStream_t st) {
-    if (np == 2) launch_sa_h_t<2>(level, nc, src_xyz, src_feat, new_xyz, ball, l, out, st);
-    else launch_sa_h_t<1>(level, nc, src_xyz, src_feat, new_xyz, ball, l, out, st);
+    (void)np;      // (the LDS-tiled reference forms exist for two planes: plain bf16 never reaches them, api.hip)
+    launch_sa_h_t<2>(level, nc, src_xyz, src_feat, new_xyz, ball, l, out, st);
 }
 
 void launch_fp_h(int np, int which, int nc, const void* points1, const void* points2, const int* nn_idx, const float* nn_w,
                  const DenseH* l, const DenseH* head1, Lin head2, void* out, hipStream_t st) {
-    if (np == 2) launch_fp_h_t<2>(which, nc, points1, points2, nn_idx, nn_w, l, head1, head2, out, st);
-    else launch_fp_h_t<1>(which, nc, points1, points2, nn_idx, nn_w, l, head1, head2, out, st);
+    (void)np;
+    launch_fp_h_t<2>(which, nc, points1, points2, nn_idx, nn_w, l, head1, head2, out, st);
 }
 
 }  // namespace lsdm

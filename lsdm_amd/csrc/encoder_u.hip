@@ -1018,12 +1018,6 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
 // instructions per product), 1 = plain bf16 (one).  Level features, U / V and Y are fp32 in HBM in both.
 #define LSDM_NP(np, ...) do { if ((np) == 2) { constexpr int NPK = 2; __VA_ARGS__; } else { constexpr int NPK = 1; __VA_ARGS__; } } while (0)
 
-// which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64);  which = 3: fp3 (256 <- 64, D1 = 128)
-// Y = coarse-level FP output x Wb^T, R = num_clouds * S rows of 256 channels
-void launch_fp_y(int np, int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st) {
-    LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<256, 256, false, NPK>), dim3((R + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, R, wb, nullptr, ybuf, nullptr));
-}
-
 // LSDM_FP2_WS: fp2 on 4 = the two-stage persistent kernel over Morton-ordered tiles with deduplicated rows (fp_d_kernel, encoder_d.hip; the default),
 // 0 = the tile-per-work-group form (fp_pre_kernel: the reference form of the stage for the bit-equality tests).  Same results bit for bit.
 int fp2_ws() {
@@ -1031,8 +1025,10 @@ int fp2_ws() {
     return e ? (atoi(e) ? 4 : 0) : 4;
 }
 
-// y_ready: ybuf already holds Y (written by the coarser stage's fused extra layer).  wb_next / ynext (which = 3, 4; optional):
-// fuse the next finer stage's Y = out x wb_next^T into this launch; `out` itself is then stored only when keep_out.
+// which = 2: fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64); 3: fp3 (256 <- 64, D1 = 128); 4: fp4 (64 <- 16, D1 = 256).
+// ybuf: the stage's pre-multiplied operand Y = coarse output x Wb^T -- written by the coarser stage's launch (which = 2, 3: y_ready) or here from
+// fpo_coarse (which = 4).  wb_next / ynext (which = 3, 4): the next finer stage's Y = out x wb_next^T as one more layer of this launch; `out` itself is
+// then stored only when keep_out.
 // (fp2 -- which = 2 -- exists in the two-plane form only: fp_d_kernel / fp_pre_kernel<64, ...> take np = 2 operands in every mode.)
 void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
@@ -1046,7 +1042,7 @@ void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p
                                        l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0, p1_mod));
         return;
     }
-    if (!y_ready) launch_fp_y(which == 2 ? 2 : np, nc * S, fpo_coarse, wb, ybuf, st);
+    (void)y_ready; (void)S;
     if (which == 2 && plan) {
         launch_fp_d(nc, points1, ybuf, nn_w, l1a, l2, out, plan, st, p1_mod);
     }
@@ -1054,15 +1050,12 @@ void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p
         hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, 4>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
                            none, nullptr, 1, p1_mod);
     }
-    else if (ynext) {
+    else {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
         // each other's gather and barrier phases)
         LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 64, 4, NPK>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64,
                                        l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0, p1_mod));
     }
-    else
-        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, false, 64, 4, NPK>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64,
-                                       l1a, l2, out, none, nullptr, 1, p1_mod));
 }
 
 // ---------------------------------------------------------------------------------------------

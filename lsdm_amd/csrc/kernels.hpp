@@ -103,7 +103,6 @@ void launch_fp_h(int np, int which, int num_clouds, const void* points1, const v
 void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const void* src_feat, const float* new_xyz, const int* ball,
                  const __bf16* blob_w, const float* blob_b, void* out, hipStream_t st);
 // y = coarse-level FP output x Wb^T (the pre-multiplied interpolation operand of the next finer FP stage), R rows of 256 channels
-void launch_fp_y(int np, int R, const float* fpo_coarse, DenseH wb, float* ybuf, hipStream_t st);
 // fp1 + head as one register-chained stack (bf16x3), a pipeline of stages with register-resident weights (encoder_d.hip: fp_c_kernel):
 // points2 (nc,1024,128) fp32, out (nc,1024,3)
 // order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
@@ -191,9 +190,6 @@ void launch_denoise_h(int np, const DenoiseHParams& P, const StepCoefs& sc, int 
                       const float* mask, const float* pcd, const float* w, const float* o12, const float* hm, const void* h2t,
                       const float* ctext, const float* ctime, const float* noise, float* out_x0, float* out_guiding, float* out_sample, hipStream_t st);
 
-// encoder_bf.hip: fp4 with fp3's pre-multiplied interpolation operand as an extra layer (bf16x3)
-void launch_fp4_y(int nc, const float* points1, const float* points2, const int* nn_idx, const float* nn_w, const DenseH* l, DenseH wb,
-                  float* out, float* ynext, bool keep_out, hipStream_t st);
 // denoise_reg.hip: the same step as launch_denoise_h with the per-point denoiser register-chained (blob: api.hip::build_denoise_reg_blob);
 // ctime: (rows,1024,128) from launch_ctext(time_half), row = step (ctime_per_sample = 0) or step * B + sample; stash: B * 32 tiles of 24 KB
 void launch_denoise_r(int np, const DenseH& blob, const Lin& pwt, const StepCoefs& sc, int mode, float eta, int B, int nsteps, int ctime_per_sample,
