@@ -610,11 +610,19 @@ def main():
                                     "frac_executed": whole_ex / peak, "mfma_issue_frac": whole_ex * issue / peak,
                                     "executed_note": "sum of the matrix stages' executed products per step of the instrumented pass (once-per-call "
                                                      "work divided by the call's %d steps) x 2 FLOP / ms_per_step of the timed region" % K},
+                     # `tflops` = the stage's REFERENCE work / its time, listed only where the launches execute (nearly) that work; where the
+                     # schedule evaluates part of it once per call or not at all (the sa2 memo, sa1, the denoiser's shared rows, the split first
+                     # layers) the figure would exceed what the hardware can do and is left out: `tflops_executed` is the honest column there
                      "kernels": [{"name": q["name"], "launches": q["launches"], "avg_ms": round(q["avg_ms"], 4),
-                                  "ms_per_step": round(q["total_ms"] / K, 4), "tflops": round(q["tflops"], 2),
+                                  "ms_per_step": round(q["total_ms"] / K, 4),
+                                  "tflops": round(q["tflops"], 2) if q["ex_tflops"] >= 0.8 * q["tflops"] else None,
                                   "executed_gflop": round(q["ex_gflop_step"], 3), "tflops_executed": round(q["ex_tflops"], 2),
                                   "frac_executed": round(q["ex_tflops"] / peak, 4), "mfma_issue_frac": round(q["ex_tflops"] * issue / peak, 4)} for q in rows]},
     })
+    # no stage may claim more than the matrix pipe can issue (executed products x instructions per product <= peak), none more executed than
+    # reference work beyond the k-step padding of the narrow layers
+    # (recorded, not raised: the line must not be lost to a bookkeeping slip -- tests/test_hip_determinism.py asserts the list is empty)
+    res["roofline"]["guard_violations"] = [q["name"] for q in rows if q["ex_tflops"] * issue > peak or (q["gflop"] > 1.0 and q["ex_tflops"] > 1.15 * q["tflops"])]
     if a.precision == "bf16x3":
         # The other roof these stages touch: bytes a launch pulls through the CUs' fill path (gathered rows +
         # weight fragments / panels streamed per tile or round; per cloud, x 9 B clouds) / stage time, against what tools/ubench/gather2_bw.hip

@@ -781,7 +781,7 @@ void run_encoder_dense(lsdm_ctx* c, const FrontSet& f, const float* clouds, int 
         prof_exec(c, K_FP2, nc * xm::FP2_FULL);
     }
     prof_mark(c, K_FP1, st);
-    if (c->fp1_reg) launch_fp_c(nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
+    if (c->fp1_reg) launch_fp_c(np, nc, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp1_s.w, c->fp1_s.b, out, st);
     else launch_fp_h(np, 1, nc, nullptr, c->fpo2, f.nn_idx[3], f.nn_w[3], c->fp_h[3], c->head_h, head2, out, st);
     prof_exec(c, K_FP1, nc * xm::FP1);
 }
@@ -1001,7 +1001,7 @@ void run_encoder_group_step(lsdm_ctx* c, const FrontSet& fj, int B, int j, float
         prof_exec(c, K_FP2, ncp * xm::FP2_PRE);
         prof_mark(c, K_FP1, st);
         // (fp1's fine level is the source cloud: walked along the Z curve sorted once per call, LSDM_FP1_ORDER=0: in index order)
-        launch_fp_c(ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
+        launch_fp_c(np, ncp, fpo2, fj.nn_idx[3] + o * 1024 * 3, fj.nn_w[3] + o * 1024 * 3, c->fp1_s.w, c->fp1_s.b, pcd_out + o * kN * 3, st,
                                                   c->fp1_order ? c->inv_order + o * 1024 : nullptr, 0);
         prof_exec(c, K_FP1, ncp * xm::FP1);
     }
@@ -1269,13 +1269,10 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                 ok = c->head_h[1].w != nullptr;
             }
         }
-        // Plain bf16 (np = 1) runs the same kernel family as bf16x3 with single-plane operands -- lin_u (U / V, Y), sa2, sa3, sa4, fp4, fp3, the
-        // conditioning and the denoiser -- except three stages whose kernels exist in the two-plane form only and keep the split arithmetic there:
-        // sa1 (once per call), fp2 (fp_d_kernel) and fp1 + head (fp_c_kernel: weights register-resident as hi + lo fragment pairs).
+        // Plain bf16 (np = 1) runs the same kernel family as bf16x3 with single-plane operands and ONE matrix instruction per product; only sa1
+        // (once per call in the sampler loop) keeps two planes: its item-list kernel exists in that form only.
         if (np == 1) {      // the A/B switches select reference forms of the bf16x3 build; plain bf16 always takes the default family
             c->sa_split = true; c->fp_pre = true; c->fp1_reg = 1;
-            const std::string p2 = "pcd_backbone.fp2";
-            ok = ok && load_dense_h(c, p2 + ".mlp_convs.1.weight", p2 + ".mlp_convs.1.bias", p2 + ".mlp_bns.1", 128, 256, 2, {}, &c->fp_h[2][1]);
         }
         ok = ok && build_sa_reg_blob(c, "pcd_backbone.sa1", 3, sa_mlp[0], 2, &c->sa_r[0]) &&
              build_sa_reg_blob(c, "pcd_backbone.sa2", 64, sa_mlp[1], np, &c->sa_r[1]) &&
@@ -1333,7 +1330,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                                                   {pb + ".conv2.weight", pb + ".conv2.bias", "", 3, 128, 32}};
                 std::vector<int> ident(128);
                 for (int k = 0; k < 128; ++k) ident[k] = k;
-                ok = build_chain_blob(c, layers, ident, 2, &c->fp1_s);
+                ok = build_chain_blob(c, layers, ident, np, &c->fp1_s);
             }
             // fp3 / fp2: first layer ([points1 (D1) || interpolated coarse output (256)] -> 256) split at the concat boundary
             {
@@ -1350,8 +1347,7 @@ int lsdm_finalize_params(lsdm_ctx* c, int C) {
                         for (int k = 0; k < d1[i]; ++k) wa[(size_t)n * d1[i] + k] = Wf[(size_t)n * K + k];
                         for (int k = 0; k < d2[i]; ++k) wb[(size_t)n * d2[i] + k] = Wf[(size_t)n * K + d1[i] + k];
                     }
-                    // (i = 1, fp2: its first layer runs in fp_d_kernel, two planes in every mode; its Wb is the extra layer of fp3's launch)
-                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], i == 1 ? 2 : np, {}), pb = pack_weight_h(wb, 256, d2[i], np, {});
+                    std::vector<uint16_t> pa = pack_weight_h(wa, 256, d1[i], np, {}), pb = pack_weight_h(wb, 256, d2[i], np, {});
                     c->fp_a[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pa.data()), pa.size() / 2));
                     c->fp_a[i].b = upload(c, Bf.data(), Bf.size());
                     c->fp_y[i].w = reinterpret_cast<const __bf16*>(upload(c, reinterpret_cast<const float*>(pb.data()), pb.size() / 2));

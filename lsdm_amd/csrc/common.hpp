@@ -82,24 +82,10 @@ __device__ __forceinline__ unsigned lds_addr(const T* p) {
 //  * written as plain arithmetic (or with __fmul_rn / __fadd_rn, which do not stop contraction) hipcc fuses one of the products into an
 //    add, and WHICH one differs from call site to call site: two inlined copies of the same expression disagreed in the last bit (fp2's
 //    three kernels on the second tile of a persistent work-group, round 4);
-//  * left to itself hipcc packs the four values of a 16-byte piece into v_pk_mul_f32 / v_pk_fma_f32 with op_sel operand selection (the
-//    low lane takes the weight from the HIGH register of the pair).  In the gather waves of the wave-specialised kernels (fp_ws_kernel,
-//    fp_s_kernel: one gather and one MFMA wave per SIMD) these lost an update now and then: the first packed FMAs after the wave woke
-//    from a long s_waitcnt vmcnt(0) came out WITHOUT their b w1 term in the low lane of lanes 48..63 (tools/fp2_reveal.py makes the
-//    interpolated rows visible in fp2's output: got = a w0 + d w2 exactly).  88 of 100 forwards at B = 16 had a few such rows in fp2, 4
-//    of 400 in fp1; nothing else changes run to run.  With scalar instructions: 0 of 400 (tools/determinism_stress.py,
-//    tests/test_hip_determinism.py).  Same speed: the gather waves have VALU slots to spare.
-// LSDM_INTERP_PACKED (hazard experiments only, tools/pk_hazard_variants.sh -- needs a build WITHOUT the Makefile's -packed-fp32-ops):
-//   1  plain expression: hipcc packs it with SGPR weight pairs and op_sel (the failing form of round 4)
-//   2  the same with the weights first moved to VGPRs (no scalar operand, no cross operand selection in the packed instructions)
+//  * left to itself hipcc packed the four values of a 16-byte piece into v_pk_mul_f32 / v_pk_fma_f32 with op_sel operand selection, and in
+//    the gather waves of round 4's wave-specialised kernels (one gather and one MFMA wave per SIMD) those lost an update now and then
+//    (the library is now built without compiler-packed fp32 altogether, csrc/Makefile).
 __device__ __forceinline__ float interp3(float a, float b, float d, float w0, float w1, float w2) {
-#if defined(LSDM_INTERP_PACKED) && LSDM_INTERP_PACKED == 2
-    float v0 = w0, v1 = w1, v2 = w2;
-    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));
-    return __builtin_fmaf(d, v2, __builtin_fmaf(b, v1, a * v0));
-#elif defined(LSDM_INTERP_PACKED)
-    return __builtin_fmaf(d, w2, __builtin_fmaf(b, w1, a * w0));       // (A/B only: reproduces the lost updates)
-#else
     float t = a * w0;
     asm("" : "+v"(t));
     t = __builtin_fmaf(b, w1, t);
@@ -107,7 +93,6 @@ __device__ __forceinline__ float interp3(float a, float b, float d, float w0, fl
     t = __builtin_fmaf(d, w2, t);
     asm("" : "+v"(t));
     return t;
-#endif
 }
 
 // Work-group barrier of the persistent kernels that hand plain LDS stores from one wave to another: an explicit wait for the wave's LDS
@@ -116,9 +101,7 @@ __device__ __forceinline__ float interp3(float a, float b, float d, float w0, fl
 // the interpolated tile before the stores had landed (a few hundred wrong elements per launch under load; round 4, tools/race_hunt.py).
 // Only lgkmcnt: the gather loads in flight across the barrier must not be waited for.
 __device__ __forceinline__ void wg_sync() {
-#ifndef LSDM_WGSYNC_BARE      // (defined only to show tools/barrier_wait_check.py the compiler's own output)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __syncthreads();
 }
 

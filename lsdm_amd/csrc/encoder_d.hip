@@ -241,11 +241,11 @@ __global__ __launch_bounds__(256) void fp_plan_kernel(const int* __restrict__ or
     dst[1] = make_int4(rec[2][0], rec[2][1], rec[3][0], rec[3][1]);
 }
 
-template <int N, int S, int D1, int C1, int C2>
+template <int N, int S, int D1, int C1, int C2, int NP>
 __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ points1, const float* __restrict__ y, const int* __restrict__ plan,
                                                    const float* __restrict__ nn_w, DenseH l1, DenseH l2, float* __restrict__ out, int p1_mod, int total_tiles) {
     using namespace fpd;
-    constexpr int NP = 2, NWM = 4;
+    constexpr int NWM = 4;
     constexpr int LDB = ldh(C1), PB = TM * LDB, LDX = ldh(D1), PX = TM * LDX;
     constexpr int KS1 = D1 / 16, KS2 = C1 / 16, NCB = C1 / 32 / NWM;
     constexpr int TPC = N / TM;                                   // tiles per cloud
@@ -287,7 +287,10 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
             for (int q = 0; q < NCB; ++q) {
                 const __bf16* wp = l1.w + ((size_t)((aw + q * NWM) * 32 + p) * NP) * 16 + 8 * h;
 #pragma unroll
-                for (int u = 0; u < KS1; ++u) { w1h[q][u] = gload<bf16x8>(wp + (size_t)u * ws); w1l[q][u] = gload<bf16x8>(wp + (size_t)u * ws + 16); }
+                for (int u = 0; u < KS1; ++u) {
+                    w1h[q][u] = gload<bf16x8>(wp + (size_t)u * ws);
+                    if constexpr (NP == 2) w1l[q][u] = gload<bf16x8>(wp + (size_t)u * ws + 16); else w1l[q][u] = w1h[q][u];
+                }
             }
 #pragma unroll
             for (int q = 0; q < NCB; ++q)
@@ -366,13 +369,18 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
                 const __bf16* xp = &bufX[i & 1][0] + pv * LDX + 8 * hv;
                 bf16x8 xh[KS1], xl[KS1];
 #pragma unroll
-                for (int u = 0; u < KS1; ++u) { xh[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * u); xl[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * u + PX); }
+                for (int u = 0; u < KS1; ++u) {
+                    xh[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * u);
+                    if constexpr (NP == 2) xl[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * u + PX);
+                }
 #pragma unroll
                 for (int u = 0; u < KS1; ++u)
 #pragma unroll
                     for (int q = 0; q < NCB; ++q) {
-                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xl[u], acc[q][0], 0, 0, 0);
-                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[q][u], xh[u], acc[q][0], 0, 0, 0);
+                        if constexpr (NP == 2) {
+                            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xl[u], acc[q][0], 0, 0, 0);
+                            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1l[q][u], xh[u], acc[q][0], 0, 0, 0);
+                        }
                         acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1h[q][u], xh[u], acc[q][0], 0, 0, 0);
                     }
             }
@@ -403,7 +411,10 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
         const size_t ws2 = (size_t)C2 * NP * 16;
         const __bf16* wp2 = l2.w + ((size_t)(cb2 * 32 + p) * NP) * 16 + 8 * h;
 #pragma unroll
-        for (int u = 0; u < KS2; ++u) { w2h[u] = gload<bf16x8>(wp2 + (size_t)u * ws2); w2l[u] = gload<bf16x8>(wp2 + (size_t)u * ws2 + 16); }
+        for (int u = 0; u < KS2; ++u) {
+            w2h[u] = gload<bf16x8>(wp2 + (size_t)u * ws2);
+            if constexpr (NP == 2) w2l[u] = gload<bf16x8>(wp2 + (size_t)u * ws2 + 16); else w2l[u] = w2h[u];
+        }
 #pragma unroll
         for (int u = 0; u < KS2; ++u) asm volatile("" : "+v"(w2h[u]), "+v"(w2l[u]));
     }
@@ -469,9 +480,12 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
             for (int r = 0; r < 16; ++r) a2[r] = 0.0f;
 #pragma unroll
             for (int u = 0; u < KS2; ++u) {
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(bp + u * 16), xl = *reinterpret_cast<const bf16x8*>(bp + u * 16 + PB);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, w2h[u], a2, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w2l[u], a2, 0, 0, 0);
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(bp + u * 16);
+                if constexpr (NP == 2) {
+                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(bp + u * 16 + PB);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, w2h[u], a2, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w2l[u], a2, 0, 0, 0);
+                }
                 a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, w2h[u], a2, 0, 0, 0);
             }
             FD_MARK(0);
@@ -516,18 +530,18 @@ __global__ __launch_bounds__(512) void fp_d_kernel(const float* __restrict__ poi
 // The points of a cloud are walked along `order` (optional; cloud c % order_mod's when order_mod > 0: the source cloud's Z curve); position -> point -> neighbour list -> rows is a chain of three dependent
 // loads, each link requested one iteration ahead of the next.
 namespace fpc {
-constexpr int TM = 32, C = 128, KS = C / 16, NB = C / 32, NP = 2, NL = 4;
+constexpr int TM = 32, C = 128, KS = C / 16, NB = C / 32, NL = 4;
 constexpr int ROWE = C + 8;              // bf16 elements per point and plane in an LDS tile (272 bytes: consecutive points start 4 banks apart)
 constexpr int PLANE = TM * ROWE;
-constexpr int FL = NB * KS * NP;         // 1 KiB fragments per layer in the blob
 }  // namespace fpc
 
-template <int N, int S>
+template <int N, int S, int NP>
 __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ points2, const int* __restrict__ nn_idx, const float* __restrict__ nn_w,
                                                    const __bf16* __restrict__ blob_w, const float* __restrict__ blob_b, float* __restrict__ out,
                                                    const int* __restrict__ order, int order_mod, int total_tiles) {
     using namespace fpc;
     constexpr int TPC = N / TM;
+    constexpr int FL = NB * KS * NP;         // 1 KiB fragments per layer in the blob
     __shared__ __attribute__((aligned(16))) __bf16 X[NL][2][NP * PLANE];          // X[s]: input tile of stage s
     __shared__ __attribute__((aligned(16))) float part[2][64 * 16];               // conv2's accumulators between its two halves
     __shared__ __attribute__((aligned(16))) float bl[NL * C + 32];
@@ -548,7 +562,8 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 wh[q][s] = gload<bf16x8>(wb + ((size_t)(((2 * half + q) * KS + s) * NP + 0) * 64 + lane) * 8);
-                wl[q][s] = gload<bf16x8>(wb + ((size_t)(((2 * half + q) * KS + s) * NP + 1) * 64 + lane) * 8);
+                if constexpr (NP == 2) wl[q][s] = gload<bf16x8>(wb + ((size_t)(((2 * half + q) * KS + s) * NP + 1) * 64 + lane) * 8);
+                else wl[q][s] = wh[q][s];
             }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -567,15 +582,21 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
             for (int j = 0; j < 4; ++j) { a0[4 * qq + j] = b0[j]; a1[4 * qq + j] = b1[j]; }
         }
         const __bf16* xp = xin + pv * ROWE + 8 * hv;
-        bf16x8 xh = *reinterpret_cast<const bf16x8*>(xp), xl = *reinterpret_cast<const bf16x8*>(xp + PLANE);
+        bf16x8 xh = *reinterpret_cast<const bf16x8*>(xp), xl = xh;
+        if constexpr (NP == 2) xl = *reinterpret_cast<const bf16x8*>(xp + PLANE);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bf16x8 ch = xh, cl = xl;
-            if (s + 1 < KS) { xh = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 1)); xl = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 1) + PLANE); }
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][s], cl, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][s], cl, a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[0][s], ch, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[1][s], ch, a1, 0, 0, 0);
+            if (s + 1 < KS) {
+                xh = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 1));
+                if constexpr (NP == 2) xl = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 1) + PLANE);
+            }
+            if constexpr (NP == 2) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][s], cl, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][s], cl, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[0][s], ch, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[1][s], ch, a1, 0, 0, 0);
+            }
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[0][s], ch, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[1][s], ch, a1, 0, 0, 0);
         }
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
                 if (xout) {      // k-step 2 (2 half + q) + s2 of the next layer, this lane's 8 k-slots: one 16-byte piece per plane
                     __bf16* d = xout + pv * ROWE + 16 * (2 * (2 * half + q) + s2) + 8 * hv;
                     *reinterpret_cast<bf16x8*>(d) = yh[2 * q + s2];
-                    *reinterpret_cast<bf16x8*>(d + PLANE) = yl[2 * q + s2];
+                    if constexpr (NP == 2) *reinterpret_cast<bf16x8*>(d + PLANE) = yl[2 * q + s2];
                 }
             }
     };
@@ -700,7 +721,8 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             w5h[s] = gload<bf16x8>(w5g + ((size_t)((4 * half + s) * NP + 0) * 64 + lane) * 8);
-            w5l[s] = gload<bf16x8>(w5g + ((size_t)((4 * half + s) * NP + 1) * 64 + lane) * 8);
+            if constexpr (NP == 2) w5l[s] = gload<bf16x8>(w5g + ((size_t)((4 * half + s) * NP + 1) * 64 + lane) * 8);
+            else w5l[s] = w5h[s];
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(w5h[s]), "+v"(w5l[s]));
@@ -727,8 +749,10 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], w5h[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5l[s], acc, 0, 0, 0);
+                    if constexpr (NP == 2) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], w5h[s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5l[s], acc, 0, 0, 0);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5h[s], acc, 0, 0, 0);
                 }
                 const int t = R.first + tj * R.stride;
@@ -755,8 +779,10 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], w5h[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5l[s], acc, 0, 0, 0);
+                    if constexpr (NP == 2) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s], w5h[s], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5l[s], acc, 0, 0, 0);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s], w5h[s], acc, 0, 0, 0);
                 }
 #pragma unroll
@@ -771,10 +797,13 @@ __global__ __launch_bounds__(512) void fp_c_kernel(const float* __restrict__ poi
     FC_FLUSH(3, ntile + 6);
 }
 
-void launch_fp_c(int nc, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st,
+void launch_fp_c(int np, int nc, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out, hipStream_t st,
                  const int* order, int order_mod) {
     const int total = 1024 / fpc::TM * nc;
-    hipLaunchKernelGGL((fp_c_kernel<1024, 1024>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points2, nn_idx, nn_w, blob_w, blob_b, out, order, order_mod, total);
+    if (np == 2)
+        hipLaunchKernelGGL((fp_c_kernel<1024, 1024, 2>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points2, nn_idx, nn_w, blob_w, blob_b, out, order, order_mod, total);
+    else
+        hipLaunchKernelGGL((fp_c_kernel<1024, 1024, 1>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points2, nn_idx, nn_w, blob_w, blob_b, out, order, order_mod, total);
 }
 
 void launch_morton_order(int nc, const float* xyz, int* order, hipStream_t st) {
@@ -786,9 +815,12 @@ void launch_fp_plan(int nc, const int* order, int order_mod, const int* idx1, co
 }
 
 // fp2 (1024 fine <- 256 coarse points per cloud, D1 = 64) on the plan of its clouds
-void launch_fp_d(int nc, const float* points1, const float* ybuf, const float* nn_w, DenseH l1a, DenseH l2, float* out, const int* plan, hipStream_t st, int p1_mod) {
+void launch_fp_d(int np, int nc, const float* points1, const float* ybuf, const float* nn_w, DenseH l1a, DenseH l2, float* out, const int* plan, hipStream_t st, int p1_mod) {
     const int total = 1024 / fpd::TM * nc;
-    hipLaunchKernelGGL((fp_d_kernel<1024, 256, 64, 256, 128>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, ybuf, plan, nn_w, l1a, l2, out, p1_mod, total);
+    if (np == 2)
+        hipLaunchKernelGGL((fp_d_kernel<1024, 256, 64, 256, 128, 2>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, ybuf, plan, nn_w, l1a, l2, out, p1_mod, total);
+    else
+        hipLaunchKernelGGL((fp_d_kernel<1024, 256, 64, 256, 128, 1>), dim3(total < 256 ? total : 256), dim3(512), 0, st, points1, ybuf, plan, nn_w, l1a, l2, out, p1_mod, total);
 }
 
 }  // namespace lsdm

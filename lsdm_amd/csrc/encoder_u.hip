@@ -1029,7 +1029,6 @@ int fp2_ws() {
 // ybuf: the stage's pre-multiplied operand Y = coarse output x Wb^T -- written by the coarser stage's launch (which = 2, 3: y_ready) or here from
 // fpo_coarse (which = 4).  wb_next / ynext (which = 3, 4): the next finer stage's Y = out x wb_next^T as one more layer of this launch; `out` itself is
 // then stored only when keep_out.
-// (fp2 -- which = 2 -- exists in the two-plane form only: fp_d_kernel / fp_pre_kernel<64, ...> take np = 2 operands in every mode.)
 void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p1_remap, const float* fpo_coarse, DenseH wb, float* ybuf,
                    const int* nn_idx, const float* nn_w, DenseH l1a, DenseH l2, float* out, bool y_ready, DenseH wb_next, float* ynext,
                    bool keep_out, hipStream_t st, int p1_mod, const int* plan) {
@@ -1044,11 +1043,11 @@ void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p
     }
     (void)y_ready; (void)S;
     if (which == 2 && plan) {
-        launch_fp_d(nc, points1, ybuf, nn_w, l1a, l2, out, plan, st, p1_mod);
+        launch_fp_d(np, nc, points1, ybuf, nn_w, l1a, l2, out, plan, st, p1_mod);
     }
     else if (which == 2) {
-        hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, 4>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256, l1a, l2, out,
-                           none, nullptr, 1, p1_mod);
+        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<64, 256, 128, false, 64, 4, NPK>), dim3(1024 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 1024, 256,
+                                       l1a, l2, out, none, nullptr, 1, p1_mod));
     }
     else {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover

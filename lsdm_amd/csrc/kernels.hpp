@@ -106,7 +106,7 @@ void launch_sa_r(int np, int level, int num_clouds, const float* src_xyz, const 
 // fp1 + head as one register-chained stack (bf16x3), a pipeline of stages with register-resident weights (encoder_d.hip: fp_c_kernel):
 // points2 (nc,1024,128) fp32, out (nc,1024,3)
 // order (optional): walk each cloud's points in that order (cloud c % order_mod's when order_mod > 0) -- results do not depend on it
-void launch_fp_c(int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
+void launch_fp_c(int np, int num_clouds, const float* points2, const int* nn_idx, const float* nn_w, const __bf16* blob_w, const float* blob_b, float* out,
                  hipStream_t st, const int* order = nullptr, int order_mod = 0);
 // encoder_u.hip (bf16x3): first SA layer split across the grouping -- U = X x Wf^T + xyz x Wx^T + b, V = xyz x Wx^T per source
 // point (level 1: sa2, 64 -> 64; level 2: sa3, 128 -> 128; level 3: sa4, 256 -> 256), then the two remaining layers on
@@ -154,7 +154,7 @@ size_t fp_plan_ints(int N);
 int fp2_ws();      // LSDM_FP2_WS (read per launch): 4 = fp_d_kernel
 void launch_morton_order(int num_clouds, const float* xyz, int* order, hipStream_t st);
 void launch_fp_plan(int num_clouds, const int* order, int order_mod, const int* idx1, const int* nn_idx, const int* p1_remap, int* plan, hipStream_t st);
-void launch_fp_d(int num_clouds, const float* points1, const float* ybuf, const float* nn_w, DenseH l1a, DenseH l2, float* out, const int* plan, hipStream_t st,
+void launch_fp_d(int np, int num_clouds, const float* points1, const float* ybuf, const float* nn_w, DenseH l1a, DenseH l2, float* out, const int* plan, hipStream_t st,
                  int p1_mod);
 // cond.hip
 // G = number of consecutive steps covered by the launch (t, e0, tr, w hold G*B rows; text / cats / mask are per sample)

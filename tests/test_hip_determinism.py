@@ -99,6 +99,10 @@ def test_bench_json_line_carries_the_contract_fields():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     # executed <= reference FLOPs (split first layers, the memo, the item lists); x3 matrix instructions per executed product
     assert 0 < rf["frac_executed"] <= rf["frac"] and abs(rf["mfma_issue_frac"] - 3 * rf["frac_executed"]) < 1e-9 and rf["mfma_issue_frac"] < 1.0
+    # every stage of the list: executed work within the matrix pipe's issue rate and not above the stage's reference work; the reference-FLOP
+    # column only where the launches execute that work
+    assert rf["guard_violations"] == [] and all(k["mfma_issue_frac"] < 1.0 for k in rf["kernels"])
+    assert all(k["tflops"] is None or k["tflops"] <= 2500.0 / 3 * 1.02 for k in rf["kernels"]), [(k["name"], k["tflops"]) for k in rf["kernels"]]
     assert set(r["fill_path"]["stages"]) >= {"fp_kernel<fp2>", "fp_kernel<fp1+head>"} and 0 < r["fill_path"]["stages"]["fp_kernel<fp1+head>"]["frac_of_l2_ceiling"] < 1.0
     assert r["repeats"]["final_sample_bit_identical_to_timed_region"] is True
     cf = r["configs"]

@@ -222,7 +222,7 @@ def test_scene_encoder_vs_oracle_and_golden(model13, sd13, golden):
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("bf16", 0.6)])
 def test_scene_encoder_split_bf16_levels_vs_oracle_and_golden(sd13, golden, precision, tol):
     """Every level of the encoder on the split-bf16 core (bf16x3: three matrix instructions per product; bf16: one, through the same
-    kernels -- sa1, fp2 and fp1 + head keep two planes there) against the oracle's taps and the reference's recorded output (G3, incl.
+    kernels -- only sa1 keeps two planes there) against the oracle's taps and the reference's recorded output (G3, incl.
     the all-zero cloud)."""
     g = golden("g3_pointnet")
     clouds = T(g["clouds"])

@@ -208,6 +208,13 @@ def test_traffic_json_matches_the_latest_kernel_record():
         if isinstance(e, dict):
             for k in e["launches"]:
                 assert k.split("<")[0].replace("lsdm::", "") in record, (stage, k)
+    # ... and that record is of ONE workload (round 5's averaged B = 16 and B = 64 launches: sa_w min 70 / avg 252 / max 342 us): from round 6 on the
+    # dominant dense kernel's fastest launch must lie within 20 % of its average
+    if int(tag[1:3]) >= 6:
+        import csv
+        rows = list(csv.DictReader(open(with_pmc[-1].replace(".md", ".csv"))))
+        dom = max((r for r in rows if "sa_w_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+        assert float(dom["MinNs"]) >= 0.8 * float(dom["AverageNs"]), (dom["Name"][:40], dom["MinNs"], dom["AverageNs"])
 
 
 def test_bench_rank_bookkeeping_world8_gloo_stub():
