@@ -1,6 +1,6 @@
 """Static check of the compiled kernels (hipcc --save-temps .s files): every s_barrier must be preceded, on EVERY path, by
 `s_waitcnt lgkmcnt(0)` after the wave's last LDS store -- hipcc (ROCm 7.2, gfx950) was seen to drop that wait at a loop-header barrier
-(fp_ws_kernel, round 4; common.hpp::wg_sync).  Walks the control-flow graph backwards from each barrier.
+(a wave-specialised kernel of round 4; common.hpp::wg_sync).  Walks the control-flow graph backwards from each barrier.
     python tools/barrier_wait_check.py /tmp/allasm/*.s"""
 import re
 import sys

@@ -41,9 +41,8 @@ def main():
     m, diff = create_model_and_diffusion("proxd")   # precision from LSDM_PRECISION (f32 | bf16x3 | bf16)
     m.load_state_dict(sd)
     print("precision:", m.precision)
-    bf = m.precision == "bf16"
-    fdt = torch.bfloat16 if bf else torch.float32
-    fname = (lambda n: n + "_bf") if bf else (lambda n: n)
+    fdt = torch.float32          # (level features and FP outputs are fp32 tensors in every precision mode)
+    fname = lambda n: n
     bt = make_synthetic_batch(B, seed=5)
     torch.manual_seed(11)
     x0 = torch.randn(B, 1024, 3)
@@ -66,7 +65,7 @@ def main():
         rep(n + ".fps_idx", ws(m, "fps_idx%d" % (l + 1), (nc, S[l]), torch.int32), taps[n + ".fps_idx"])
         rep(n + ".new_xyz", ws(m, "xyz%d" % (l + 1), (nc, S[l], 3)), taps[n + ".new_xyz"])
         rep(n + ".ball_idx", ws(m, "ball%d" % (l + 1), (nc, S[l], 32), torch.int32), taps[n + ".ball_idx"])
-        rep(n + ".new_points", ws(m, ("feat_bf%d" if bf else "feat%d") % (l + 1), (nc, S[l], Cc[l]), fdt).float(), taps[n + ".new_points"])
+        rep(n + ".new_points", ws(m, "feat%d" % (l + 1), (nc, S[l], Cc[l])), taps[n + ".new_points"])
     for i, (n, N) in enumerate((("fp4", 64), ("fp3", 256), ("fp2", 1024), ("fp1", 1024))):
         rep(n + ".nn_idx", ws(m, "nn_idx%d" % (i + 1), (nc, N, 3), torch.int32), taps[n + ".nn_idx"])
         rep(n + ".nn_w", ws(m, "nn_w%d" % (i + 1), (nc, N, 3)), taps[n + ".nn_w"])

@@ -21,7 +21,7 @@ python - <<PY
 import json
 d=json.load(open("$R/gpurun_out/pmcmem_$TAG.json"))
 for k,v in d.items():
-    if any(s in k for s in ("fp_ws","fp_pre_kernel<64","fp_s_kernel","sa_w_kernel","sa_p_kernel","sa_ur","fp_pre_kernel<128")):
+    if any(s in k for s in ("fp_d_kernel","fp_c_kernel","sa_w_kernel","sa_p_kernel","sa_ur","fp_pre_kernel<128","fp_pre_kernel<256")):
         print(k[:50])
         for c in sorted(v): print("    %-44s %14.0f  (%d launches)"%(c, v[c]["mean_per_launch"], v[c]["launches"]))
 PY
