@@ -54,7 +54,7 @@ typedef enum {
     LSDM_PREC_F32 = 0,      /* exact fp32 products: v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain)            */
     LSDM_PREC_BF16X3 = 1,   /* fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate:
                              * fp32-class results (dropped term 2^-18 relative) at 5.3x the f32 MFMA rate       */
-    LSDM_PREC_BF16 = 2      /* plain bf16 products, fp32 accumulate; level features stored as bf16             */
+    LSDM_PREC_BF16 = 2      /* plain bf16 products (one MFMA per product), fp32 accumulate and fp32 level features     */
 } lsdm_precision;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------- */
@@ -121,7 +121,12 @@ LSDM_API int lsdm_sample_steps(lsdm_ctx* ctx, int mode, float eta, int B, int t_
  * are computed once; each step only re-orders them (feature rows, 3-NN positions with the per-step tie rule re-applied).
  * The arithmetic and its operands are those of lsdm_sample_steps -- results are bit-identical (tests) -- unlike the hoisted
  * variant below, which changes the random stream.  Clouds whose finest FPS is not a permutation (duplicated points) fall
- * back to the per-step 3-NN inside the kernel. */
+ * back to the per-step 3-NN inside the kernel.
+ * Degenerate clouds: a cloud whose 1024 points are bit-identical (the zero padding of a scene with fewer than eight objects,
+ * posa/dataset.py:456) has an encoder output independent of the FPS draws (farthest_point_sample returns [start, 0, 0, ...], every
+ * ball is indices 0..31: pointnet2_utils.py:60-104); the call classifies the clouds (ONE host synchronisation on `stream`, in front
+ * of its other work), evaluates one representative per distinct such cloud once and runs the per-step encoder on the others only.
+ * Results are bit-identical with and without it (LSDM_DEG_FAST=0). */
 LSDM_API int lsdm_sample_steps_invariant(lsdm_ctx* ctx, int mode, float eta, int B, int t_first, int K, float* x, const float* mask,
                                 const float* given_objs, const float* given_cats, const float* text_feat,
                                 const int64_t* fps_start_steps, const float* noise_steps, float* out_cat, float* out_x0,

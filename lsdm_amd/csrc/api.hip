@@ -304,9 +304,9 @@ constexpr double SA1_ITEM = 32.0 * (16 * 32 + 32 * 32 + 32 * 64);
 constexpr double SA3_UV = 256.0 * 128 * 128, SA3_ITEM = 32.0 * (128 * 128 + 128 * 256), SA4_UV = 64.0 * 256 * 256, SA4_ITEM = 32.0 * (256 * 256 + 256 * 512);
 constexpr double SA3 = 256.0 * 128 * 128 + 2048.0 * (128 * 128 + 128 * 256), SA3_FULL = 2048.0 * (144 * 128 + 128 * 128 + 128 * 256);
 constexpr double SA4 = 64.0 * 256 * 256 + 512.0 * (256 * 256 + 256 * 512), SA4_FULL = 512.0 * (272 * 256 + 256 * 256 + 256 * 512);
-constexpr double FP4_PRE = 16.0 * 512 * 256 + 64.0 * 3 * 256 * 256, FP4_Y = 64.0 * (768 * 256 + 2 * 256 * 256), FP4_FULL = 64.0 * (768 * 256 + 256 * 256);
-constexpr double FP3_PRE = 256.0 * (128 * 256 + 256 * 256), FP3_OWN_Y = 64.0 * 256 * 256, FP3_NEXT_Y = 256.0 * 256 * 256, FP3_FULL = 256.0 * (384 * 256 + 256 * 256);
-constexpr double FP2_PRE = 1024.0 * (64 * 256 + 256 * 128), FP2_OWN_Y = 256.0 * 256 * 256, FP2_FULL = 1024.0 * (320 * 256 + 256 * 128);
+constexpr double FP4_PRE = 16.0 * 512 * 256 + 64.0 * 3 * 256 * 256, FP4_FULL = 64.0 * (768 * 256 + 256 * 256);
+constexpr double FP3_PRE = 256.0 * (128 * 256 + 256 * 256), FP3_NEXT_Y = 256.0 * 256 * 256, FP3_FULL = 256.0 * (384 * 256 + 256 * 256);
+constexpr double FP2_PRE = 1024.0 * (64 * 256 + 256 * 128), FP2_FULL = 1024.0 * (320 * 256 + 256 * 128);
 constexpr double FP1 = 1024.0 * (4 * 128 * 128 + 128 * 32);
 constexpr double DEN_PASS = 32.0 * 132 * 16384, DEN_S = 32.0 * 48 * 16384;   // denoise_reg.hip RL<>: products per 32-point block x 32 blocks per chain
 constexpr double UP12_HALF = 128.0 * 128 * 512, CTEXT_HALF = 1024.0 * 128 * 512 + 1024.0 * 128 * 128;   // per row (sample or step), one half of the 256 rows
@@ -1725,7 +1725,6 @@ static int sample_steps_impl(lsdm_ctx* c, bool inv, int mode, float eta, int B, 
             launch_sa(0, nc, enc_clouds, enc_clouds, enc_clouds, c->inv_ball, c->sa[0], static_cast<float*>(c->inv_F1), si);
             prof_exec(c, K_SA1, nc * kKernelMacs[K_SA1]);
         } else {
-            const int np = c->prec == LSDM_PREC_BF16X3 ? 2 : 1;
             const bool items1 = c->sa_pair && (long long)nc * kN < kItemRowLimit;
             if (!items1) prof_exec(c, K_SA1, nc * xm::SA1);
             if (items1) {

@@ -619,8 +619,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define LSDM_SAW_SPREAD 1
 #endif
     constexpr bool SPREAD = LSDM_SAW_SPREAD != 0;
-    constexpr int PPS = (FP / NW) / (KS / 2);        // pieces per k-step over the first half of the k loop
-    static_assert(!SPREAD || (FP / NW) % (KS / 2) == 0, "spread");
+#ifndef LSDM_SAW_SPREAD_STEPS
+#define LSDM_SAW_SPREAD_STEPS (KS / 2)
+#endif
+    constexpr int SST = (FP / NW) < (LSDM_SAW_SPREAD_STEPS) ? (FP / NW) : (LSDM_SAW_SPREAD_STEPS);       // k-steps of a panel's k loop that issue copies of the next panel (from the first one on)
+    constexpr int PPS = (FP / NW) / SST;             // pieces per k-step
+    static_assert(!SPREAD || (FP / NW) % SST == 0, "spread");
     fetch(0);
     lds_dma_wait();
     __syncthreads();
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     f0l = wfrag_lds_u<NP>(W, KS, 0, s + 1, NP - 1, lane); f1l = wfrag_lds_u<NP>(W, KS, 1, s + 1, NP - 1, lane);
                 }
                 if constexpr (SPREAD) {
-                    if (s < KS / 2) {
+                    if (s < SST) {
 #pragma unroll
                         for (int i = 0; i < PPS; ++i) fetch_piece((q + 1) % NPANEL, s * PPS + i);
                     }
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     f0l = wfrag_lds_u<NP>(W, KS, 0, s + 1, NP - 1, lane); f1l = wfrag_lds_u<NP>(W, KS, 1, s + 1, NP - 1, lane);
                 }
                 if constexpr (SPREAD) {
-                    if (s < KS / 2) {
+                    if (s < SST) {
 #pragma unroll
                         for (int i = 0; i < PPS; ++i) fetch_piece((NB2 / PB + q + 1) % NPANEL, s * PPS + i);
                     }
