@@ -1027,9 +1027,12 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B * g, 0, f.h2p, st);
         prof_exec(c, K_UP12, np == 0 ? B * g * kKernelMacs[K_UP12] : B * g * xm::UP12_HALF);
         // per-sample timesteps: the timestep half of combine_extraction's pre-activation per (step, sample) row
+        // (ctext_kernel evaluates the timestep / text halves of combine_extraction's pre-activation: work the reference counts in the denoiser
+        // -- timed and accounted with that stage, weight 0: not a launch of it)
         if (np != 0 && c->den_reg && g == 1) {
+            prof_mark(c, K_DENOISE, st, 0);
             launch_ctext(np, c->den_h, B, f.h2p, c->ct_time, true, st);
-            prof_exec(c, K_UP12, B * xm::CTEXT_HALF);
+            prof_exec(c, K_DENOISE, B * xm::CTEXT_HALF);
         }
     } else if (!reuse_hm) {
         // per call: the sample rows (text / category embeddings, attention weights, translation tokens) of set 0
@@ -1040,8 +1043,10 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         if (np != 0) {
             prof_mark(c, K_UP12, st);
             launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, B, 128, c->h2x, st);
+            prof_exec(c, K_UP12, B * xm::UP12_HALF);
+            prof_mark(c, K_DENOISE, st, 0);
             launch_ctext(np, c->den_h, B, c->h2x, c->ctext, false, st);
-            prof_exec(c, K_UP12, B * (xm::UP12_HALF + xm::CTEXT_HALF));
+            prof_exec(c, K_DENOISE, B * xm::CTEXT_HALF);
         }
         prof_mark(c, K_POSA, st);
         launch_posa(c->posa, given_objs, B, c->posa_ws, c->hm, st);
@@ -1054,8 +1059,10 @@ void run_conditioning(lsdm_ctx* c, FrontSet& f, int B, int g, const int64_t* t, 
         launch_cond_time(c->cond, t, B, g, f.e0, st);
         prof_mark(c, K_UP12, st);
         launch_upsample12(np, f.e0, c->up0, c->up2.w, c->up2.b, g, 0, f.h2p, st);
+        prof_exec(c, K_UP12, g * xm::UP12_HALF);      // one row per STEP: every chain of the batch is at the same timestep
+        prof_mark(c, K_DENOISE, st, 0);
         launch_ctext(np, c->den_h, g, f.h2p, c->ct_time, true, st);
-        prof_exec(c, K_UP12, g * (xm::UP12_HALF + xm::CTEXT_HALF));      // one row per STEP: every chain of the batch is at the same timestep
+        prof_exec(c, K_DENOISE, g * xm::CTEXT_HALF);
     }
     prof_mark(c, -1, st);
 }
