@@ -272,10 +272,12 @@ def _b64_check(tag, errs, ties):
                 assert e[key][1] <= tol * max(1.0, e["scale"] / 4.0 if key == "sample" else 1.0), (tag, prec, k, key, e, ties[k])
 
 
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1])
 def test_config3_b64_mixed_timesteps_one_step(seed):
     """One p_sample step at the benched batch with a DIFFERENT timestep per chain (t_b = (991 - 7 b) mod 1000: the whole schedule in one batch --
-    tools/parity_b64.py's case, where the raw per-step sample sits at 8.8e-4 through the 3-NN tie order alone)."""
+    tools/parity_b64.py's case, where the raw per-step sample sits at 8.5e-4 .. 1.0e-3 through the 3-NN tie order alone).  (An oracle step at
+    B = 64 is a minute of host time: the suite runs this case on seed 1 and the segment below on seed 2; tools/parity_b64_mid.py runs both on both
+    seeds with five-step segments -- profiles/r06_parity_extra.txt.)"""
     B = 64
     torch.manual_seed(seed)
     x = torch.randn(B, 1024, 3)
@@ -283,11 +285,11 @@ def test_config3_b64_mixed_timesteps_one_step(seed):
     _b64_check("mixed-t seed %d" % seed, *_b64_case(seed, ts, x))
 
 
-@pytest.mark.parametrize("seed,K", [(1, 5), (2, 2)])
+@pytest.mark.parametrize("seed,K", [(2, 3)])
 def test_config3_b64_mid_schedule_segment(seed, K):
     """Steps t = 524 .. 524 - K + 1 at the benched batch from x_524 = q_sample(0, 524, noise) (p_sample_loop(skip_timesteps=475)'s start): the
-    guidance term and coef2 are at full weight here, unlike at t = 999 .. 997.  (Five steps on the first seed, two on the second: an oracle
-    step at B = 64 is a minute of host time; tools/parity_b64_mid.py runs five on both -- profiles/r06_parity_extra.txt.)"""
+    guidance term and coef2 are at full weight here, unlike at t = 999 .. 997 -- on the seed whose raw per-step sample exceeds 1e-3 in bf16x3
+    through the tie order alone (1.03e-3 .. 1.11e-3; 7e-5 .. 3.4e-4 of a sample that has grown to 37 with the choice injected)."""
     B = 64
     _, diff = create_model_and_diffusion("proxd")
     torch.manual_seed(10 + seed)
