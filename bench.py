@@ -121,9 +121,12 @@ def parity_check(precision, dev):
     torch.cuda.synchronize()
     return {"max_abs_sample": float((out["sample"].cpu() - ref["sample"]).abs().max()),
             "max_abs_pred_xstart": float((out["pred_xstart"].cpu() - ref["pred_xstart"]).abs().max()),
-            "at_the_benched_batch": "tests/test_hip_configs.py::test_config3_b64_* (pytest -m gpu): B=64, 8 objects, C=13, K=3 steps vs the oracle "
-                                    "with stage taps -- FPS / ball indices equal on all 576 clouds x 4 levels, 3-NN distances bit-identical, "
-                                    "sample <= 1e-3 raw and <= 5e-5 (f32) / 1e-4 (bf16x3) with the kernel's equally-near neighbour choice injected",
+            "at_the_benched_batch": "tests/test_hip_configs.py::test_config3_b64_* (pytest -m gpu): B=64, 8 objects, C=13, steps from t=999, one step with a "
+                                    "different timestep per chain and a mid-schedule segment vs the oracle with stage taps -- FPS / ball indices equal on all "
+                                    "576 clouds x 4 levels, 3-NN distances bit-identical; what the caller reads (pred_xstart, guiding points, saved_cat) <= 1e-3 "
+                                    "raw (measured <= 1.2e-4); a per-step sample <= 5e-5 (f32) / 1e-4 (bf16x3) of its magnitude with the kernel's equally-near "
+                                    "neighbour choice injected into the oracle (raw: up to 1.1e-3 through the reference's unspecified order of exactly tied "
+                                    "3-NN distances, profiles/r06_parity_extra.txt)",
             "against": "CPU oracle (oracle/cpu_ref.py, pinned to goldens recorded from the reference), one p_sample step, B=2, t=900"}
 
 
