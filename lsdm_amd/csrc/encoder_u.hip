@@ -820,11 +820,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // fine point are gathered and interpolated cooperatively (coalesced 16-byte pieces, fp32, no bf16 split) into an LDS tile
 // from which every wave initialises its accumulators; the matrix pipe then only contracts over the D1 columns of p1.
 // One LDS region is reused in sequence: interpolated tile (fp32) -> p1 operand tile -> layer-1 activations.
+// SL > 0 (fp3, fp4: a cloud has 64 / 16 coarse rows, 64 / 16 KB): no gather and no tile -- the cloud's Y rows land in LDS whole (round 6; phase
+// table before / after in profiles/r06_fp_pre_phase.txt: requests + interpolation 8.7 -> 5.4 us of a work-group's 32.7 -> 30.9, fp3 169 -> 161 us).
 // FUSE: the stage's output feeds ONLY the next finer stage's interpolation (fp3 -> fp2), whose first layer is pre-multiplied at THIS
 // level: ynext = out x Wb_next^T is one more layer on the rows that are already on chip -- no separate row-wise GEMM launch, no
 // re-read of `out` (which is then stored only when keep_out: the parity taps of the stage entry points).
 // TM_ x NW_: 64 rows x 4 waves, two work-groups per CU; or 128 rows x 8 waves, one per CU (half the weight stream per row).
-template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4, int NP_ = 2>
+#ifdef LSDM_PHASE_TIMING
+// per-phase s_memtime sums of wave 0 of every work-group (tools/fppre_phase.py), by D1 (64: fp2's reference form, 128: fp3, 256: fp4): 3 x 8 slots --
+// 0 requests + interpolation -> tile, 1 accumulators <- tile, 2 p1 tile + layer-1 k loops, 3 layer-1 epilogue, 4 layer-2 k loops, 5 layer-2
+// epilogue -> next tile, 6 extra layer (or the plain layer 2 of the unfused form) + stores, 7 = work-groups
+__device__ unsigned long long g_fppre_phase[64 * 24];
+#define FPP_T0() unsigned long long pt_ = __builtin_amdgcn_s_memtime(); unsigned long long pd_[7] = {}
+#define FPP_MARK(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pd_[slot] += n_ - pt_; pt_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FPP_FLUSH(D1V) do { if (threadIdx.x == 0) { unsigned long long* g_ = g_fppre_phase + (blockIdx.x & 63) * 24 + ((D1V) == 64 ? 0 : ((D1V) == 128 ? 8 : 16)); \
+        for (int i_ = 0; i_ < 7; ++i_) atomicAdd(g_ + i_, pd_[i_]); atomicAdd(g_ + 7, 1ull); } } while (0)
+extern "C" __attribute__((visibility("default"))) int lsdm_debug_fppre_phase(unsigned long long* out24, int reset) {
+    static unsigned long long h[64 * 24], z[64 * 24];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fppre_phase), sizeof h) != hipSuccess) return -1;
+    for (int s = 0; s < 24; ++s) { out24[s] = 0; for (int c = 0; c < 64; ++c) out24[s] += h[c * 24 + s]; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fppre_phase), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#else
+#define FPP_T0() do {} while (0)
+#define FPP_MARK(slot) do {} while (0)
+#define FPP_FLUSH(D1V) do {} while (0)
+#endif
+template <int D1, int C1, int C2, bool FUSE = false, int TM_ = 64, int NW_ = 4, int NP_ = 2, int SL = 0>
 __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kernel(const float* __restrict__ points1, const int* __restrict__ p1_remap,
                                                         const float* __restrict__ y, const int* __restrict__ nn_idx,
                                                         const float* __restrict__ nn_w, int N, int S, DenseH l1, DenseH l2,
@@ -840,7 +863,12 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     static_assert(C1 % 64 == 0, "tile rows: whole bank rounds");
     auto tile_swz = [](int row) -> int { return (((row & 1) | ((row & 2) << 2) | (((row >> 2) & 3) << 1)) << 2); };
     constexpr int LDX = ldh(D1), PX = TM * LDX, LDB = ldh(C1), PB = TM * LDB, LDC = ldh(C2), PC = TM * LDC;
-    constexpr int BYTES = imax(imax(imax(TM * LDT * 4, NP * PX * 2), NP * PB * 2), FUSE ? NP * PC * 2 : 0);
+    // SL > 0 (fp3: 64, fp4: 16 coarse points per cloud): ALL the cloud's Y rows land in LDS once, by LDS-DMA (one 1 KB row per wave instruction, no
+    // index in front of the request: they leave with the index loads), and the accumulators are interpolated straight out of them as in
+    // fp_d_kernel -- no gathered 192 KB per tile, no interpolated tile.  Same three rows, same interp3, same order: bit-identical.
+    constexpr int RS = 260;                                    // floats per landed row (1 KB + 16 bytes: consecutive rows start four banks apart)
+    static_assert(SL == 0 || C1 == 256, "a landed row is one 1 KB wave copy");
+    constexpr int BYTES = imax(imax(imax(imax(SL > 0 ? 0 : TM * LDT * 4, SL * RS * 4), NP * PX * 2), NP * PB * 2), FUSE ? NP * PC * 2 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char region[BYTES];
     float* tile = reinterpret_cast<float*>(region);
     __bf16* bufX = reinterpret_cast<__bf16*>(region);
@@ -860,30 +888,46 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     // three neighbour indices and weights of phase A -- one L2 round trip for all of them, then the p1 rows and the Y rows go out
     // back to back.  (With the p1 rows fetched through their indices first, phase A's indices waited a whole round trip behind them:
     // fp2 333 us in the loop-invariant schedule against 303 in the strict one, whose p1 rows are contiguous.)
+    FPP_T0();
+    if constexpr (SL > 0) {
+        const unsigned dst0 = lds_addr(tile);
+        for (int r = wave; r < SL; r += NW) lds_dma16(yb + (size_t)r * C1 + 4 * lane, __builtin_amdgcn_readfirstlane(dst0 + (unsigned)r * (RS * 4)));
+    }
     const int arow = tid / TPP, sub = tid % TPP;
-    const size_t ao = ((size_t)c * N + n0 + arow) * 3;
+    const size_t ao = ((size_t)c * N + n0 + (SL > 0 ? p : arow)) * 3;    // (SL: the lane's point of row block 0; block rb is 96 words further)
     int xrow[XIT];
     if (p1_remap) {
 #pragma unroll
         for (int it = 0; it < XIT; ++it) xrow[it] = p1_remap[(size_t)c * N + n0 + (tid + it * NT) / (D1 / 4)];
     }
-    const int i0 = nn_idx[ao + 0], i1 = nn_idx[ao + 1], i2 = nn_idx[ao + 2];
-    const float w0 = nn_w[ao + 0], w1 = nn_w[ao + 1], w2 = nn_w[ao + 2];
+    constexpr int NRB = SL > 0 ? TM / 32 : 1;                 // (SL: the three rows and weights of the lane's point in every row block)
+    int ni[NRB][3];
+    float nw[NRB][3];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { ni[rb][j] = nn_idx[ao + 96 * rb + j]; nw[rb][j] = nn_w[ao + 96 * rb + j]; }
+    // SL: ONE round trip in front of the accumulators -- the landed rows and every index; the p1 rows (a second, dependent one through
+    // p1_remap) are requested behind that wait and fly under phase B (`late` pins their address arithmetic behind the wait)
+    int late = 0;
+    if constexpr (SL > 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(late) : : "memory");
     if (p1_remap) {
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int e = tid + it * NT;
             const int row = e / (D1 / 4), c4 = e - row * (D1 / 4);
             // (p1_mod > 0: a launch over the clouds of several steps; points1 is the per-CALL tensor in source order, cloud c % p1_mod)
-            gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? c % p1_mod : c) * N + xrow[it]) * D1 + 4 * c4);
+            gx[it] = load4f(points1 + ((size_t)(p1_mod > 0 ? c % p1_mod : c) * N + (xrow[it] + late)) * D1 + 4 * c4);
         }
     } else {
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4);
+        for (int it = 0; it < XIT; ++it) gx[it] = load4f(p1 + (size_t)(tid + it * NT) * 4 + late);
     }
     // ---- phase A: interpolated Y rows -> fp32 tile.  Four threads per fine point, 16 pieces (of 4 channels) each ------------
-    {
+    if constexpr (SL == 0) {
         const int row = arow;
+        const int i0 = ni[0][0], i1 = ni[0][1], i2 = ni[0][2];
+        const float w0 = nw[0][0], w1 = nw[0][1], w2 = nw[0][2];
         const float* r0 = yb + (size_t)i0 * C1;
         const float* r1 = yb + (size_t)i1 * C1;
         const float* r2 = yb + (size_t)i2 * C1;
@@ -914,6 +958,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
         }
     }
     __syncthreads();
+    FPP_MARK(0);
     // ---- phase B: accumulators start from the interpolated rows (transposed product: lane owns channels 8q + 4h + j of point p)
     using TS = SplitH<NW, TM, C1>;
     constexpr int NCB = TS::CB / TS::CSTEP;
@@ -921,20 +966,38 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     constexpr int RB1 = TS::RB;
     const int cb0 = wave % TS::CSTEP;
     f32x16 acc[NCB][RB1];
+    if constexpr (SL > 0) {
+        static_assert(SL == 0 || RB1 == NRB, "one set of neighbours per row block of the wave");
 #pragma unroll
-    for (int q = 0; q < NCB; ++q)
+        for (int rb = 0; rb < RB1; ++rb) {
+            const float *r0 = tile + ni[rb][0] * RS + 4 * h, *r1 = tile + ni[rb][1] * RS + 4 * h, *r2 = tile + ni[rb][2] * RS + 4 * h;
 #pragma unroll
-        for (int rb = 0; rb < RB1; ++rb)
+            for (int q = 0; q < NCB; ++q)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int ch = (cb0 + q * TS::CSTEP) * 32 + 8 * qd;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(r0 + ch), b = *reinterpret_cast<const f32x4*>(r1 + ch), d = *reinterpret_cast<const f32x4*>(r2 + ch);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = t[j];
-            }
+                    for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = interp3(a[j], b[j], d[j], nw[rb][0], nw[rb][1], nw[rb][2]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NCB; ++q)
+#pragma unroll
+            for (int rb = 0; rb < RB1; ++rb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(tile + (rb * 32 + p) * LDT + (((cb0 + q * TS::CSTEP) * 32 + 8 * qd + 4 * h) ^ tile_swz(p)));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[q][rb][4 * qd + j] = t[j];
+                }
+    }
     f32x4 bv1[NCB][4];
 #pragma unroll
     for (int q = 0; q < NCB; ++q) load_bias_h(bv1[q], l1.b, cb0 + q * TS::CSTEP, lane);
     __syncthreads();
+    FPP_MARK(1);
     // ---- phase C: p1 operand tile, K = D1 -----------------------------------------------------------------------------------
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
@@ -947,10 +1010,12 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
     for (int q = 0; q < NCB; ++q)
         mma_kloop_h<RB1, NP, true, D1 / 16>(acc[q], bufX, LDX, PX, l1.w, C1, cb0 + q * TS::CSTEP, 0, lane);
     __syncthreads();
+    FPP_MARK(2);
     // ---- phase D: layer-1 epilogue -> bufB, layer 2 (direct orientation) -> global -----------------------------------------------
 #pragma unroll
     for (int q = 0; q < NCB; ++q) store_lds_h<ACT_RELU, RB1, NP>(acc[q], 0, cb0 + q * TS::CSTEP, bv1[q], bufB, LDB, PB, lane);
     __syncthreads();
+    FPP_MARK(3);
     using T2 = SplitH<NW, TM, C2>;
     const int cb2 = wave % T2::CSTEP, rg2 = wave / T2::CSTEP;
     if constexpr (!FUSE) {
@@ -984,6 +1049,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
             mma_kloop_h<RB2, NP, true, C1 / 16>(a2[q], bufB, LDB, PB, l2.w, C2, cb2 + q * T2::CSTEP, 0, lane);
         }
         __syncthreads();
+        FPP_MARK(4);
 #pragma unroll
         for (int q = 0; q < NCB2; ++q) {
             const int cb = cb2 + q * T2::CSTEP;
@@ -999,6 +1065,7 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
             store_lds_b_h<ACT_RELU, RB2, NP>(a2[q], 0, cb, bufC, LDC, PC, lane);
         }
         __syncthreads();
+        FPP_MARK(5);
         using T3 = SplitH<NW, TM, 256>;
         const int cb3 = wave % T3::CSTEP, rg3 = wave / T3::CSTEP;
 #pragma unroll 1
@@ -1016,6 +1083,8 @@ __global__ __launch_bounds__(NW_ * 64, TM_ == 64 ? NW_ / 2 : 1) void fp_pre_kern
                 }
         }
     }
+    FPP_MARK(6);
+    FPP_FLUSH(D1);
 }
 
 // Every launcher below takes np, the number of bf16 planes of the operands and of the weight blobs handed in: 2 = bf16x3 (three matrix
@@ -1041,7 +1110,7 @@ void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p
     if (which == 4) {
         // fp4: 64 fine <- 16 coarse points per cloud, D1 = 256, the coarse features are 512 wide
         LSDM_NP(np, hipLaunchKernelGGL((lin_u_kernel<512, 256, false, NPK>), dim3((nc * 16 + 63) / 64), dim3(256), 0, st, fpo_coarse, nullptr, nc * 16, wb, nullptr, ybuf, nullptr));
-        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true, 64, 4, NPK>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16,
+        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<256, 256, 256, true, 64, 4, NPK, 16>), dim3(64 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 64, 16,
                                        l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0, p1_mod));
         return;
     }
@@ -1055,8 +1124,9 @@ void launch_fp_pre(int np, int which, int nc, const float* points1, const int* p
     }
     else {
         // (128-row tiles on one 8-wave work-group per CU were measured slower, 175 vs 156 us: two independent work-groups per CU cover
-        // each other's gather and barrier phases)
-        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 64, 4, NPK>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64,
+        // each other's gather and barrier phases; 64 rows on EIGHT waves, four per SIMD at 128 registers: 240 vs 169 us, fp4 98 vs 54 --
+        // profiles/r06_fp_pre_phase.txt)
+        LSDM_NP(np, hipLaunchKernelGGL((fp_pre_kernel<128, 256, 256, true, 64, 4, NPK, 64>), dim3(256 / 64 * nc), dim3(256), 0, st, points1, p1_remap, ybuf, nn_idx, nn_w, 256, 64,
                                        l1a, l2, out, wb_next, ynext, keep_out ? 1 : 0, p1_mod));
     }
 }
