@@ -4,10 +4,12 @@
 
 A "step" is one p_sample iteration (SceneDiffusionModel.forward + posterior update) of the whole per-GPU batch:
 BASELINE.json configs[2] -- B = 64 chains, 9 slots x 1024 points (8 objects = the 8192-pt scene cloud, + the human
-branch), C = 13, cosine T = 1000 -- with STRICT per-step recompute of everything the reference recomputes (PointNet++
-with freshly drawn FPS starts, conditioning MLPs).  Inputs, weights and the RNG draws of the timed steps (host
-generator, reference order) are resident in HBM before the timed region; the K steps run inside ONE C-ABI call
-(lsdm_sample_steps) on one stream.  Ranks are independent chain batches (seed = base + rank); the only
+branch), C = 13, cosine T = 1000 -- every step with freshly drawn FPS starts and its own conditioning, as the reference
+recomputes them.  Inputs, weights and the RNG draws of the timed steps (host generator, reference order) are resident
+in HBM before the timed region; the K steps run inside ONE C-ABI call: lsdm_sample_steps_invariant (default -- what
+p_sample_loop calls: the work that does not depend on the FPS draws is evaluated once per call, inside the timed call;
+bit-identical to the strict entry point, checked every run) with lsdm_sample_steps (every stage every step) reported
+beside it as `strict_recompute`.  Ranks are independent chain batches (seed = base + rank); the only
 collective is one all-gather of the final samples.
 
 dtype (--precision): "bf16x3" (default) = fp32 operands split into bf16 hi+lo, three bf16 MFMAs per product, fp32
@@ -30,8 +32,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (before the HIP runtime loads): RCCL needs it on this driver
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
