@@ -217,6 +217,12 @@ def test_traffic_json_matches_the_latest_kernel_record():
         assert float(dom["MinNs"]) >= 0.8 * float(dom["AverageNs"]), (dom["Name"][:40], dom["MinNs"], dom["AverageNs"])
 
 
+def test_design_md_keeps_its_own_size_rule():
+    """DESIGN.md describes the code as it is and stays within 40 KiB; measurements and negative results go to docs/HISTORY.md."""
+    n = os.path.getsize(os.path.join(ROOT, "DESIGN.md"))
+    assert n <= 40 * 1024, "DESIGN.md is %d bytes (> 40 KiB): move history to docs/HISTORY.md" % n
+
+
 def test_bench_rank_bookkeeping_world8_gloo_stub():
     """The driver's 8-GPU command line -- `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W` -- with the GPU
     work stubbed at the Runner boundary (--stub-runner: gloo, CPU, no library call): everything AROUND the kernels is bench.py's real code.  Eight
